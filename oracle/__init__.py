@@ -1,0 +1,261 @@
+"""ctypes loader for the CPU ORACLE (test infrastructure only).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.  It is a
+checker, never the thing shipped or measured as the product.  PARITY UNPINNED -- see slr_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libslr_oracle.so")
+_lib = None
+
+MF_PLANES = 14
+PI_F = np.float32(3.1416)
+
+
+class Camera(C.Structure):
+    """Mirror of slro_camera (virtualcamera.h:27-37 fields the path reads)."""
+    _fields_ = [("fc", C.c_float * 2), ("cc", C.c_float * 2), ("k", C.c_float * 5),
+                ("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+    @staticmethod
+    def make(fc, cc, k, R=None, t=None):
+        cam = Camera()
+        cam.fc[:] = [float(v) for v in fc]
+        cam.cc[:] = [float(v) for v in cc]
+        kk = list(k) + [0.0] * (5 - len(k))
+        cam.k[:] = [float(v) for v in kk]
+        R = np.eye(3) if R is None else np.asarray(R)
+        t = np.zeros(3) if t is None else np.asarray(t)
+        cam.R[:] = [float(v) for v in R.reshape(-1)]
+        cam.t[:] = [float(v) for v in t.reshape(-1)]
+        return cam
+
+
+def build(force=False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "slr_oracle.c")
+    if (not force and os.path.exists(_LIB_PATH)
+            and (not os.path.exists(src) or os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src))):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.slro_gray_num_bits.restype = C.c_int
+        _lib.slro_gen_graycodes.restype = C.c_int
+        _lib.slro_gray_to_dec.restype = C.c_int
+        _lib.slro_wrapped_phase.restype = C.c_int
+        _lib.slro_heterodyne.restype = C.c_float
+        _lib.slro_line_line_intersection.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _planes_ptrs(planes):
+    """planes: ndarray [N][H][pitch] u8 (C-contiguous) -> array of N row-0 pointers + pitch."""
+    assert planes.dtype == np.uint8 and planes.ndim == 3 and planes.flags.c_contiguous
+    n = planes.shape[0]
+    arr = (C.c_void_p * n)()
+    for i in range(n):
+        arr[i] = planes[i].ctypes.data
+    return arr, planes.shape[2]
+
+
+# ---- encoders ---------------------------------------------------------------------------------
+def gray_num_bits(n):
+    return lib().slro_gray_num_bits(C.c_int(n))
+
+
+def gen_multifreq(projW, projH):
+    out = np.empty((MF_PLANES, projH, projW), np.uint8)
+    lib().slro_gen_multifreq(C.c_int(projW), C.c_int(projH), _p(out))
+    return out
+
+
+def gen_graycodes(scanW, scanH, use_epi):
+    ncol, nrow = gray_num_bits(scanW), gray_num_bits(scanH)
+    n = 2 + 2 * ncol + (0 if use_epi else 2 * nrow)
+    out = np.empty((n, scanH, scanW), np.uint8)
+    r = lib().slro_gen_graycodes(C.c_int(scanW), C.c_int(scanH), C.c_int(1 if use_epi else 0), _p(out))
+    assert r == n
+    return out
+
+
+def gray_to_dec(bits):
+    b = np.ascontiguousarray(bits, np.uint8)
+    return lib().slro_gray_to_dec(_p(b), C.c_int(b.size))
+
+
+# ---- remap -------------------------------------------------------------------------------------
+def remap_u8(src, map_xy, map_frac):
+    src = np.ascontiguousarray(src, np.uint8)
+    H, W = src.shape
+    assert map_xy.shape == (H, W, 2) and map_xy.dtype == np.int16 and map_xy.flags.c_contiguous
+    assert map_frac.shape == (H, W) and map_frac.dtype == np.uint16 and map_frac.flags.c_contiguous
+    dst = np.empty((H, W), np.uint8)
+    lib().slro_remap_u8(_p(src), C.c_int(W), C.c_int(W), C.c_int(H), _p(map_xy), _p(map_frac),
+                        _p(dst), C.c_int(W))
+    return dst
+
+
+def init_undistort_rectify_map(M, D, R, P, W, H):
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    D = np.ascontiguousarray(D, np.float64).reshape(5)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    P = np.ascontiguousarray(P, np.float64).reshape(12)
+    xy = np.empty((H, W, 2), np.int16)
+    fr = np.empty((H, W), np.uint16)
+    lib().slro_init_undistort_rectify_map(_p(M), _p(D), _p(R), _p(P), C.c_int(W), C.c_int(H),
+                                          _p(xy), _p(fr))
+    return xy, fr
+
+
+# ---- decode ------------------------------------------------------------------------------------
+def mf_decode(planes, black_thr, W=None):
+    """planes [14][H][pitch] u8 -> (phase [H][W] f32, valid [H][W] u8)."""
+    ptrs, pitch = _planes_ptrs(planes)
+    H = planes.shape[1]
+    W = pitch if W is None else W
+    phase = np.empty((H, W), np.float32)
+    valid = np.empty((H, W), np.uint8)
+    lib().slro_mf_decode(ptrs, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
+                         _p(phase), _p(valid))
+    return phase, valid
+
+
+def wrapped_phase(G1, G2, G3, G4):
+    P = C.c_float(0)
+    ok = lib().slro_wrapped_phase(C.c_int(G1), C.c_int(G2), C.c_int(G3), C.c_int(G4), C.byref(P))
+    return bool(ok), np.float32(P.value)
+
+
+def heterodyne(P):
+    a = (C.c_double * 3)(*[float(v) for v in P])
+    return np.float32(lib().slro_heterodyne(a))
+
+
+def gray_decode(planes, n_col_bits, n_row_bits, black_thr, white_thr, scan_w, scan_h, W=None):
+    ptrs, pitch = _planes_ptrs(planes)
+    H = planes.shape[1]
+    W = pitch if W is None else W
+    cx = np.empty((H, W), np.int32)
+    cy = np.empty((H, W), np.int32)
+    valid = np.empty((H, W), np.uint8)
+    lib().slro_gray_decode(ptrs, C.c_int(n_col_bits), C.c_int(n_row_bits), C.c_int(pitch),
+                           C.c_int(W), C.c_int(H), C.c_int(black_thr), C.c_int(white_thr),
+                           C.c_int(scan_w), C.c_int(scan_h), _p(cx), _p(cy), _p(valid))
+    return cx, cy, valid
+
+
+# ---- triangulation -----------------------------------------------------------------------------
+def undistort_point(px, py, cam):
+    ox, oy = C.c_float(0), C.c_float(0)
+    lib().slro_undistort_point(C.c_float(px), C.c_float(py), C.byref(cam), C.byref(ox), C.byref(oy))
+    return np.float32(ox.value), np.float32(oy.value)
+
+
+def _q(Q):
+    return np.ascontiguousarray(Q, np.float64).reshape(16)
+
+
+def _t(T):
+    return None if T is None else np.ascontiguousarray(T, np.float32).reshape(12)
+
+
+def mf_triangulate(phaseL, validL, phaseR, validR, camL, camR, Q, T=None, rows=None):
+    H, W = phaseL.shape
+    xyz = np.zeros((H, W, 3), np.float32)
+    has = np.zeros((H, W), np.uint8)
+    mk = np.full((H, W), -1, np.int32)
+    Qa, Ta = _q(Q), _t(T)
+    r0, r1 = (0, H) if rows is None else rows
+    lib().slro_mf_triangulate_rows(_p(np.ascontiguousarray(phaseL, np.float32)), _p(np.ascontiguousarray(validL)),
+                                   _p(np.ascontiguousarray(phaseR, np.float32)), _p(np.ascontiguousarray(validR)),
+                                   C.c_int(W), C.c_int(H), C.c_int(r0), C.c_int(r1),
+                                   C.byref(camL), C.byref(camR), _p(Qa), _p(Ta), _p(xyz), _p(has), _p(mk))
+    return xyz, has, mk
+
+
+def ge_triangulate(codeL, validL, codeR, validR, Q, T=None, whiteL=None, whiteR=None):
+    H, W = codeL.shape
+    xyz = np.zeros((H, W, 3), np.float32)
+    has = np.zeros((H, W), np.uint8)
+    mk = np.full((H, W), -1, np.int32)
+    color = np.zeros((H, W), np.uint8) if whiteL is not None else None
+    Qa, Ta = _q(Q), _t(T)
+    wl = None if whiteL is None else np.ascontiguousarray(whiteL, np.uint8)
+    wr = None if whiteR is None else np.ascontiguousarray(whiteR, np.uint8)
+    lib().slro_ge_triangulate(_p(np.ascontiguousarray(codeL, np.int32)), _p(np.ascontiguousarray(validL)),
+                              _p(np.ascontiguousarray(codeR, np.int32)), _p(np.ascontiguousarray(validR)),
+                              C.c_int(W), C.c_int(H), _p(Qa), _p(Ta), _p(wl), _p(wr),
+                              _p(xyz), _p(has), _p(color), _p(mk))
+    return xyz, has, color, mk
+
+
+def gray_bucket(code_x, code_y, valid, scan_w, scan_h):
+    H, W = code_x.shape
+    nb = scan_w * scan_h
+    offsets = np.zeros(nb + 1, np.int32)
+    items = np.zeros(max(1, H * W), np.uint32)
+    lib().slro_gray_bucket(_p(np.ascontiguousarray(code_x, np.int32)), _p(np.ascontiguousarray(code_y, np.int32)),
+                           _p(np.ascontiguousarray(valid)), C.c_int(W), C.c_int(H),
+                           C.c_int(scan_w), C.c_int(scan_h), _p(offsets), _p(items))
+    return offsets, items[:offsets[-1]].copy()
+
+
+def ray_triangulate(offL, itemsL, offR, itemsR, camL, camR, scan_w, scan_h, T=None):
+    xyz = np.zeros((scan_h, scan_w, 3), np.float32)
+    cnt = np.zeros((scan_h, scan_w), np.uint8)
+    Ta = _t(T)
+    iL = np.ascontiguousarray(itemsL, np.uint32) if itemsL.size else np.zeros(1, np.uint32)
+    iR = np.ascontiguousarray(itemsR, np.uint32) if itemsR.size else np.zeros(1, np.uint32)
+    lib().slro_ray_triangulate(_p(offL), _p(iL), _p(offR), _p(iR), C.byref(camL), C.byref(camR), _p(Ta),
+                               C.c_int(scan_w), C.c_int(scan_h), _p(xyz), _p(cnt))
+    return xyz, cnt
+
+
+def line_line_intersection(p1, v1, p2, v2):
+    a = [np.ascontiguousarray(v, np.float32) for v in (p1, v1, p2, v2)]
+    out = np.zeros(3, np.float32)
+    ok = lib().slro_line_line_intersection(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out))
+    return bool(ok), out
+
+
+def cam2world(cam, p):
+    a = np.ascontiguousarray(p, np.float32).copy()
+    lib().slro_cam2world(C.byref(cam), _p(a))
+    return a
+
+
+def pointcloud_from_grid(xyz, has, scan_w, scan_h, color=None):
+    H, W = has.shape
+    s = np.zeros((scan_h, scan_w, 3), np.float32)
+    c = np.zeros((scan_h, scan_w), np.uint8)
+    col = np.zeros((scan_h, scan_w), np.uint8) if color is not None else None
+    lib().slro_pointcloud_from_grid(_p(np.ascontiguousarray(xyz, np.float32)), _p(np.ascontiguousarray(has)),
+                                    _p(None if color is None else np.ascontiguousarray(color)),
+                                    C.c_int(W), C.c_int(H), C.c_int(scan_w), C.c_int(scan_h),
+                                    _p(s), _p(c), _p(col))
+    return s, c, col
+
+
+def pointcloud_get(pc_sum, pc_count):
+    n = pc_count.size
+    out = np.zeros((n, 3), np.float32)
+    lib().slro_pointcloud_get(_p(np.ascontiguousarray(pc_sum, np.float32)), _p(np.ascontiguousarray(pc_count)),
+                              C.c_int(n), _p(out))
+    return out.reshape(pc_count.shape + (3,))
