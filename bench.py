@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the structured-light hot path on MI355X.
+
+Metric (BASELINE.json): Mpixels/s of decode + unwrap + triangulate on synthetic 4096x3000 stereo x 14-image
+multi-frequency stacks (configs[1]).  One "step" = one stereo frame per GPU through the whole MF path
+(MFReconstruct::runReconstruction between imread and MeshCreator): fused rectify+decode of both cameras, then
+row-wise phase match + Q-matrix triangulation -> XYZ [H][W][3] + mask.  1 pixel = one (row, col) of one stereo
+frame.  Inputs are resident in HBM when the timed region starts.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): frames shard across ranks (weak scaling, no
+data-path collective inside the kernels); the per-step point cloud is assembled on every rank with one RCCL
+all-gather on a side stream, overlapped with the next step's compute (north_star: "RCCL all-gather over xGMI only
+to assemble the final point cloud").  --gather off measures the sharded path alone.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed inside the timed
+region on the kernels' own stream), "kernels" (all kernels), "cpu_baseline" (the CPU oracle on a bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+BLACK_THR = 40                 # Duke/Set.ui:429-431 default
+
+# algorithmic bytes per camera-pixel (or stereo-pixel for the match kernel) -- SURVEY.md 8(d), DESIGN.md
+ALG_BYTES = {
+    "slr_mf_rectify_decode": 25.0,     # 14 src + 6 map + 4 phase + 1 valid
+    "slr_mf_decode": 19.0,             # 12 fringe + 2 white/black + 4 phase + 1 valid
+    "slr_mf_match_triangulate": 23.0,  # 2x(4+1) read + 12 + 1 write
+    "slr_remap_u8": 8.0,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=3000)
+    ap.add_argument("--rectify", type=int, default=1, help="1: raw planes + fused rectification (the reference path)")
+    ap.add_argument("--gather", choices=["on", "off"], default="on", help="N>1: all-gather the point cloud every step")
+    ap.add_argument("--profile", type=int, default=1, help="bracket every kernel with HIP events (roofline)")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU triangulation sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
+    """The CPU oracle (a port of the reference loops, 1 thread like the reference) on a bounded sample of the same
+    workload: full-frame remap + decode for both cameras, triangulation on `rows` image rows (it is O(W^2) per
+    row), scaled to a per-frame time."""
+    import numpy as np
+    import oracle as O                      # checker / baseline only, never the product path
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import calib_parts
+    O.build()
+    camL, camR, Q, T = calib_parts(O, calib)
+    t0 = time.perf_counter()
+    dec = []
+    for cam in range(2):
+        planes = stack_cpu[cam]
+        if maps_cpu is not None:
+            planes = np.stack([O.remap_u8(planes[p], maps_cpu[cam][0], maps_cpu[cam][1]) for p in range(14)])
+        dec.append(O.mf_decode(planes, BLACK_THR))
+    t_dec = time.perf_counter() - t0
+    r0 = H // 2 - rows // 2
+    t0 = time.perf_counter()
+    O.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q, T, rows=(r0, r0 + rows))
+    t_tri = time.perf_counter() - t0
+    per_frame = t_dec + t_tri * (H / float(rows))
+    return {
+        "value": round(W * H / per_frame / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": "1 stereo frame %dx%d: full-frame remap+decode of both cameras (%.1f s) + match/triangulate on %d of %d "
+                  "rows (%.1f s), scaled to the frame; single thread, gcc -O2" % (W, H, t_dec, rows, H, t_tri),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
+                         (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    slr = importlib.import_module("structure-light-reconstructor_amd")
+    synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+    W, H = args.width, args.height
+
+    compute = torch.cuda.Stream(device=dev)
+    ctx = slr.Context(local, stream=compute)
+    calib, _ = synth.make_calibration(W, H)
+    ctx.set_calibration(calib)
+    maps = None
+    if args.rectify:
+        maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
+        torch.cuda.synchronize()
+        for cam in range(2):
+            ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    # one synthetic stereo frame per rank (seed 1234 + rank), resident in HBM
+    stack = synth.render_mf_stack(W, H, seed=1234 + rank, noise=2, device=dev).unsqueeze(0).contiguous()
+    torch.cuda.synchronize()
+
+    nbuf = 2
+    xyz = [torch.empty((1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    has = [torch.empty((1, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    do_gather = world > 1 and args.gather == "on"
+    if do_gather:
+        comm = torch.cuda.Stream(device=dev)
+        g_xyz = torch.empty((world, H, W, 3), dtype=torch.float32, device=dev)
+        g_has = torch.empty((world, H, W), dtype=torch.uint8, device=dev)
+        done_compute = [torch.cuda.Event() for _ in range(nbuf)]
+        done_gather = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def step(i):
+        b = i % nbuf
+        if do_gather:
+            compute.wait_event(done_gather[b])          # buffer b is free again once its gather finished
+        ctx.reconstruct_mf_batch(stack, BLACK_THR, bool(args.rectify), xyz=xyz[b], has=has[b])
+        if do_gather:
+            done_compute[b].record(compute)
+            comm.wait_event(done_compute[b])
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(g_xyz, xyz[b][0])
+                dist.all_gather_into_tensor(g_has, has[b][0])
+                done_gather[b].record(comm)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    if args.profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    ctx.timer_begin()
+    for i in range(args.steps):
+        step(i)
+    ev_ms = ctx.timer_end()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile() if args.profile else {}
+    if args.profile:
+        ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    npix = float(W) * H
+    value = world * npix * args.steps / elapsed / 1e6
+
+    kernels, roofline = [], None
+    for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        avg_ms = ms / n
+        entry = {"name": name, "launches": n, "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ms, 3)}
+        if name in ALG_BYTES:
+            gbs = ALG_BYTES[name] * npix / (avg_ms * 1e-3) / 1e9
+            entry.update({"alg_bytes_per_px": ALG_BYTES[name], "achieved_GBs": round(gbs, 1),
+                          "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        kernels.append(entry)
+    if kernels:
+        k0 = kernels[0]                                  # dominant kernel by total time in the timed region
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(k0["name"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0.get("achieved_GBs"), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": k0.get("frac_hbm_peak"), "traffic": traffic,
+                    "avg_launch_us": k0["avg_us"], "alg_bytes_per_launch": ALG_BYTES.get(k0["name"], 0) * npix}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        rows = args.cpu_rows or max(8, min(H, int(600 * (4096.0 / W) ** 2)))
+        maps_cpu = None if maps is None else [(m[0].cpu().numpy(), m[1].cpu().numpy()) for m in maps]
+        cpu = cpu_baseline(synth, W, H, stack[0].cpu().numpy(), maps_cpu, calib, rows)
+
+    if rank == 0:
+        out = {
+            "metric": "Mpixels/s decode+unwrap+triangulate, 4096x3000 stereo, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 in, f32 phase/XYZ (f64 undistort + Q reprojection)", "data": "synthetic",
+            "config": {"workload": "1x %dx%d stereo, 3-freq x 4-step (14 planes/camera) rectify+decode+unwrap+match+"
+                                   "triangulate per GPU per step" % (W, H),
+                       "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify),
+                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", RCCL all-gather of XYZ+mask per step"
+                                                                           if do_gather else "")},
+            "stream_event_ms_per_step": round(ev_ms / args.steps, 4),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

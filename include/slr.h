@@ -1,0 +1,189 @@
+/*
+ * slr.h -- C ABI of libslr_hip.so: the MI355X (gfx950) drop-in for the dense per-pixel loops of
+ * DrawZeroPoint/Structure-Light-Reconstructor ("Duke").
+ *
+ * The reference has NO plugin / FFI interface: the hot path is private member functions of
+ * MFReconstruct and Reconstruct, called synchronously from MainWindow::startreconstruct
+ * (Duke/mainwindow.cpp:562-652).  The boundary is therefore defined at the seam inside
+ *     MFReconstruct::runReconstruction      Duke/mfreconstruct.cpp:160-187
+ *     Reconstruct::runReconstruction_GE     Duke/reconstruct.cpp:271-307
+ *     Reconstruct::runReconstruction        Duke/reconstruct.cpp:230-265
+ * after cv::imread has produced the raw 8-bit planes (mfreconstruct.cpp:125, reconstruct.cpp:164) and
+ * before MeshCreator consumes points3DProjView (mainwindow.cpp:632-637).  Every entry point below names
+ * the reference function(s) it replaces.  INTEGRATION.md shows the ~40-line shim a maintainer adds to the
+ * Qt application.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns an slr_status (0 = ok, <0 error);
+ *     slr_last_error(ctx) gives the message (reference: bool + QMessageBox, mfreconstruct.cpp:62-63).
+ *   - images are row-major, 8-bit, `pitch` bytes between rows; all per-pixel outputs are dense [H][W].
+ *   - `mem` says where EVERY data pointer of that call lives: SLR_MEM_HOST (library stages through its
+ *     own device buffers and returns after the results are back on the host) or SLR_MEM_DEVICE (pointers
+ *     are HIP device pointers on the ctx's GPU; work is enqueued on the ctx stream and NOT synchronised).
+ *     Arrays of plane pointers (`planes`) are always host arrays; their elements follow `mem`.
+ *   - one ctx per GPU, one HIP stream per ctx; calls on one ctx must be serialised by the caller
+ *     (the reference is single-threaded; its hidden left/right flip-flop globals, reconstruct.cpp:4 and
+ *     mfreconstruct.cpp:4, are replaced by the explicit `cam` argument: 0 = left, 1 = right).
+ *   - there is NO CPU fallback: with no usable GPU slr_create fails with SLR_ERR_NO_DEVICE.
+ */
+#ifndef SLR_H
+#define SLR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLR_VERSION 100            /* 0.1.0 */
+#define SLR_MF_PLANES 14           /* mfreconstruct.cpp:22 numberOfImgs: white, black, 3 freq x 4 steps */
+#define SLR_MAX_GRAY_BITS 16       /* per axis; reference allows 44 planes total (graycodes.h:12) */
+#define SLR_MAX_GRAY_PLANES (2 + 4 * SLR_MAX_GRAY_BITS)
+
+typedef enum slr_status {
+    SLR_OK = 0,
+    SLR_ERR_INVALID_ARG = -1,
+    SLR_ERR_NO_DEVICE = -2,
+    SLR_ERR_HIP = -3,
+    SLR_ERR_NOT_CONFIGURED = -4,   /* calibration / rectify maps missing */
+    SLR_ERR_UNSUPPORTED = -5,
+    SLR_ERR_OOM = -6
+} slr_status;
+
+typedef enum slr_mem { SLR_MEM_HOST = 0, SLR_MEM_DEVICE = 1 } slr_mem;
+
+/* VirtualCamera (Duke/virtualcamera.h:27-37): the fields the path reads.  All f32 because the reference
+ * parses every calibration number through `float` (virtualcamera.cpp:82-84).  k[4] (k3) is carried but,
+ * like the reference (utilities.cpp:66), ignored by the undistortion. */
+typedef struct slr_camera {
+    float fc[2];      /* cam_matrix (0,0),(1,1) */
+    float cc[2];      /* cam_matrix (0,2),(1,2) */
+    float k[5];       /* cam_distortion 5x1 */
+    float R[9];       /* cam_rotation_matrix, row-major */
+    float t[3];       /* cam_trans_vectror */
+} slr_camera;
+
+typedef struct slr_calib {
+    slr_camera cam[2];   /* 0 = left, 1 = right */
+    double Q[16];        /* stereoRect::Q, 4x4 row-major f64 (stereorect.cpp:41) */
+    float T[12];         /* scan/transfer_mat<sn>.txt, 3x4 row-major (mfreconstruct.cpp:278-282) */
+    int has_T;           /* scanSN > 0 */
+} slr_calib;
+
+typedef struct slr_ctx slr_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------- */
+int          slr_version(void);
+const char  *slr_status_string(int status);
+int          slr_create(int device_id, slr_ctx **out);           /* replaces `new MFReconstruct()/Reconstruct()` mainwindow.cpp:577-582 */
+int          slr_destroy(slr_ctx *ctx);                          /* Reconstruct::~Reconstruct reconstruct.cpp:24-31 */
+int          slr_set_stream(slr_ctx *ctx, void *hip_stream);     /* borrow a caller stream (NULL -> ctx-owned stream) */
+int          slr_synchronize(slr_ctx *ctx);
+const char  *slr_last_error(const slr_ctx *ctx);
+
+/* ---- configuration ---------------------------------------------------------------------------------- */
+/* replaces MFReconstruct::loadCameras (mfreconstruct.cpp:67-108) / Reconstruct::loadCameras
+ * (reconstruct.cpp:99-148) + stereoRect::Q (stereorect.cpp:41): the host parses the text files, the
+ * library keeps the numbers. */
+int slr_set_calibration(slr_ctx *ctx, const slr_calib *calib);
+/* replaces the map half of stereoRect::calParameters (stereorect.cpp:42-43): map_xy = CV_16SC2 [H][W][2]
+ * (x,y), map_frac = CV_16UC1 [H][W]; copied into library-owned HBM. */
+int slr_set_rectify_maps(slr_ctx *ctx, int cam, const int16_t *map_xy, const uint16_t *map_frac,
+                         int W, int H, slr_mem mem);
+
+/* ---- K1: stereoRect::doStereoRectify -> cv::remap INTER_LINEAR (stereorect.cpp:26-34) ----------------- */
+int slr_remap_u8(slr_ctx *ctx, int cam, const uint8_t *src, int src_pitch,
+                 uint8_t *dst, int dst_pitch, int W, int H, slr_mem mem);
+
+/* ---- K2: MFReconstruct::computeShadows + decodePatterns + getPhase (mfreconstruct.cpp:190-269) -------
+ * planes[14] already rectified.  phase [H][W] f32 (0 where mask==0), valid [H][W] u8. */
+int slr_mf_decode(slr_ctx *ctx, const uint8_t *const planes[SLR_MF_PLANES], int pitch, int W, int H,
+                  int black_thr, float *phase, uint8_t *valid, slr_mem mem);
+/* fused K1+K2: loadCamImgs' 14x doStereoRectify (mfreconstruct.cpp:119-134) + the above, raw planes in */
+int slr_mf_rectify_decode(slr_ctx *ctx, int cam, const uint8_t *const planes[SLR_MF_PLANES], int pitch,
+                          int W, int H, int black_thr, float *phase, uint8_t *valid, slr_mem mem);
+
+/* ---- K3 / K3': Reconstruct::computeShadows + decodePatterns_GE/getProjPixel_GE (reconstruct.cpp:79-97,
+ * 210-227,381-407) or decodePaterns/getProjPixel (:56-74,:325-370) + GrayCodes::grayToDec
+ * (graycodes.cpp:116-128).  n_row_bits==0 -> GRAY_EPI (code_y may be NULL).  code = -1 where invalid. */
+int slr_gray_decode(slr_ctx *ctx, const uint8_t *const *planes, int n_col_bits, int n_row_bits,
+                    int pitch, int W, int H, int black_thr, int white_thr, int scan_w, int scan_h,
+                    int32_t *code_x, int32_t *code_y, uint8_t *valid, slr_mem mem);
+/* fused K1+K3 (GRAY_EPI rectifies every plane first, reconstruct.cpp:166-175) */
+int slr_gray_rectify_decode(slr_ctx *ctx, int cam, const uint8_t *const *planes, int n_col_bits,
+                            int n_row_bits, int pitch, int W, int H, int black_thr, int white_thr,
+                            int scan_w, int scan_h, int32_t *code_x, int32_t *code_y, uint8_t *valid,
+                            slr_mem mem);
+
+/* ---- K4: MFReconstruct::triangulation (mfreconstruct.cpp:272-334) + Utilities::undistortPoints
+ * (utilities.cpp:58-94).  Natural [H][W] output: xyz [H][W][3] f32 (0 where none), has [H][W] u8,
+ * match_k [H][W] i32 (-1 where none; may be NULL).  Uses ctx calibration (cam[0], cam[1], Q, T). */
+int slr_mf_triangulate(slr_ctx *ctx, const float *phaseL, const uint8_t *validL,
+                       const float *phaseR, const uint8_t *validR, int W, int H,
+                       float *xyz, uint8_t *has, int32_t *match_k, slr_mem mem);
+
+/* ---- K5: Reconstruct::triangulation_ge (reconstruct.cpp:555-611).  whiteL/whiteR: rectified white planes
+ * (pitch W) or NULL; color [H][W] u8 grey or NULL (haveColor, reconstruct.cpp:597-601). */
+int slr_ge_triangulate(slr_ctx *ctx, const int32_t *codeL, const uint8_t *validL,
+                       const int32_t *codeR, const uint8_t *validR, int W, int H,
+                       const uint8_t *whiteL, const uint8_t *whiteR,
+                       float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, slr_mem mem);
+
+/* ---- K3' scatter + K6: decodePaterns' bucket scatter (reconstruct.cpp:61-72, reconstruct.h:94-97) +
+ * Reconstruct::triangulation (reconstruct.cpp:417-481) + cam2WorldSpace (:310-322) + Utilities::
+ * pixelToImageSpace/normalize/line_lineIntersection (utilities.cpp:19-28,47-56,399-425) +
+ * PointCloudImage::addPoint accumulation (pointcloudimage.cpp:86-97).
+ * xyz_sum [scan_h][scan_w][3] f32, count [scan_h][scan_w] u8. */
+int slr_ray_triangulate(slr_ctx *ctx,
+                        const int32_t *code_xL, const int32_t *code_yL, const uint8_t *validL,
+                        const int32_t *code_xR, const int32_t *code_yR, const uint8_t *validR,
+                        int W, int H, int scan_w, int scan_h,
+                        float *xyz_sum, uint8_t *count, slr_mem mem);
+
+/* ---- PointCloudImage contract (pointcloudimage.cpp:3-97) ---------------------------------------------
+ * from_grid: what addPoint(i=row, j=col, p) against PointCloudImage(scan_w, scan_h) produces for the
+ * GE/MF modes: transposed + cropped (Q11): pc[j][i] iff i<scan_w && j<scan_h.
+ * pc_sum [scan_h][scan_w][3], pc_count [scan_h][scan_w], pc_color [scan_h][scan_w] (NULL ok). */
+int slr_pointcloud_from_grid(slr_ctx *ctx, const float *xyz, const uint8_t *has, const uint8_t *color,
+                             int W, int H, int scan_w, int scan_h,
+                             float *pc_sum, uint8_t *pc_count, uint8_t *pc_color, slr_mem mem);
+/* getPoint (pointcloudimage.cpp:56-67): out[n][3] = sum / (float)count, 0 where count==0 */
+int slr_pointcloud_get(slr_ctx *ctx, const float *pc_sum, const uint8_t *pc_count, size_t n,
+                       float *out, slr_mem mem);
+
+/* ---- whole-path drop-ins ----------------------------------------------------------------------------
+ * One call per stereo frame = the body of run*Reconstruction between imread and MeshCreator.
+ * rectify != 0: planes are RAW camera images and the ctx maps are applied (fused); 0: already rectified. */
+int slr_reconstruct_mf(slr_ctx *ctx, const uint8_t *const planesL[SLR_MF_PLANES],
+                       const uint8_t *const planesR[SLR_MF_PLANES], int pitch, int W, int H,
+                       int black_thr, int rectify,
+                       float *xyz, uint8_t *has, slr_mem mem);        /* MFReconstruct::runReconstruction */
+int slr_reconstruct_ge(slr_ctx *ctx, const uint8_t *const *planesL, const uint8_t *const *planesR,
+                       int n_col_bits, int pitch, int W, int H, int black_thr, int white_thr,
+                       int scan_w, int rectify, int have_color,
+                       float *xyz, uint8_t *has, uint8_t *color, slr_mem mem);  /* runReconstruction_GE */
+int slr_reconstruct_gray(slr_ctx *ctx, const uint8_t *const *planesL, const uint8_t *const *planesR,
+                         int n_col_bits, int n_row_bits, int pitch, int W, int H,
+                         int black_thr, int white_thr, int scan_w, int scan_h,
+                         float *xyz_sum, uint8_t *count, slr_mem mem);          /* runReconstruction */
+
+/* Device-resident batch fast path (frames of one GPU's shard).  stack = [n_frames][2 cams][14][H][pitch]
+ * contiguous u8 in HBM; xyz = [n_frames][H][W][3], has = [n_frames][H][W].  Always SLR_MEM_DEVICE. */
+int slr_reconstruct_mf_batch(slr_ctx *ctx, int n_frames, const uint8_t *stack, int pitch, int W, int H,
+                             int black_thr, int rectify, float *xyz, uint8_t *has);
+
+/* ---- measurement hooks (bench.py): HIP-event timing on the ctx stream ------------------------------ */
+int slr_timer_begin(slr_ctx *ctx);                 /* records an event on the ctx stream */
+int slr_timer_end(slr_ctx *ctx, float *ms);        /* records + synchronises, returns elapsed ms */
+/* per-kernel profiler: when enabled every kernel launch is bracketed by two HIP events on the ctx stream */
+int          slr_profile_enable(slr_ctx *ctx, int on);
+int          slr_profile_reset(slr_ctx *ctx);
+int          slr_profile_kernel_count(void);
+const char  *slr_profile_kernel_name(int kernel_id);
+int          slr_profile_get(slr_ctx *ctx, int kernel_id, double *total_ms, long *launches);   /* synchronises */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLR_H */

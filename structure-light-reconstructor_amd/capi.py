@@ -1,0 +1,399 @@
+"""ctypes binding of libslr_hip.so (include/slr.h) -- the only compute path of this package.
+
+numpy arrays are passed as SLR_MEM_HOST, torch CUDA tensors as SLR_MEM_DEVICE.  There is no CPU fallback:
+if the shared library is missing or no GPU is usable, an exception is raised (never a silent fallback).
+PyTorch is used only for device memory, streams and torch.distributed -- plumbing, not the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslr_hip.so")
+
+MF_PLANES = 14
+MAX_GRAY_BITS = 16
+MEM_HOST, MEM_DEVICE = 0, 1
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/slr.h declares (checked by tests/test_capi_symbols.py without a GPU)
+SYMBOLS = [
+    "slr_version", "slr_status_string", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
+    "slr_last_error", "slr_set_calibration", "slr_set_rectify_maps", "slr_remap_u8", "slr_mf_decode",
+    "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
+    "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch",
+    "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
+    "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
+]
+
+
+class SlrError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("slr status %d: %s" % (status, message))
+        self.status = status
+
+
+class Camera(C.Structure):
+    _fields_ = [("fc", C.c_float * 2), ("cc", C.c_float * 2), ("k", C.c_float * 5),
+                ("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class Calib(C.Structure):
+    _fields_ = [("cam", Camera * 2), ("Q", C.c_double * 16), ("T", C.c_float * 12), ("has_T", C.c_int)]
+
+
+def make_camera(fc, cc, k, R=None, t=None):
+    cam = Camera()
+    cam.fc[:] = [float(v) for v in fc]
+    cam.cc[:] = [float(v) for v in cc]
+    kk = list(k) + [0.0] * (5 - len(k))
+    cam.k[:] = [float(v) for v in kk]
+    R = np.eye(3) if R is None else np.asarray(R)
+    t = np.zeros(3) if t is None else np.asarray(t)
+    cam.R[:] = [float(v) for v in R.reshape(-1)]
+    cam.t[:] = [float(v) for v in t.reshape(-1)]
+    return cam
+
+
+def make_calib(camL, camR, Q, T=None):
+    cal = Calib()
+    cal.cam[0] = camL
+    cal.cam[1] = camR
+    cal.Q[:] = [float(v) for v in np.asarray(Q, np.float64).reshape(-1)]
+    if T is not None:
+        cal.T[:] = [float(v) for v in np.asarray(T, np.float32).reshape(-1)]
+        cal.has_T = 1
+    else:
+        cal.has_T = 0
+    return cal
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libslr_hip.so.  torch is imported first so that the HIP runtime already mapped by torch
+    (same SONAME libamdhip64.so.7) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libslr_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C structure-light-reconstructor_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (plumbing: makes torch's HIP runtime the process-wide one)
+    except Exception:  # pragma: no cover - torch is optional for pure C users
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.slr_status_string.restype = C.c_char_p
+    lib.slr_last_error.restype = C.c_char_p
+    lib.slr_profile_kernel_name.restype = C.c_char_p
+    lib.slr_last_error.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _mem_of(arrs):
+    kinds = set()
+    for a in arrs:
+        if a is None:
+            continue
+        if _is_torch(a):
+            if not a.is_cuda:
+                raise ValueError("torch tensors must live on the GPU (use numpy for host buffers)")
+            kinds.add(MEM_DEVICE)
+        else:
+            kinds.add(MEM_HOST)
+    if len(kinds) > 1:
+        raise ValueError("all buffers of one call must be host (numpy) or device (torch.cuda)")
+    return kinds.pop() if kinds else MEM_HOST
+
+
+def _ptr(a):
+    if a is None:
+        return C.c_void_p(None)
+    if _is_torch(a):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    assert a.flags.c_contiguous
+    return C.c_void_p(a.ctypes.data)
+
+
+def _plane_ptrs(planes):
+    """planes: [N][H][pitch] u8 ndarray/tensor, or a list of N [H][pitch] arrays -> (ptr array, N, H, pitch)."""
+    if isinstance(planes, (list, tuple)):
+        n = len(planes)
+        H, pitch = planes[0].shape
+        arr = (C.c_void_p * n)()
+        for i, p in enumerate(planes):
+            assert tuple(p.shape) == (H, pitch)
+            arr[i] = _ptr(p).value
+        return arr, n, H, pitch
+    n, H, pitch = planes.shape
+    base = _ptr(planes).value
+    arr = (C.c_void_p * n)()
+    for i in range(n):
+        arr[i] = base + i * H * pitch
+    return arr, n, H, pitch
+
+
+def _flat(planes):
+    return list(planes) if isinstance(planes, (list, tuple)) else [planes]
+
+
+class Context:
+    """One slr_ctx: one GPU, one HIP stream.  Mirrors the C ABI one to one."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.slr_create(C.c_int(device_id), C.byref(h))
+        if st != OK:
+            raise SlrError(st, self.lib.slr_status_string(st).decode())
+        self.h = h
+        self.device_id = device_id
+        if stream is not None:
+            self.set_stream(stream)
+
+    # -- plumbing
+    def _chk(self, st):
+        if st != OK:
+            msg = self.lib.slr_status_string(st).decode()
+            detail = self.lib.slr_last_error(self.h)
+            raise SlrError(st, msg + (" (" + detail.decode() + ")" if detail else ""))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.slr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t as int, a torch.cuda.Stream, or None for the ctx-owned stream."""
+        raw = getattr(stream, "cuda_stream", stream)
+        self._chk(self.lib.slr_set_stream(self.h, C.c_void_p(raw)))
+
+    def synchronize(self):
+        self._chk(self.lib.slr_synchronize(self.h))
+
+    def _new(self, like_mem, shape, dtype, like=None):
+        if like_mem == MEM_DEVICE:
+            import torch
+            tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+            return torch.empty(shape, dtype=tdt, device=like.device)
+        return np.empty(shape, dtype)
+
+    # -- configuration
+    def set_calibration(self, calib):
+        self._chk(self.lib.slr_set_calibration(self.h, C.byref(calib)))
+
+    def set_rectify_maps(self, cam, map_xy, map_frac):
+        H, W = map_frac.shape
+        mem = _mem_of([map_xy, map_frac])
+        self._chk(self.lib.slr_set_rectify_maps(self.h, C.c_int(cam), _ptr(map_xy), _ptr(map_frac),
+                                                C.c_int(W), C.c_int(H), C.c_int(mem)))
+
+    # -- K1
+    def remap_u8(self, cam, src, out=None):
+        H, W = src.shape
+        mem = _mem_of([src, out])
+        out = self._new(mem, (H, W), np.uint8, src) if out is None else out
+        self._chk(self.lib.slr_remap_u8(self.h, C.c_int(cam), _ptr(src), C.c_int(W), _ptr(out), C.c_int(W),
+                                        C.c_int(W), C.c_int(H), C.c_int(mem)))
+        return out
+
+    # -- K2
+    def mf_decode(self, planes, black_thr, W=None, rectify_cam=None, phase=None, valid=None):
+        ptrs, n, H, pitch = _plane_ptrs(planes)
+        assert n == MF_PLANES
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planes) + [phase, valid])
+        like = _flat(planes)[0]
+        phase = self._new(mem, (H, W), np.float32, like) if phase is None else phase
+        valid = self._new(mem, (H, W), np.uint8, like) if valid is None else valid
+        if rectify_cam is None:
+            st = self.lib.slr_mf_decode(self.h, ptrs, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
+                                        _ptr(phase), _ptr(valid), C.c_int(mem))
+        else:
+            st = self.lib.slr_mf_rectify_decode(self.h, C.c_int(rectify_cam), ptrs, C.c_int(pitch), C.c_int(W),
+                                                C.c_int(H), C.c_int(black_thr), _ptr(phase), _ptr(valid), C.c_int(mem))
+        self._chk(st)
+        return phase, valid
+
+    # -- K3 / K3'
+    def gray_decode(self, planes, n_col_bits, n_row_bits, black_thr, white_thr, scan_w, scan_h, W=None,
+                    rectify_cam=None):
+        ptrs, n, H, pitch = _plane_ptrs(planes)
+        assert n >= 2 + 2 * n_col_bits + 2 * n_row_bits
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planes))
+        like = _flat(planes)[0]
+        cx = self._new(mem, (H, W), np.int32, like)
+        cy = self._new(mem, (H, W), np.int32, like) if n_row_bits > 0 else None
+        valid = self._new(mem, (H, W), np.uint8, like)
+        args = [ptrs, C.c_int(n_col_bits), C.c_int(n_row_bits), C.c_int(pitch), C.c_int(W), C.c_int(H),
+                C.c_int(black_thr), C.c_int(white_thr), C.c_int(scan_w), C.c_int(scan_h), _ptr(cx), _ptr(cy),
+                _ptr(valid), C.c_int(mem)]
+        if rectify_cam is None:
+            st = self.lib.slr_gray_decode(self.h, *args)
+        else:
+            st = self.lib.slr_gray_rectify_decode(self.h, C.c_int(rectify_cam), *args)
+        self._chk(st)
+        return cx, cy, valid
+
+    # -- K4
+    def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True):
+        H, W = phaseL.shape
+        mem = _mem_of([phaseL, validL, phaseR, validR])
+        xyz = self._new(mem, (H, W, 3), np.float32, phaseL)
+        has = self._new(mem, (H, W), np.uint8, phaseL)
+        mk = self._new(mem, (H, W), np.int32, phaseL) if want_match else None
+        self._chk(self.lib.slr_mf_triangulate(self.h, _ptr(phaseL), _ptr(validL), _ptr(phaseR), _ptr(validR),
+                                              C.c_int(W), C.c_int(H), _ptr(xyz), _ptr(has), _ptr(mk), C.c_int(mem)))
+        return xyz, has, mk
+
+    # -- K5
+    def ge_triangulate(self, codeL, validL, codeR, validR, whiteL=None, whiteR=None, want_match=True):
+        H, W = codeL.shape
+        mem = _mem_of([codeL, validL, codeR, validR, whiteL, whiteR])
+        xyz = self._new(mem, (H, W, 3), np.float32, codeL)
+        has = self._new(mem, (H, W), np.uint8, codeL)
+        color = self._new(mem, (H, W), np.uint8, codeL) if whiteL is not None else None
+        mk = self._new(mem, (H, W), np.int32, codeL) if want_match else None
+        self._chk(self.lib.slr_ge_triangulate(self.h, _ptr(codeL), _ptr(validL), _ptr(codeR), _ptr(validR),
+                                              C.c_int(W), C.c_int(H), _ptr(whiteL), _ptr(whiteR), _ptr(xyz),
+                                              _ptr(has), _ptr(color), _ptr(mk), C.c_int(mem)))
+        return xyz, has, color, mk
+
+    # -- K3' scatter + K6
+    def ray_triangulate(self, cxL, cyL, vL, cxR, cyR, vR, scan_w, scan_h):
+        H, W = cxL.shape
+        mem = _mem_of([cxL, cyL, vL, cxR, cyR, vR])
+        xyz = self._new(mem, (scan_h, scan_w, 3), np.float32, cxL)
+        cnt = self._new(mem, (scan_h, scan_w), np.uint8, cxL)
+        self._chk(self.lib.slr_ray_triangulate(self.h, _ptr(cxL), _ptr(cyL), _ptr(vL), _ptr(cxR), _ptr(cyR), _ptr(vR),
+                                               C.c_int(W), C.c_int(H), C.c_int(scan_w), C.c_int(scan_h),
+                                               _ptr(xyz), _ptr(cnt), C.c_int(mem)))
+        return xyz, cnt
+
+    # -- PointCloudImage
+    def pointcloud_from_grid(self, xyz, has, scan_w, scan_h, color=None):
+        H, W = has.shape
+        mem = _mem_of([xyz, has, color])
+        s = self._new(mem, (scan_h, scan_w, 3), np.float32, xyz)
+        c = self._new(mem, (scan_h, scan_w), np.uint8, xyz)
+        col = self._new(mem, (scan_h, scan_w), np.uint8, xyz) if color is not None else None
+        self._chk(self.lib.slr_pointcloud_from_grid(self.h, _ptr(xyz), _ptr(has), _ptr(color), C.c_int(W), C.c_int(H),
+                                                    C.c_int(scan_w), C.c_int(scan_h), _ptr(s), _ptr(c), _ptr(col),
+                                                    C.c_int(mem)))
+        return s, c, col
+
+    def pointcloud_get(self, pc_sum, pc_count):
+        mem = _mem_of([pc_sum, pc_count])
+        n = int(np.prod(pc_count.shape))
+        out = self._new(mem, tuple(pc_count.shape) + (3,), np.float32, pc_sum)
+        self._chk(self.lib.slr_pointcloud_get(self.h, _ptr(pc_sum), _ptr(pc_count), C.c_size_t(n), _ptr(out),
+                                              C.c_int(mem)))
+        return out
+
+    # -- whole-path drop-ins
+    def reconstruct_mf(self, planesL, planesR, black_thr, rectify, W=None, xyz=None, has=None):
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert n == MF_PLANES and n2 == MF_PLANES and (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planesL) + _flat(planesR) + [xyz, has])
+        like = _flat(planesL)[0]
+        xyz = self._new(mem, (H, W, 3), np.float32, like) if xyz is None else xyz
+        has = self._new(mem, (H, W), np.uint8, like) if has is None else has
+        self._chk(self.lib.slr_reconstruct_mf(self.h, pl, pr, C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                              C.c_int(black_thr), C.c_int(1 if rectify else 0), _ptr(xyz), _ptr(has),
+                                              C.c_int(mem)))
+        return xyz, has
+
+    def reconstruct_mf_batch(self, stack, black_thr, rectify, W=None, xyz=None, has=None):
+        """stack: torch.cuda u8 [n_frames][2][14][H][pitch]."""
+        import torch
+        nf, two, n, H, pitch = stack.shape
+        assert two == 2 and n == MF_PLANES and stack.is_cuda and stack.is_contiguous()
+        W = pitch if W is None else W
+        xyz = torch.empty((nf, H, W, 3), dtype=torch.float32, device=stack.device) if xyz is None else xyz
+        has = torch.empty((nf, H, W), dtype=torch.uint8, device=stack.device) if has is None else has
+        self._chk(self.lib.slr_reconstruct_mf_batch(self.h, C.c_int(nf), _ptr(stack), C.c_int(pitch), C.c_int(W),
+                                                    C.c_int(H), C.c_int(black_thr), C.c_int(1 if rectify else 0),
+                                                    _ptr(xyz), _ptr(has)))
+        return xyz, has
+
+    def reconstruct_ge(self, planesL, planesR, n_col_bits, black_thr, white_thr, scan_w, rectify, have_color, W=None):
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert n >= 2 + 2 * n_col_bits and n2 >= 2 + 2 * n_col_bits and (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planesL) + _flat(planesR))
+        like = _flat(planesL)[0]
+        xyz = self._new(mem, (H, W, 3), np.float32, like)
+        has = self._new(mem, (H, W), np.uint8, like)
+        color = self._new(mem, (H, W), np.uint8, like) if have_color else None
+        self._chk(self.lib.slr_reconstruct_ge(self.h, pl, pr, C.c_int(n_col_bits), C.c_int(pitch), C.c_int(W),
+                                              C.c_int(H), C.c_int(black_thr), C.c_int(white_thr), C.c_int(scan_w),
+                                              C.c_int(1 if rectify else 0), C.c_int(1 if have_color else 0),
+                                              _ptr(xyz), _ptr(has), _ptr(color), C.c_int(mem)))
+        return xyz, has, color
+
+    def reconstruct_gray(self, planesL, planesR, n_col_bits, n_row_bits, black_thr, white_thr, scan_w, scan_h, W=None):
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planesL) + _flat(planesR))
+        like = _flat(planesL)[0]
+        xyz = self._new(mem, (scan_h, scan_w, 3), np.float32, like)
+        cnt = self._new(mem, (scan_h, scan_w), np.uint8, like)
+        self._chk(self.lib.slr_reconstruct_gray(self.h, pl, pr, C.c_int(n_col_bits), C.c_int(n_row_bits),
+                                                C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
+                                                C.c_int(white_thr), C.c_int(scan_w), C.c_int(scan_h), _ptr(xyz),
+                                                _ptr(cnt), C.c_int(mem)))
+        return xyz, cnt
+
+    # -- measurement
+    def timer_begin(self):
+        self._chk(self.lib.slr_timer_begin(self.h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        self._chk(self.lib.slr_timer_end(self.h, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.slr_profile_enable(self.h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._chk(self.lib.slr_profile_reset(self.h))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} for every kernel launched since the last reset."""
+        out = {}
+        for i in range(self.lib.slr_profile_kernel_count()):
+            ms, n = C.c_double(0), C.c_long(0)
+            self._chk(self.lib.slr_profile_get(self.h, C.c_int(i), C.byref(ms), C.byref(n)))
+            if n.value:
+                out[self.lib.slr_profile_kernel_name(C.c_int(i)).decode()] = (ms.value, n.value)
+        return out

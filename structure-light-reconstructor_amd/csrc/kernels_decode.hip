@@ -1,0 +1,450 @@
+// kernels_decode.hip -- K1 (rectification remap), K2 (multi-frequency phase decode + heterodyne unwrap),
+// K3/K3' (Gray-code decode) and the fused rectify+decode variants.  gfx950 (MI355X) only.
+//
+// All three are HBM-bound streaming kernels over N separate u8 planes: no MFMA, plain integer/f32 ALU,
+// wide coalesced loads, a 511-entry atanf table in LDS (the reference's quotient is an integer).
+//
+// Reference behaviour restated (never copied):
+//   K1  stereoRect::doStereoRectify -> cv::remap(CV_16SC2,CV_16UC1,INTER_LINEAR)   Duke/stereorect.cpp:26-34
+//   K2  MFReconstruct::computeShadows/decodePatterns/getPhase                      Duke/mfreconstruct.cpp:190-269
+//   K3  Reconstruct::computeShadows/decodePatterns_GE/getProjPixel_GE              Duke/reconstruct.cpp:79-97,210-227,381-407
+//   K3' Reconstruct::decodePaterns/getProjPixel (col + row bits)                   Duke/reconstruct.cpp:56-74,325-370
+//       GrayCodes::grayToDec                                                       Duke/graycodes.cpp:116-128
+#include "slr_device.hpp"
+
+namespace slr {
+
+// native clang vectors (HIP's uint4/float4 are structs and cannot be used with __builtin_nontemporal_*)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------------
+// per-pixel math
+// ------------------------------------------------------------------------------------------------------
+
+// mfreconstruct.cpp:246-261.  n = G4-G2, d = G1-G3.  The branch chain collapses to: d==0 special cases,
+// otherwise a = atanf((float)(n / d)) [C integer division] and the quadrant offset; the n==0 cases of the
+// reference (:246-249) equal the general formula because atanf(0)==0 exactly.
+// Integer division without the ~30-instruction idiv: |n|,|d| <= 255, so floor(|n|/|d|) ==
+// (int)((|n|+0.5f) * rcp(|d|)) -- the true value stays >= 0.5/255 away from any integer, far more than the
+// 1-ulp error of v_rcp_f32 (verified exhaustively over all 511x511 pairs by tests/test_gpu_parity.py).
+__device__ __forceinline__ float wrapped_phase(int G1, int G2, int G3, int G4, const float *lut, int &ok)
+{
+    const int n = G4 - G2, d = G1 - G3;
+    const int an = n < 0 ? -n : n, ad = d < 0 ? -d : d;
+    const int qa = (int)(((float)an + 0.5f) * __builtin_amdgcn_rcpf((float)(ad == 0 ? 1 : ad)));
+    const int q = ((n ^ d) < 0) ? -qa : qa;
+    const float a = lut[(ad == 0 ? 0 : q) + 255];
+    float P = (d < 0) ? (a + kPI) : ((n > 0) ? (a + kTwoPI) : a);
+    if (d == 0) {
+        P = (n > 0) ? kThreeHalfPI : kHalfPI;         // :250-253
+        if (n == 0) { P = 0.0f; ok = 0; }             // :254-255 (Q5 rule: P=0, pixel invalid)
+    }
+    return P;
+}
+
+// mfreconstruct.cpp:265-268: P[] are doubles, P12/P23 computed in f64 and narrowed once, rest f32.
+__device__ __forceinline__ float heterodyne(float P0f, float P1f, float P2f)
+{
+    const double P0 = P0f, P1 = P1f, P2 = P2f;
+    const double two_pi = (double)kTwoPI;
+    const float P12 = (float)((P0 > P1) ? (P0 - P1) : (P0 - P1 + two_pi));
+    const float P23 = (float)((P1 > P2) ? (P1 - P2) : (P1 - P2 + two_pi));
+    const float P123 = (P12 > P23) ? (P12 - P23) : (P12 - P23 + kTwoPI);
+    return P123 / kTwoPI * 255;
+}
+
+// one pixel of K2: g[0]=white g[1]=black g[2..13] fringes
+__device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const float *lut, int &valid)
+{
+    // computeShadows :198-204: (float)white - (float)black > blackThreshold (exact in integers)
+    const int mask = (g[0] - g[1] > black_thr) ? 1 : 0;
+    int ok = 1;
+    const float P0 = wrapped_phase(g[2], g[3], g[4], g[5], lut, ok);
+    const float P1 = wrapped_phase(g[6], g[7], g[8], g[9], lut, ok);
+    const float P2 = wrapped_phase(g[10], g[11], g[12], g[13], lut, ok);
+    const float ph = heterodyne(P0, P1, P2);
+    valid = mask & ok;
+    return mask ? ph : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// rectification taps (cv::remap fixed-point bilinear, SURVEY 8c-3 ii)
+// ------------------------------------------------------------------------------------------------------
+struct Tap {
+    int off;        // sy*pitch + sx (valid only when inlier)
+    int wx0, wx1;   // 32-fx, fx
+    int wy0, wy1;   // 32-fy, fy
+    int sx, sy;
+    int kind;       // 0 = all four taps inside, 1 = fully outside (-> 0), 2 = partial (per-tap checks)
+};
+
+__device__ __forceinline__ Tap make_tap(int sx, int sy, unsigned frac, int pitch, int W, int H)
+{
+    Tap t;
+    const int f = frac & 1023, fx = f & 31, fy = f >> 5;
+    t.wx0 = 32 - fx; t.wx1 = fx; t.wy0 = 32 - fy; t.wy1 = fy;
+    t.sx = sx; t.sy = sy;
+    t.off = sy * pitch + sx;
+    if ((unsigned)sx < (unsigned)(W - 1) && (unsigned)sy < (unsigned)(H - 1)) t.kind = 0;
+    else if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) t.kind = 1;
+    else t.kind = 2;
+    return t;
+}
+
+// (s00*w00 + s01*w01 + s10*w10 + s11*w11 + 16384) >> 15 with w = a*b*32  ==  (h0*wy0 + h1*wy1 + 512) >> 10
+__device__ __forceinline__ int blend(int s00, int s01, int s10, int s11, const Tap &t)
+{
+    const int h0 = s00 * t.wx0 + s01 * t.wx1;
+    const int h1 = s10 * t.wx0 + s11 * t.wx1;
+    return (h0 * t.wy0 + h1 * t.wy1 + 512) >> 10;
+}
+
+__device__ __forceinline__ int sample(const uint8_t *__restrict__ p, int pitch, int W, int H, const Tap &t)
+{
+    if (t.kind == 0) {
+        const uint8_t *q = p + t.off;
+        return blend(q[0], q[1], q[pitch], q[pitch + 1], t);
+    }
+    if (t.kind == 1) return 0;
+    const bool x0 = (unsigned)t.sx < (unsigned)W, x1 = (unsigned)(t.sx + 1) < (unsigned)W;
+    const bool y0 = (unsigned)t.sy < (unsigned)H, y1 = (unsigned)(t.sy + 1) < (unsigned)H;
+    const int s00 = (x0 && y0) ? p[t.off] : 0;
+    const int s01 = (x1 && y0) ? p[t.off + 1] : 0;
+    const int s10 = (x0 && y1) ? p[t.off + pitch] : 0;
+    const int s11 = (x1 && y1) ? p[t.off + pitch + 1] : 0;
+    return blend(s00, s01, s10, s11, t);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1: standalone remap, 4 destination pixels per thread (W % 4 == 0) or 1 (generic)
+// ------------------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void remap_kernel(const uint8_t *__restrict__ src, int src_pitch,
+                                                    uint8_t *__restrict__ dst, int dst_pitch, int W, int H,
+                                                    const int16_t *__restrict__ map_xy,
+                                                    const uint16_t *__restrict__ map_frac)
+{
+    const int gpr = (W + V - 1) / V;
+    const unsigned total = (unsigned)gpr * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        const int row = g / gpr, col0 = (g - row * gpr) * V;
+        const size_t m = (size_t)row * W + col0;
+        if (V == 4) {
+            const u32x4 xy = *reinterpret_cast<const u32x4 *>(map_xy + 2 * m);
+            const u32x2 fr = *reinterpret_cast<const u32x2 *>(map_frac + m);
+            const unsigned xyw[4] = {xy.x, xy.y, xy.z, xy.w};
+            const unsigned frw[4] = {fr.x & 0xFFFFu, fr.x >> 16, fr.y & 0xFFFFu, fr.y >> 16};
+            unsigned out = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const Tap t = make_tap((int)(short)(xyw[i] & 0xFFFFu), (int)(short)(xyw[i] >> 16), frw[i],
+                                       src_pitch, W, H);
+                out |= (unsigned)sample(src, src_pitch, W, H, t) << (8 * i);
+            }
+            *reinterpret_cast<unsigned *>(dst + (size_t)row * dst_pitch + col0) = out;
+        } else {
+            const Tap t = make_tap(map_xy[2 * m], map_xy[2 * m + 1], map_frac[m], src_pitch, W, H);
+            dst[(size_t)row * dst_pitch + col0] = (uint8_t)sample(src, src_pitch, W, H, t);
+        }
+    }
+}
+
+hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int W, int H,
+                           const int16_t *map_xy, const uint16_t *map_frac, hipStream_t s)
+{
+    const bool vec = (W % 4 == 0) && (dst_pitch % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+    const size_t groups = vec ? (size_t)(W / 4) * H : (size_t)W * H;
+    const unsigned blocks = (unsigned)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
+    if (vec) hipLaunchKernelGGL(remap_kernel<4>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
+    else     hipLaunchKernelGGL(remap_kernel<1>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2: multi-frequency decode.  NW dwords (4*NW pixels) per thread per plane; NW==0 -> generic 1 px/thread.
+// ------------------------------------------------------------------------------------------------------
+template <int NW> struct WordVec;
+template <> struct WordVec<1> { typedef unsigned type; };
+template <> struct WordVec<2> { typedef u32x2 type; };
+template <> struct WordVec<4> { typedef u32x4 type; };
+
+__device__ __forceinline__ unsigned word_of(unsigned v, int) { return v; }
+__device__ __forceinline__ unsigned word_of(const u32x2 &v, int k) { return v[k]; }
+__device__ __forceinline__ unsigned word_of(const u32x4 &v, int k) { return v[k]; }
+
+__device__ __forceinline__ void load_lut(float *lut, const float *__restrict__ lut_g)
+{
+    for (int i = threadIdx.x; i < kAtanLutSize; i += blockDim.x) lut[i] = lut_g[i];
+    __syncthreads();
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+                                                        const float *__restrict__ lut_g,
+                                                        float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    __shared__ float lut[512];
+    load_lut(lut, lut_g);
+    typedef typename WordVec<NW>::type vec_t;
+    constexpr int V = 4 * NW;
+    const int gpr = W / V;                                  // launcher guarantees W % V == 0
+    const unsigned total = (unsigned)gpr * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        unsigned row, col0;
+        if (pitch == W) { row = 0; col0 = g * V; }          // flat image: no row arithmetic
+        else { row = g / gpr; col0 = (g - row * gpr) * V; }
+        const size_t so = (size_t)row * pitch + col0, oo = (size_t)row * W + col0;
+        vec_t w[SLR_MF_PLANES];
+#pragma unroll
+        for (int p = 0; p < SLR_MF_PLANES; p++)
+            w[p] = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(pl.p[p] + so));
+        unsigned vout[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            float ph[4];
+            unsigned vw = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int gpx[SLR_MF_PLANES];
+#pragma unroll
+                for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (word_of(w[p], k) >> (8 * b)) & 0xFFu;
+                int v;
+                ph[b] = mf_pixel(gpx, black_thr, lut, v);
+                vw |= (unsigned)v << (8 * b);
+            }
+            f32x4 o; o.x = ph[0]; o.y = ph[1]; o.z = ph[2]; o.w = ph[3];
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(phase + oo + 4 * k));
+            vout[k] = vw;
+        }
+        vec_t vv;
+        if constexpr (NW == 1) vv = vout[0];
+        else if constexpr (NW == 2) { vv.x = vout[0]; vv.y = vout[1]; }
+        else { vv.x = vout[0]; vv.y = vout[1]; vv.z = vout[2]; vv.w = vout[3]; }
+        __builtin_nontemporal_store(vv, reinterpret_cast<vec_t *>(valid + oo));
+    }
+}
+
+// generic (any W / pitch / alignment): one pixel per thread
+__global__ __launch_bounds__(256) void mf_decode_scalar_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+                                                               const float *__restrict__ lut_g,
+                                                               float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    __shared__ float lut[512];
+    load_lut(lut, lut_g);
+    const unsigned total = (unsigned)W * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        const unsigned row = g / W, col = g - row * W;
+        const size_t so = (size_t)row * pitch + col;
+        int gpx[SLR_MF_PLANES];
+#pragma unroll
+        for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = pl.p[p][so];
+        int v;
+        phase[g] = mf_pixel(gpx, black_thr, lut, v);
+        valid[g] = (uint8_t)v;
+    }
+}
+
+// fused K1+K2: V destination pixels per thread (V = 4 when W % 4 == 0, else 1); taps gathered through L1/L2
+template <int V>
+__global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+                                                             const float *__restrict__ lut_g,
+                                                             const int16_t *__restrict__ map_xy,
+                                                             const uint16_t *__restrict__ map_frac,
+                                                             float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    __shared__ float lut[512];
+    load_lut(lut, lut_g);
+    const int gpr = W / V;
+    const unsigned total = (unsigned)gpr * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        const unsigned row = g / gpr, col0 = (g - row * gpr) * V;
+        const size_t m = (size_t)row * W + col0;
+        unsigned xyw[V], frw[V];
+        if constexpr (V == 4) {
+            const u32x4 xy = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(map_xy + 2 * m));
+            const u32x2 fr = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(map_frac + m));
+            xyw[0] = xy.x; xyw[1] = xy.y; xyw[2] = xy.z; xyw[3] = xy.w;
+            frw[0] = fr.x & 0xFFFFu; frw[1] = fr.x >> 16; frw[2] = fr.y & 0xFFFFu; frw[3] = fr.y >> 16;
+        } else {
+            xyw[0] = (unsigned)(uint16_t)map_xy[2 * m] | ((unsigned)(uint16_t)map_xy[2 * m + 1] << 16);
+            frw[0] = map_frac[m];
+        }
+        float ph[V];
+        unsigned vw = 0;
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            const Tap t = make_tap((int)(short)(xyw[i] & 0xFFFFu), (int)(short)(xyw[i] >> 16), frw[i], pitch, W, H);
+            int gpx[SLR_MF_PLANES];
+#pragma unroll
+            for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = sample(pl.p[p], pitch, W, H, t);
+            int v;
+            ph[i] = mf_pixel(gpx, black_thr, lut, v);
+            vw |= (unsigned)v << (8 * i);
+        }
+        if constexpr (V == 4) {
+            f32x4 o; o.x = ph[0]; o.y = ph[1]; o.z = ph[2]; o.w = ph[3];
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(phase + m));
+            __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+        } else {
+            phase[m] = ph[0];
+            valid[m] = (uint8_t)vw;
+        }
+    }
+}
+
+static unsigned pick_blocks(size_t groups)
+{
+    // memory-bound streaming: cap at 256 CUs x 8 workgroups and grid-stride the rest
+    const size_t b = (groups + 255) / 256;
+    return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
+                            float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
+                            hipStream_t s)
+{
+    if (map_xy) {
+        const bool vec = (W % 4 == 0);
+        if (vec) hipLaunchKernelGGL(mf_rect_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
+                                    pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
+        else     hipLaunchKernelGGL(mf_rect_decode_kernel<1>, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
+                                    pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
+        return hipGetLastError();
+    }
+    bool a16 = (W % 16 == 0) && (pitch % 16 == 0), a4 = (W % 4 == 0) && (pitch % 4 == 0);
+    for (int p = 0; p < SLR_MF_PLANES; p++) {
+        a16 = a16 && ((uintptr_t)pl.p[p] % 16 == 0);
+        a4 = a4 && ((uintptr_t)pl.p[p] % 4 == 0);
+    }
+    a16 = a16 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 16 == 0);
+    a4 = a4 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0);
+    if (a16)      hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 16) * H)), dim3(256), 0, s,
+                                     pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
+                                     pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    else          hipLaunchKernelGGL(mf_decode_scalar_kernel, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
+                                     pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 / K3': Gray decode.  V pixels per thread (4 with dword loads, or 1 generic / rectified-generic).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gray_to_binary(int g)
+{
+    // graycodes.cpp:116-128: running XOR from the MSB == prefix-XOR of the packed Gray word
+    g ^= g >> 1; g ^= g >> 2; g ^= g >> 4; g ^= g >> 8;
+    return g;
+}
+
+template <int V, bool RECT>
+__global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_col_bits, int n_row_bits, int pitch,
+                                                          int W, int H, int black_thr, int white_thr, int scan_w,
+                                                          int scan_h, const int16_t *__restrict__ map_xy,
+                                                          const uint16_t *__restrict__ map_frac,
+                                                          int32_t *__restrict__ code_x, int32_t *__restrict__ code_y,
+                                                          uint8_t *__restrict__ valid)
+{
+    const int gpr = W / V;
+    const unsigned total = (unsigned)gpr * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        const unsigned row = g / gpr, col0 = (g - row * gpr) * V;
+        const size_t so = (size_t)row * pitch + col0, m = (size_t)row * W + col0;
+        Tap taps[V];
+        if constexpr (RECT) {
+#pragma unroll
+            for (int i = 0; i < V; i++)
+                taps[i] = make_tap(map_xy[2 * (m + i)], map_xy[2 * (m + i) + 1], map_frac[m + i], pitch, W, H);
+        }
+        // fetch one plane's V pixels as packed bytes
+        auto fetch = [&](int plane) -> unsigned {
+            const uint8_t *p = pl.p[plane];
+            if constexpr (RECT) {
+                unsigned r = 0;
+#pragma unroll
+                for (int i = 0; i < V; i++) r |= (unsigned)sample(p, pitch, W, H, taps[i]) << (8 * i);
+                return r;
+            } else if constexpr (V == 4) {
+                return __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(p + so));
+            } else {
+                return p[so];
+            }
+        };
+        const unsigned wv = fetch(0), bv = fetch(1);
+        int gx[V], gy[V], err[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) { gx[i] = 0; gy[i] = 0; err[i] = 0; }
+        for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
+            const unsigned a = fetch(2 * c + 2), b = fetch(2 * c + 3);
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
+                const int df = v1 - v2;
+                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gx[i] = (gx[i] << 1) | (v1 > v2 ? 1 : 0);
+            }
+        }
+        for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
+            const unsigned a = fetch(2 * c + 2 + 2 * n_col_bits), b = fetch(2 * c + 3 + 2 * n_col_bits);
+#pragma unroll
+            for (int i = 0; i < V; i++) {
+                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
+                const int df = v1 - v2;
+                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gy[i] = (gy[i] << 1) | (v1 > v2 ? 1 : 0);
+            }
+        }
+        int cx[V], cy[V];
+        unsigned vw = 0;
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            const int mask = ((int)((wv >> (8 * i)) & 0xFF) - (int)((bv >> (8 * i)) & 0xFF) > black_thr) ? 1 : 0;
+            const int x = gray_to_binary(gx[i]), y = gray_to_binary(gy[i]);
+            int e = err[i];
+            if (n_row_bits > 0) e |= (y > scan_h || x > scan_w) ? 1 : 0;   // reconstruct.cpp:364 (Q9 '>')
+            else e |= (x > scan_w) ? 1 : 0;                                // reconstruct.cpp:403
+            const int ok = mask & (e ^ 1);
+            cx[i] = ok ? x : -1;
+            cy[i] = (ok && n_row_bits > 0) ? y : -1;
+            vw |= (unsigned)ok << (8 * i);
+        }
+        if constexpr (V == 4) {
+            i32x4 o; o.x = cx[0]; o.y = cx[1]; o.z = cx[2]; o.w = cx[3];
+            __builtin_nontemporal_store(o, reinterpret_cast<i32x4 *>(code_x + m));
+            if (code_y) { i32x4 q; q.x = cy[0]; q.y = cy[1]; q.z = cy[2]; q.w = cy[3];
+                          __builtin_nontemporal_store(q, reinterpret_cast<i32x4 *>(code_y + m)); }
+            __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+        } else {
+            code_x[m] = cx[0];
+            if (code_y) code_y[m] = cy[0];
+            valid[m] = (uint8_t)vw;
+        }
+    }
+}
+
+hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
+                              int black_thr, int white_thr, int scan_w, int scan_h, int32_t *code_x,
+                              int32_t *code_y, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
+                              hipStream_t s)
+{
+    const int nplanes = 2 + 2 * n_col_bits + 2 * n_row_bits;
+    bool a4 = (W % 4 == 0) && ((uintptr_t)code_x % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
+              (!code_y || (uintptr_t)code_y % 16 == 0);
+    if (!map_xy) {
+        a4 = a4 && (pitch % 4 == 0);
+        for (int p = 0; p < nplanes; p++) a4 = a4 && ((uintptr_t)pl.p[p] % 4 == 0);
+    }
+#define SLR_GRAY_LAUNCH(V, RECT)                                                                              \
+    hipLaunchKernelGGL((gray_decode_kernel<V, RECT>), dim3(pick_blocks((size_t)(W / V) * H)), dim3(256), 0, s, \
+                       pl, n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy,  \
+                       map_frac, code_x, code_y, valid)
+    if (map_xy) { if (a4) SLR_GRAY_LAUNCH(4, true); else SLR_GRAY_LAUNCH(1, true); }
+    else        { if (a4) SLR_GRAY_LAUNCH(4, false); else SLR_GRAY_LAUNCH(1, false); }
+#undef SLR_GRAY_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace slr

@@ -1,0 +1,244 @@
+// kernels_match.hip -- K4 (multi-frequency phase match + Q-matrix triangulation) and K5 (Gray-code
+// epipolar match + Q-matrix triangulation).  gfx950 (MI355X) only.
+//
+// Both search along one rectified image row, so a row of the right camera lives in LDS and rows are the
+// unit of parallelism (one workgroup per row).  Neither is HBM-bound: K4 is an LDS-broadcast/VALU sweep with
+// exact first-match semantics, K5 is an LDS sort + wave-parallel speculative walk that reproduces the
+// reference's sequential `kstart` dependency exactly (wavefront shuffles do the prefix-max).
+//
+// Reference behaviour restated (never copied):
+//   K4  MFReconstruct::triangulation                    Duke/mfreconstruct.cpp:272-334
+//       Utilities::undistortPoints                      Duke/utilities.cpp:58-94
+//   K5  Reconstruct::triangulation_ge (live code)       Duke/reconstruct.cpp:555-611
+// f64 is used exactly where the reference uses it (undistortPoints, Q*p); built with -ffp-contract=off so
+// no FMA contraction changes a rounding.
+#include "slr_device.hpp"
+
+#include <math.h>
+
+namespace slr {
+
+// utilities.cpp:58-94 (k[4] = 0 -> the k3 term vanishes exactly)
+__device__ __forceinline__ void undistort_point(float px, float py, const DevCamera &c, float &ox, float &oy)
+{
+    double x = px, y = py;
+    const double x0 = x = (x - c.cx) * c.ifx;
+    const double y0 = y = (y - c.cy) * c.ify;
+#pragma unroll 1
+    for (int it = 0; it < 5; it++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((0 * r2 + c.k1) * r2 + c.k0) * r2);
+        const double deltaX = 2 * c.k2 * x * y + c.k3 * (r2 + 2 * x * x);
+        const double deltaY = c.k2 * (r2 + 2 * y * y) + 2 * c.k3 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    ox = (float)((double)(float)(x * c.fx) + c.cx);
+    oy = (float)((double)(float)(y * c.fy) + c.cy);
+}
+
+// p3D = Q * p2D (cv::Mat f64 GEMM, sequential accumulation), X = (float)(xyz / w)
+__device__ __forceinline__ void reproject(const double *Q, double p0, double p1, double p2, float X[3])
+{
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double s = 0;
+        s += Q[i * 4 + 0] * p0;
+        s += Q[i * 4 + 1] * p1;
+        s += Q[i * 4 + 2] * p2;
+        s += Q[i * 4 + 3] * 1.0;
+        r[i] = s;
+    }
+    X[0] = (float)(r[0] / r[3]);
+    X[1] = (float)(r[1] / r[3]);
+    X[2] = (float)(r[2] / r[3]);
+}
+
+// matCoordTrans(3x4 f32) * [X;1]  (OpenCV f32 GEMM: f64 accumulate, narrow once)
+__device__ __forceinline__ void apply_T(const float *T, float X[3])
+{
+    float Y[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        s += (double)T[r * 4 + 0] * (double)X[0];
+        s += (double)T[r * 4 + 1] * (double)X[1];
+        s += (double)T[r * 4 + 2] * (double)X[2];
+        s += (double)T[r * 4 + 3] * 1.0;
+        Y[r] = (float)s;
+    }
+    X[0] = Y[0]; X[1] = Y[1]; X[2] = Y[2];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4 (exact brute-force form): one workgroup per row; right-row phase in LDS with NaN marking "no phase"
+// (NaN never passes fabsf(d) < 0.1f), each lane owns left pixels j, every lane sweeps k ascending and
+// retires at its first hit (mfreconstruct.cpp:289-327, Q7).  The LDS reads are wave-uniform broadcasts.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                       const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                       int W, int H, DevCalib cal, float *__restrict__ xyz,
+                                                       uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    extern __shared__ float phR[];                 // W rounded up to a multiple of 4, NaN padded
+    const int row = blockIdx.x;
+    const size_t base = (size_t)row * W;
+    const int Wp = (W + 3) & ~3;
+    for (int k = threadIdx.x; k < Wp; k += 256)
+        phR[k] = (k < W && validR[base + k]) ? phaseR[base + k] : __builtin_nanf("");
+    __syncthreads();
+
+    for (int j0 = 0; j0 < W; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        const bool inb = j < W;
+        const bool act = inb && validL[base + j];
+        const float pl = act ? phaseL[base + j] : 0.0f;
+        int best = -1;
+        bool searching = act;
+        for (int k = 0; k < Wp; k += 4) {
+            if (!__any(searching)) break;
+            const float4 r = *reinterpret_cast<const float4 *>(phR + k);
+            const bool c0 = fabsf(pl - r.x) < 0.1f, c1 = fabsf(pl - r.y) < 0.1f;
+            const bool c2 = fabsf(pl - r.z) < 0.1f, c3 = fabsf(pl - r.w) < 0.1f;
+            if (searching && (c0 | c1 | c2 | c3)) {
+                best = k + (c0 ? 0 : (c1 ? 1 : (c2 ? 2 : 3)));
+                searching = false;
+            }
+        }
+        if (!inb) continue;
+        float X[3] = {0.0f, 0.0f, 0.0f};
+        if (best >= 0) {
+            float ulx, uly, urx, ury;
+            undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);      // mfreconstruct.cpp:297
+            undistort_point((float)best, (float)row, cal.cam[1], urx, ury);   // :298
+            reproject(cal.Q, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);   // :299-311
+            if (cal.has_T) apply_T(cal.T, X);                                 // :315-323
+        }
+        float *o = xyz + 3 * (base + j);
+        o[0] = X[0]; o[1] = X[1]; o[2] = X[2];
+        has[base + j] = best >= 0 ? 1 : 0;
+        if (match_k) match_k[base + j] = best;
+    }
+}
+
+hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
+                           int W, int H, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
+                           hipStream_t s)
+{
+    const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);
+    hipLaunchKernelGGL(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, cal,
+                       xyz, has, match_k);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5: one workgroup per row.
+//   1. keys (code<<16 | k) of the valid right pixels are bitonic-sorted in LDS -> for every code an
+//      ascending list of columns.
+//   2. wave 0 walks the left row 64 pixels at a time.  The reference carries `kstart` from match to match
+//      (reconstruct.cpp:556,561,604), a sequential dependency.  Each lane first searches with the incoming
+//      kstart (speculation); an exclusive prefix-max over the lanes' matches (wave shuffles) gives every
+//      lane the kstart it would really have seen; lanes whose kstart moved re-search.  Lane l is final after
+//      at most l rounds, a fixed point equals the sequential answer, and monotone rows finish in one round.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bitonic_sort_lds(unsigned *S, int N)
+{
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
+                const int i = 2 * t - (t & (jj - 1));       // index with bit jj clear
+                const int p = i + jj;
+                const unsigned a = S[i], b = S[p];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { S[i] = b; S[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
+                                                       const int32_t *__restrict__ codeR, const uint8_t *__restrict__ validR,
+                                                       int W, int H, int N, DevCalib cal,
+                                                       const uint8_t *__restrict__ whiteL, const uint8_t *__restrict__ whiteR,
+                                                       float *__restrict__ xyz, uint8_t *__restrict__ has,
+                                                       uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
+{
+    extern __shared__ unsigned S[];                // N = next pow2 >= W keys
+    const int row = blockIdx.x;
+    const size_t base = (size_t)row * W;
+    for (int k = threadIdx.x; k < N; k += 256) {
+        unsigned key = 0xFFFFFFFFu;
+        if (k < W && validR[base + k]) key = ((unsigned)codeR[base + k] << 16) | (unsigned)k;
+        S[k] = key;
+    }
+    __syncthreads();
+    bitonic_sort_lds(S, N);
+    if (threadIdx.x >= 64) return;                 // wave 0 walks; no barrier below this line
+
+    const int lane = threadIdx.x;
+    int ks = 0;                                    // reconstruct.cpp:556
+    for (int j0 = 0; j0 < W; j0 += 64) {
+        const int j = j0 + lane;
+        const bool inb = j < W;
+        const int c = (inb && validL[base + j]) ? codeL[base + j] : -1;
+        int my_ks = ks, m = -1, inc = -1;
+        while (true) {
+            m = -1;
+            if (c >= 0) {
+                const unsigned target = ((unsigned)c << 16) | (unsigned)my_ks;
+                int lo = 0, hi = N;                // first index with S[idx] >= target
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S[mid] < target) lo = mid + 1; else hi = mid;
+                }
+                if (lo < N) {
+                    const unsigned v = S[lo];
+                    if ((v >> 16) == (unsigned)c) m = (int)(v & 0xFFFFu);
+                }
+            }
+            inc = m;                               // inclusive prefix max over lanes
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(inc, d);
+                if (lane >= d) inc = inc > t ? inc : t;
+            }
+            int exc = __shfl_up(inc, 1);
+            if (lane == 0) exc = -1;
+            const int new_ks = ks > exc ? ks : exc;
+            const bool changed = (c >= 0) && (new_ks != my_ks);
+            my_ks = new_ks;
+            if (!__any(changed)) break;
+        }
+        const int last = __shfl(inc, 63);
+        ks = ks > last ? ks : last;                // kstart = k of the last match (reconstruct.cpp:604)
+
+        if (!inb) continue;
+        float X[3] = {0.0f, 0.0f, 0.0f};
+        int col = 0;
+        if (m >= 0) {
+            reproject(cal.Q, (double)j, (double)row, (double)(j - m), X);   // reconstruct.cpp:570-582
+            if (cal.has_T) apply_T(cal.T, X);
+            if (color) col = ((int)whiteL[base + j] + (int)whiteR[base + m]) / 2;   // :598
+        }
+        float *o = xyz + 3 * (base + j);
+        o[0] = X[0]; o[1] = X[1]; o[2] = X[2];
+        has[base + j] = m >= 0 ? 1 : 0;
+        if (color) color[base + j] = (uint8_t)col;
+        if (match_k) match_k[base + j] = m;
+    }
+}
+
+hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR, const uint8_t *validR,
+                           int W, int H, const DevCalib &cal, const uint8_t *whiteL, const uint8_t *whiteR,
+                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s)
+{
+    int N = 2;
+    while (N < W) N <<= 1;
+    hipLaunchKernelGGL(ge_match_kernel, dim3(H), dim3(256), (size_t)N * sizeof(unsigned), s, codeL, validL, codeR,
+                       validR, W, H, N, cal, whiteL, whiteR, xyz, has, color, match_k);
+    return hipGetLastError();
+}
+
+}  // namespace slr

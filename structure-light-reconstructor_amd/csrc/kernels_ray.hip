@@ -1,0 +1,280 @@
+// kernels_ray.hip -- GRAY_ONLY mode: K3' bucket scatter (as a stable key sort) and K6 ray-ray midpoint
+// triangulation with PointCloudImage sum/count accumulation; plus the PointCloudImage adaptors.
+// gfx950 (MI355X) only.
+//
+// Reference behaviour restated (never copied):
+//   scatter   Reconstruct::decodePaterns  camPixels[ac(x,y)].push_back(Point(col,row))   Duke/reconstruct.cpp:61-72
+//             ac(x,y) = x*scan_h + y                                                     Duke/reconstruct.h:94-97
+//   K6        Reconstruct::triangulation                                                 Duke/reconstruct.cpp:417-481
+//             cam2WorldSpace                                                             Duke/reconstruct.cpp:310-322
+//             Utilities::pixelToImageSpace / normalize / line_lineIntersection           Duke/utilities.cpp:47-56,19-28,399-425
+//             PointCloudImage::addPoint / setPoint / getPoint                            Duke/pointcloudimage.cpp:28-37,56-67,86-97
+//
+// The reference pushes camera pixels into per-projector-pixel vectors while walking the camera image
+// column-major; a bucket's traversal order (c1 outer, c2 inner) fixes the f32 accumulation order.  Here the
+// same order is obtained by enumerating pixels in column-major order and STABLE radix-sorting by bucket key.
+#include "slr_device.hpp"
+
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+
+namespace slr {
+
+__global__ __launch_bounds__(256) void ray_keys_kernel(const int32_t *__restrict__ code_x, const int32_t *__restrict__ code_y,
+                                                       const uint8_t *__restrict__ valid, int W, int H, int scan_w,
+                                                       int scan_h, uint32_t *__restrict__ keys, uint32_t *__restrict__ items)
+{
+    const unsigned total = (unsigned)W * (unsigned)H;
+    const unsigned nb = (unsigned)scan_w * (unsigned)scan_h;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const unsigned col = t / H, row = t - col * H;         // column-major traversal (reconstruct.cpp:61-62)
+        const size_t o = (size_t)row * W + col;
+        unsigned key = nb;                                     // sentinel: sorts after every real bucket
+        if (valid[o]) {
+            const unsigned long long k = (unsigned long long)code_x[o] * (unsigned)scan_h + (unsigned)code_y[o];
+            if (k < nb) key = (unsigned)k;                     // Q9: key >= scan_w*scan_h is an OOB write -> dropped
+        }
+        keys[t] = key;
+        items[t] = col | (row << 16);
+    }
+}
+
+hipError_t launch_ray_keys(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
+                           int scan_w, int scan_h, uint32_t *keys, uint32_t *items, hipStream_t s)
+{
+    const size_t n = (size_t)W * H;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ray_keys_kernel, dim3(blocks), dim3(256), 0, s, code_x, code_y, valid, W, H, scan_w, scan_h,
+                       keys, items);
+    return hipGetLastError();
+}
+
+size_t ray_sort_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 32, 0);
+    return bytes;
+}
+
+hipError_t launch_ray_sort(uint32_t *keys_in, uint32_t *keys_out, uint32_t *items_in, uint32_t *items_out, size_t n,
+                           int key_bits, void *temp, size_t temp_bytes, hipStream_t s)
+{
+    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, items_in, items_out, (int)n, 0,
+                                              key_bits, s);
+}
+
+// ---- per camera-pixel unit ray (reconstruct.cpp:440-445) ----------------------------------------------
+__device__ __forceinline__ void undistort_point_ray(float px, float py, const DevCamera &c, float &ox, float &oy)
+{
+    double x = px, y = py;
+    const double x0 = x = (x - c.cx) * c.ifx;
+    const double y0 = y = (y - c.cy) * c.ify;
+#pragma unroll 1
+    for (int it = 0; it < 5; it++) {
+        const double r2 = x * x + y * y;
+        const double icdist = 1. / (1 + ((0 * r2 + c.k1) * r2 + c.k0) * r2);
+        const double deltaX = 2 * c.k2 * x * y + c.k3 * (r2 + 2 * x * x);
+        const double deltaY = c.k2 * (r2 + 2 * y * y) + 2 * c.k3 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    ox = (float)((double)(float)(x * c.fx) + c.cx);
+    oy = (float)((double)(float)(y * c.fy) + c.cy);
+}
+
+// cam2WorldSpace: p <- (float)(-(R^T t)) + (float)(R^T p), f64 accumulation inside each product
+__device__ __forceinline__ void cam2world(const DevCamera &c, float p[3])
+{
+    float out[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        double s = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            s += (double)c.R[k * 3 + r] * (double)c.t[k];
+            s2 += (double)c.R[k * 3 + r] * (double)p[k];
+        }
+        out[r] = (float)(s * -1.0) + (float)s2;
+    }
+    p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
+}
+
+__device__ __forceinline__ void pixel_ray(uint32_t item, const DevCamera &c, const float pos[3], float ray[3])
+{
+    float ux, uy, pt[3];
+    undistort_point_ray((float)(item & 0xFFFFu), (float)(item >> 16), c, ux, uy);
+    pt[0] = (ux - c.ccx) / c.fcx;                  // utilities.cpp:51-53
+    pt[1] = (uy - c.ccy) / c.fcy;
+    pt[2] = 1.0f;
+    cam2world(c, pt);
+    ray[0] = pos[0] - pt[0]; ray[1] = pos[1] - pt[1]; ray[2] = pos[2] - pt[2];
+    // utilities.cpp:21-25: sqrt(float) overload, max(0.000001, mag) in f64, divide by the f32 narrowing
+    const double mag = (double)sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    const float dv = (float)(0.000001 > mag ? 0.000001 : mag);
+    ray[0] /= dv; ray[1] /= dv; ray[2] /= dv;
+}
+
+__device__ __forceinline__ float dot3(const float a[3], const float b[3])
+{
+    float s = 0;
+    s += a[0] * b[0];
+    s += a[1] * b[1];
+    s += a[2] * b[2];
+    return s;
+}
+
+// utilities.cpp:399-425
+__device__ __forceinline__ bool line_line(const float p1[3], const float v1[3], const float p2[3], const float v2[3],
+                                          float out[3])
+{
+    const float v12[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const float a = dot3(v1, v1), c = dot3(v2, v2), b = dot3(v1, v2);
+    const float d = dot3(v12, v1), e = dot3(v12, v2);
+    const float denom = a * c - b * b;
+    if (fabsf(denom) < 0.1f) return false;
+    const float s = (b / denom) * e - (c / denom) * d;
+    const float t = -(b / denom) * d + (a / denom) * e;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float u = p1[k] + s * v1[k];
+        const float w = p2[k] + t * v2[k];
+        out[k] = 0.5f * (u + w);
+    }
+    return true;
+}
+
+__device__ __forceinline__ unsigned lower_bound_u32(const uint32_t *__restrict__ a, unsigned n, unsigned key)
+{
+    unsigned lo = 0, hi = n;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one thread per projector pixel (bucket)
+__global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__restrict__ keysL, const uint32_t *__restrict__ itemsL,
+                                                              const uint32_t *__restrict__ keysR, const uint32_t *__restrict__ itemsR,
+                                                              unsigned n, DevCalib cal, int scan_w, int scan_h,
+                                                              float *__restrict__ xyz_sum, uint8_t *__restrict__ count)
+{
+    const unsigned nb = (unsigned)scan_w * (unsigned)scan_h;
+    float posL[3] = {0, 0, 0}, posR[3] = {0, 0, 0};
+    cam2world(cal.cam[0], posL);                   // reconstruct.cpp:239-240
+    cam2world(cal.cam[1], posR);
+    for (unsigned b = blockIdx.x * 256u + threadIdx.x; b < nb; b += gridDim.x * 256u) {
+        const unsigned i = b / scan_h, j = b - i * scan_h;   // bucket ac(i,j): projector column i, row j
+        const size_t o = (size_t)j * scan_w + i;             // addPoint(i_w=i, j_h=j) -> points[j][i]
+        float sum[3] = {0.0f, 0.0f, 0.0f};
+        unsigned num = 0;
+        const unsigned l0 = lower_bound_u32(keysL, n, b);
+        const unsigned r0 = lower_bound_u32(keysR, n, b);
+        if (l0 < n && keysL[l0] == b && r0 < n && keysR[r0] == b) {
+            for (unsigned c1 = l0; c1 < n && keysL[c1] == b; c1++) {
+                float ray1[3];
+                pixel_ray(itemsL[c1], cal.cam[0], posL, ray1);
+                for (unsigned c2 = r0; c2 < n && keysR[c2] == b; c2++) {
+                    float ray2[3], X[3];
+                    pixel_ray(itemsR[c2], cal.cam[1], posR, ray2);
+                    if (!line_line(posL, ray1, posR, ray2, X)) continue;
+                    if (cal.has_T) {
+                        float Y[3];
+#pragma unroll
+                        for (int r = 0; r < 3; r++) {
+                            double s = 0;
+                            s += (double)cal.T[r * 4 + 0] * (double)X[0];
+                            s += (double)cal.T[r * 4 + 1] * (double)X[1];
+                            s += (double)cal.T[r * 4 + 2] * (double)X[2];
+                            s += (double)cal.T[r * 4 + 3] * 1.0;
+                            Y[r] = (float)s;
+                        }
+                        X[0] = Y[0]; X[1] = Y[1]; X[2] = Y[2];
+                    }
+                    if (num == 0) { sum[0] = X[0]; sum[1] = X[1]; sum[2] = X[2]; num = 1; }   // setPoint
+                    else {                                                                    // addPoint
+                        sum[0] = X[0] + sum[0]; sum[1] = X[1] + sum[1]; sum[2] = X[2] + sum[2];
+                        num = (num + 1) & 0xFFu;           // uchar counter wraps (pointcloudimage.cpp:95)
+                    }
+                }
+            }
+        }
+        xyz_sum[3 * o] = sum[0]; xyz_sum[3 * o + 1] = sum[1]; xyz_sum[3 * o + 2] = sum[2];
+        count[o] = (uint8_t)num;
+    }
+}
+
+hipError_t launch_ray_triangulate(const uint32_t *keysL, const uint32_t *itemsL, const uint32_t *keysR,
+                                  const uint32_t *itemsR, size_t n, const DevCalib &cal, int scan_w, int scan_h,
+                                  float *xyz_sum, uint8_t *count, hipStream_t s)
+{
+    const size_t nb = (size_t)scan_w * scan_h;
+    const unsigned blocks = (unsigned)((nb + 255) / 256 < 8192 ? (nb + 255) / 256 : 8192);
+    hipLaunchKernelGGL(ray_triangulate_kernel, dim3(blocks), dim3(256), 0, s, keysL, itemsL, keysR, itemsR,
+                       (unsigned)n, cal, scan_w, scan_h, xyz_sum, count);
+    return hipGetLastError();
+}
+
+// ---- PointCloudImage adaptors --------------------------------------------------------------------------
+// addPoint(i=row, j=col, p) against PointCloudImage(w=scan_w, h=scan_h): points[j][i] iff i<scan_w && j<scan_h
+// (pointcloudimage.cpp:88).  Gather form: one thread per PointCloudImage cell.
+__global__ __launch_bounds__(256) void pc_from_grid_kernel(const float *__restrict__ xyz, const uint8_t *__restrict__ has,
+                                                           const uint8_t *__restrict__ color, int W, int H, int scan_w,
+                                                           int scan_h, float *__restrict__ pc_sum,
+                                                           uint8_t *__restrict__ pc_count, uint8_t *__restrict__ pc_color)
+{
+    const unsigned total = (unsigned)scan_w * (unsigned)scan_h;
+    for (unsigned d = blockIdx.x * 256u + threadIdx.x; d < total; d += gridDim.x * 256u) {
+        const unsigned j = d / scan_w, i = d - j * scan_w;   // cell (row=j_h, col=i_w)
+        float x = 0, y = 0, z = 0;
+        uint8_t c = 0, col = 0;
+        if (i < (unsigned)H && j < (unsigned)W) {            // source pixel (row i, col j)
+            const size_t o = (size_t)i * W + j;
+            if (has[o]) {
+                x = xyz[3 * o]; y = xyz[3 * o + 1]; z = xyz[3 * o + 2];
+                c = 1;
+                if (color) col = color[o];
+            }
+        }
+        pc_sum[3 * (size_t)d] = x; pc_sum[3 * (size_t)d + 1] = y; pc_sum[3 * (size_t)d + 2] = z;
+        pc_count[d] = c;
+        if (pc_color) pc_color[d] = col;
+    }
+}
+
+hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8_t *color, int W, int H, int scan_w,
+                               int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color, hipStream_t s)
+{
+    const size_t n = (size_t)scan_w * scan_h;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pc_from_grid_kernel, dim3(blocks), dim3(256), 0, s, xyz, has, color, W, H, scan_w, scan_h,
+                       pc_sum, pc_count, pc_color);
+    return hipGetLastError();
+}
+
+// getPoint: Vec3d(sum) / (float)num narrowed to Point3f (pointcloudimage.cpp:62)
+__global__ __launch_bounds__(256) void pc_get_kernel(const float *__restrict__ pc_sum, const uint8_t *__restrict__ pc_count,
+                                                     size_t n, float *__restrict__ out)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) {
+        const unsigned c = pc_count[i];
+        float x = 0, y = 0, z = 0;
+        if (c) {
+            const double dn = (double)(float)c;
+            x = (float)((double)pc_sum[3 * i] / dn);
+            y = (float)((double)pc_sum[3 * i + 1] / dn);
+            z = (float)((double)pc_sum[3 * i + 2] / dn);
+        }
+        out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z;
+    }
+}
+
+hipError_t launch_pc_get(const float *pc_sum, const uint8_t *pc_count, size_t n, float *out, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? ((n + 255) / 256 ? (n + 255) / 256 : 1) : 8192);
+    hipLaunchKernelGGL(pc_get_kernel, dim3(blocks), dim3(256), 0, s, pc_sum, pc_count, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace slr

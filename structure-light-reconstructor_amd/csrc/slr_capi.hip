@@ -1,0 +1,800 @@
+// slr_capi.hip -- the C ABI of libslr_hip.so (include/slr.h): context, device memory staging, launch
+// sequencing and the built-in HIP-event profiler.  Host-side C++ compiled by hipcc; every entry point is
+// extern "C", takes plain pointers and sizes, and never lets an exception escape.
+//
+// There is deliberately no CPU implementation behind these symbols: if no gfx950-class device is usable,
+// slr_create fails and nothing else can be called.
+#include "slr_device.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace slr;
+
+namespace {
+
+const char *kKernelNames[K_COUNT] = {
+    "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
+    "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_keys", "slr_ray_sort", "slr_ray_triangulate",
+    "slr_pc_from_grid", "slr_pc_get"};
+
+// scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
+enum Slot {
+    S_STAGE0 = 0,            // host-mode staging: 16 generic slots
+    S_PHASE_L = 16, S_VALID_L, S_PHASE_R, S_VALID_R,
+    S_CODEX_L, S_CODEY_L, S_CODEX_R, S_CODEY_R,
+    S_KEYS_A, S_KEYS_B, S_ITEMS_A, S_ITEMS_B, S_KEYS_L, S_ITEMS_L, S_SORT_TMP,
+    S_XYZ, S_HAS, S_COLOR,
+    S_COUNT
+};
+
+struct ProfRec { hipEvent_t a, b; int id; };
+
+}  // namespace
+
+struct slr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    bool has_calib = false;
+    DevCalib cal;
+    float *d_lut = nullptr;
+    int16_t *d_map_xy[2] = {nullptr, nullptr};
+    uint16_t *d_map_frac[2] = {nullptr, nullptr};
+    int map_w = 0, map_h = 0;
+    void *scratch[S_COUNT] = {};
+    size_t scratch_cap[S_COUNT] = {};
+    // profiler
+    bool profiling = false;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> free_events;
+    double prof_ms[K_COUNT] = {};
+    long prof_n[K_COUNT] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+int fail(slr_ctx *c, int code, const char *what, const char *detail = nullptr)
+{
+    if (c) {
+        c->err = what;
+        if (detail) { c->err += ": "; c->err += detail; }
+    }
+    return code;
+}
+
+#define SLR_HIP(c, expr)                                                                       \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) return fail((c), e__ == hipErrorOutOfMemory ? SLR_ERR_OOM : SLR_ERR_HIP, #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+#define SLR_TRY(expr)                \
+    do {                             \
+        int s__ = (expr);            \
+        if (s__ != SLR_OK) return s__; \
+    } while (0)
+
+int use_device(slr_ctx *c)
+{
+    SLR_HIP(c, hipSetDevice(c->device));
+    return SLR_OK;
+}
+
+int get_scratch(slr_ctx *c, int slot, size_t bytes, void **out)
+{
+    if (bytes == 0) bytes = 16;
+    if (c->scratch_cap[slot] < bytes) {
+        if (c->scratch[slot]) {
+            SLR_HIP(c, hipStreamSynchronize(c->stream));
+            SLR_HIP(c, hipFree(c->scratch[slot]));
+            c->scratch[slot] = nullptr;
+            c->scratch_cap[slot] = 0;
+        }
+        const size_t cap = (bytes + 255) & ~(size_t)255;
+        SLR_HIP(c, hipMalloc(&c->scratch[slot], cap));
+        c->scratch_cap[slot] = cap;
+    }
+    *out = c->scratch[slot];
+    return SLR_OK;
+}
+
+// ---- per-call staging of host pointers ------------------------------------------------------------------
+struct Stage {
+    slr_ctx *c;
+    slr_mem mem;
+    int next = S_STAGE0;
+    struct Out { void *host; void *dev; size_t bytes; };
+    std::vector<Out> outs;
+
+    Stage(slr_ctx *ctx, slr_mem m) : c(ctx), mem(m) {}
+
+    int in(const void *p, size_t bytes, const void **dev)
+    {
+        if (!p || mem == SLR_MEM_DEVICE) { *dev = p; return SLR_OK; }
+        if (next >= S_STAGE0 + 16) return fail(c, SLR_ERR_INVALID_ARG, "too many staged buffers");
+        void *d;
+        SLR_TRY(get_scratch(c, next++, bytes, &d));
+        SLR_HIP(c, hipMemcpyAsync(d, p, bytes, hipMemcpyHostToDevice, c->stream));
+        *dev = d;
+        return SLR_OK;
+    }
+    int out(void *p, size_t bytes, void **dev)
+    {
+        if (!p || mem == SLR_MEM_DEVICE) { *dev = p; return SLR_OK; }
+        if (next >= S_STAGE0 + 16) return fail(c, SLR_ERR_INVALID_ARG, "too many staged buffers");
+        void *d;
+        SLR_TRY(get_scratch(c, next++, bytes, &d));
+        outs.push_back({p, d, bytes});
+        *dev = d;
+        return SLR_OK;
+    }
+    // N planes of H*pitch bytes each -> one contiguous device stack; fills dev plane pointers
+    int planes(const uint8_t *const *pl, int n, int pitch, int H, const uint8_t **dev_ptrs)
+    {
+        if (mem == SLR_MEM_DEVICE) { for (int i = 0; i < n; i++) dev_ptrs[i] = pl[i]; return SLR_OK; }
+        if (next >= S_STAGE0 + 16) return fail(c, SLR_ERR_INVALID_ARG, "too many staged buffers");
+        const size_t plane = (size_t)pitch * H;
+        void *d;
+        SLR_TRY(get_scratch(c, next++, plane * n, &d));
+        for (int i = 0; i < n; i++) {
+            SLR_HIP(c, hipMemcpyAsync((uint8_t *)d + plane * i, pl[i], plane, hipMemcpyHostToDevice, c->stream));
+            dev_ptrs[i] = (const uint8_t *)d + plane * i;
+        }
+        return SLR_OK;
+    }
+    int finish()
+    {
+        if (mem == SLR_MEM_DEVICE) return SLR_OK;
+        for (auto &o : outs) SLR_HIP(c, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
+        SLR_HIP(c, hipStreamSynchronize(c->stream));
+        return SLR_OK;
+    }
+};
+
+// ---- profiler ---------------------------------------------------------------------------------------------
+int prof_event(slr_ctx *c, hipEvent_t *e)
+{
+    if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); return SLR_OK; }
+    SLR_HIP(c, hipEventCreate(e));
+    return SLR_OK;
+}
+
+struct ProfScope {
+    slr_ctx *c; int id; ProfRec r{}; bool on;
+    ProfScope(slr_ctx *ctx, int kid) : c(ctx), id(kid), on(ctx->profiling)
+    {
+        if (!on) return;
+        if (prof_event(c, &r.a) != SLR_OK || prof_event(c, &r.b) != SLR_OK) { on = false; return; }
+        r.id = id;
+        (void)hipEventRecord(r.a, c->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(r.b, c->stream);
+        c->pending.push_back(r);
+    }
+};
+
+int prof_drain(slr_ctx *c)
+{
+    if (c->pending.empty()) return SLR_OK;
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &r : c->pending) {
+        float ms = 0;
+        SLR_HIP(c, hipEventElapsedTime(&ms, r.a, r.b));
+        c->prof_ms[r.id] += ms;
+        c->prof_n[r.id] += 1;
+        c->free_events.push_back(r.a);
+        c->free_events.push_back(r.b);
+    }
+    c->pending.clear();
+    return SLR_OK;
+}
+
+int check_dims(slr_ctx *c, int W, int H, int pitch)
+{
+    if (W <= 0 || H <= 0 || pitch < W) return fail(c, SLR_ERR_INVALID_ARG, "bad image size/pitch");
+    if ((long long)W * H >= (1ll << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "image too large");
+    if (W > 65535 || H > 65535) return fail(c, SLR_ERR_UNSUPPORTED, "W,H must be < 65536");
+    return SLR_OK;
+}
+
+int need_maps(slr_ctx *c, int cam, int W, int H)
+{
+    if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 (left) or 1 (right)");
+    if (!c->d_map_xy[cam]) return fail(c, SLR_ERR_NOT_CONFIGURED, "rectify maps not set (slr_set_rectify_maps)");
+    if (c->map_w != W || c->map_h != H) return fail(c, SLR_ERR_INVALID_ARG, "image size differs from rectify map size");
+    return SLR_OK;
+}
+
+int need_calib(slr_ctx *c)
+{
+    if (!c->has_calib) return fail(c, SLR_ERR_NOT_CONFIGURED, "calibration not set (slr_set_calibration)");
+    return SLR_OK;
+}
+
+// ---- device-pointer cores (shared by the single-op entry points and the pipelines) ------------------------
+int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, int pitch, int W, int H,
+                   int black_thr, float *phase, uint8_t *valid)
+{
+    MfPlanes mp;
+    for (int i = 0; i < SLR_MF_PLANES; i++) mp.p[i] = pl[i];
+    ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
+    SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
+                                rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
+                                c->stream));
+    return SLR_OK;
+}
+
+int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, int ncol, int nrow, int pitch,
+                     int W, int H, int black_thr, int white_thr, int scan_w, int scan_h, int32_t *cx, int32_t *cy,
+                     uint8_t *valid)
+{
+    GrayPlanes gp;
+    const int n = 2 + 2 * ncol + 2 * nrow;
+    for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) gp.p[i] = i < n ? pl[i] : nullptr;
+    ProfScope ps(c, rectify ? K_GRAY_RECT_DECODE : K_GRAY_DECODE);
+    SLR_HIP(c, launch_gray_decode(gp, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx, cy, valid,
+                                  rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
+                                  c->stream));
+    return SLR_OK;
+}
+
+int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *vL, const int32_t *cxR,
+             const int32_t *cyR, const uint8_t *vR, int W, int H, int scan_w, int scan_h, float *xyz_sum,
+             uint8_t *count)
+{
+    const size_t n = (size_t)W * H;
+    const unsigned long long nb = (unsigned long long)scan_w * scan_h;
+    if (nb >= 0xFFFFFFFFull) return fail(c, SLR_ERR_UNSUPPORTED, "scan_w*scan_h too large");
+    int key_bits = 1;
+    while ((1ull << key_bits) <= nb) key_bits++;
+    void *ka, *kb, *ia, *ib, *kl, *il, *tmp;
+    const size_t tb = ray_sort_temp_bytes(n);
+    SLR_TRY(get_scratch(c, S_KEYS_A, n * 4, &ka));
+    SLR_TRY(get_scratch(c, S_KEYS_B, n * 4, &kb));
+    SLR_TRY(get_scratch(c, S_ITEMS_A, n * 4, &ia));
+    SLR_TRY(get_scratch(c, S_ITEMS_B, n * 4, &ib));
+    SLR_TRY(get_scratch(c, S_KEYS_L, n * 4, &kl));
+    SLR_TRY(get_scratch(c, S_ITEMS_L, n * 4, &il));
+    SLR_TRY(get_scratch(c, S_SORT_TMP, tb, &tmp));
+    // left camera -> (kl, il)
+    { ProfScope ps(c, K_RAY_KEYS);
+      SLR_HIP(c, launch_ray_keys(cxL, cyL, vL, W, H, scan_w, scan_h, (uint32_t *)ka, (uint32_t *)ia, c->stream)); }
+    { ProfScope ps(c, K_RAY_SORT);
+      SLR_HIP(c, launch_ray_sort((uint32_t *)ka, (uint32_t *)kl, (uint32_t *)ia, (uint32_t *)il, n, key_bits, tmp, tb, c->stream)); }
+    // right camera -> (kb, ib)
+    { ProfScope ps(c, K_RAY_KEYS);
+      SLR_HIP(c, launch_ray_keys(cxR, cyR, vR, W, H, scan_w, scan_h, (uint32_t *)ka, (uint32_t *)ia, c->stream)); }
+    { ProfScope ps(c, K_RAY_SORT);
+      SLR_HIP(c, launch_ray_sort((uint32_t *)ka, (uint32_t *)kb, (uint32_t *)ia, (uint32_t *)ib, n, key_bits, tmp, tb, c->stream)); }
+    { ProfScope ps(c, K_RAY_TRI);
+      SLR_HIP(c, launch_ray_triangulate((uint32_t *)kl, (uint32_t *)il, (uint32_t *)kb, (uint32_t *)ib, n, c->cal,
+                                        scan_w, scan_h, xyz_sum, count, c->stream)); }
+    return SLR_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================================
+extern "C" {
+
+int slr_version(void) { return SLR_VERSION; }
+
+const char *slr_status_string(int s)
+{
+    switch (s) {
+        case SLR_OK: return "ok";
+        case SLR_ERR_INVALID_ARG: return "invalid argument";
+        case SLR_ERR_NO_DEVICE: return "no usable HIP device";
+        case SLR_ERR_HIP: return "HIP runtime error";
+        case SLR_ERR_NOT_CONFIGURED: return "calibration or rectify maps not configured";
+        case SLR_ERR_UNSUPPORTED: return "unsupported size or mode";
+        case SLR_ERR_OOM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+int slr_create(int device_id, slr_ctx **out)
+{
+    if (!out) return SLR_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SLR_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c = new (std::nothrow) slr_ctx();
+    if (!c) return SLR_ERR_OOM;
+    c->device = device_id;
+    int st = SLR_OK;
+    do {
+        if (hipSetDevice(device_id) != hipSuccess) { st = SLR_ERR_NO_DEVICE; break; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { st = SLR_ERR_HIP; break; }
+        c->own_stream = true;
+        // 511-entry atanf table over the integer quotients; the host libm fills it so the
+        // device never evaluates a transcendental (no libm-vs-ocml ULP drift)
+        float lut[kAtanLutSize];
+        for (int q = -255; q <= 255; q++) lut[q + 255] = atanf((float)q);
+        if (hipMalloc(&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
+        if (hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) { st = SLR_ERR_HIP; break; }
+        if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) { st = SLR_ERR_HIP; break; }
+    } while (0);
+    if (st != SLR_OK) { slr_destroy(c); return st; }
+    *out = c;
+    return SLR_OK;
+}
+
+int slr_destroy(slr_ctx *c)
+{
+    if (!c) return SLR_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &r : c->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    for (int i = 0; i < S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); }
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SLR_OK;
+}
+
+int slr_set_stream(slr_ctx *c, void *hip_stream)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    if (hip_stream) {
+        if (c->own_stream) { SLR_HIP(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
+        c->stream = (hipStream_t)hip_stream;
+    } else if (!c->own_stream) {
+        SLR_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return SLR_OK;
+}
+
+int slr_synchronize(slr_ctx *c)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+const char *slr_last_error(const slr_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
+{
+    if (!c || !cal) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 2; k++) {
+        const slr_camera &s = cal->cam[k];
+        DevCamera &d = c->cal.cam[k];
+        if (s.fc[0] == 0.0f || s.fc[1] == 0.0f) return fail(c, SLR_ERR_INVALID_ARG, "zero focal length");
+        d.fx = s.fc[0]; d.fy = s.fc[1];                 // utilities.cpp:68-73: f32 widened, ifx = 1./fx in f64
+        d.ifx = 1. / d.fx; d.ify = 1. / d.fy;
+        d.cx = s.cc[0]; d.cy = s.cc[1];
+        d.k0 = s.k[0]; d.k1 = s.k[1]; d.k2 = s.k[2]; d.k3 = s.k[3];   // k[4] ignored (utilities.cpp:66)
+        d.fcx = s.fc[0]; d.fcy = s.fc[1]; d.ccx = s.cc[0]; d.ccy = s.cc[1];
+        memcpy(d.R, s.R, sizeof(d.R));
+        memcpy(d.t, s.t, sizeof(d.t));
+    }
+    memcpy(c->cal.Q, cal->Q, sizeof(c->cal.Q));
+    memcpy(c->cal.T, cal->T, sizeof(c->cal.T));
+    c->cal.has_T = cal->has_T ? 1 : 0;
+    c->has_calib = true;
+    return SLR_OK;
+}
+
+int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint16_t *map_frac, int W, int H,
+                         slr_mem mem)
+{
+    if (!c || !map_xy || !map_frac) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 or 1");
+    SLR_TRY(check_dims(c, W, H, W));
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->map_w != W || c->map_h != H) {
+        for (int k = 0; k < 2; k++) {
+            if (c->d_map_xy[k]) { SLR_HIP(c, hipFree(c->d_map_xy[k])); c->d_map_xy[k] = nullptr; }
+            if (c->d_map_frac[k]) { SLR_HIP(c, hipFree(c->d_map_frac[k])); c->d_map_frac[k] = nullptr; }
+        }
+        c->map_w = W; c->map_h = H;
+    }
+    const size_t n = (size_t)W * H;
+    if (!c->d_map_xy[cam]) SLR_HIP(c, hipMalloc(&c->d_map_xy[cam], n * 4));
+    if (!c->d_map_frac[cam]) SLR_HIP(c, hipMalloc(&c->d_map_frac[cam], n * 2));
+    const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
+    SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+int slr_remap_u8(slr_ctx *c, int cam, const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int W, int H,
+                 slr_mem mem)
+{
+    if (!c || !src || !dst) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(check_dims(c, W, H, src_pitch));
+    if (dst_pitch < W) return fail(c, SLR_ERR_INVALID_ARG, "bad dst pitch");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_maps(c, cam, W, H));
+    Stage st(c, mem);
+    const void *ds; void *dd;
+    SLR_TRY(st.in(src, (size_t)src_pitch * H, &ds));
+    SLR_TRY(st.out(dst, (size_t)dst_pitch * H, &dd));
+    { ProfScope ps(c, K_REMAP);
+      SLR_HIP(c, launch_remap_u8((const uint8_t *)ds, src_pitch, (uint8_t *)dd, dst_pitch, W, H, c->d_map_xy[cam],
+                                 c->d_map_frac[cam], c->stream)); }
+    return st.finish();
+}
+
+static int mf_decode_entry(slr_ctx *c, int cam, bool rectify, const uint8_t *const *planes, int pitch, int W, int H,
+                           int black_thr, float *phase, uint8_t *valid, slr_mem mem)
+{
+    if (!c || !planes || !phase || !valid) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < SLR_MF_PLANES; i++) if (!planes[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    if (rectify) SLR_TRY(need_maps(c, cam, W, H));
+    Stage st(c, mem);
+    const uint8_t *dp[SLR_MF_PLANES];
+    void *dph, *dv;
+    SLR_TRY(st.planes(planes, SLR_MF_PLANES, pitch, H, dp));
+    SLR_TRY(st.out(phase, (size_t)W * H * 4, &dph));
+    SLR_TRY(st.out(valid, (size_t)W * H, &dv));
+    SLR_TRY(core_mf_decode(c, cam, rectify, dp, pitch, W, H, black_thr, (float *)dph, (uint8_t *)dv));
+    return st.finish();
+}
+
+int slr_mf_decode(slr_ctx *c, const uint8_t *const planes[SLR_MF_PLANES], int pitch, int W, int H, int black_thr,
+                  float *phase, uint8_t *valid, slr_mem mem)
+{
+    return mf_decode_entry(c, 0, false, planes, pitch, W, H, black_thr, phase, valid, mem);
+}
+
+int slr_mf_rectify_decode(slr_ctx *c, int cam, const uint8_t *const planes[SLR_MF_PLANES], int pitch, int W, int H,
+                          int black_thr, float *phase, uint8_t *valid, slr_mem mem)
+{
+    return mf_decode_entry(c, cam, true, planes, pitch, W, H, black_thr, phase, valid, mem);
+}
+
+static int gray_decode_entry(slr_ctx *c, int cam, bool rectify, const uint8_t *const *planes, int ncol, int nrow,
+                             int pitch, int W, int H, int black_thr, int white_thr, int scan_w, int scan_h,
+                             int32_t *cx, int32_t *cy, uint8_t *valid, slr_mem mem)
+{
+    if (!c || !planes || !cx || !valid) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (ncol < 1 || ncol > SLR_MAX_GRAY_BITS || nrow < 0 || nrow > SLR_MAX_GRAY_BITS)
+        return fail(c, SLR_ERR_INVALID_ARG, "bit counts out of range");
+    if (nrow > 0 && !cy) return fail(c, SLR_ERR_INVALID_ARG, "code_y required when n_row_bits > 0");
+    const int n = 2 + 2 * ncol + 2 * nrow;
+    for (int i = 0; i < n; i++) if (!planes[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    if (rectify) SLR_TRY(need_maps(c, cam, W, H));
+    Stage st(c, mem);
+    const uint8_t *dp[SLR_MAX_GRAY_PLANES];
+    void *dx, *dy, *dv;
+    SLR_TRY(st.planes(planes, n, pitch, H, dp));
+    SLR_TRY(st.out(cx, (size_t)W * H * 4, &dx));
+    SLR_TRY(st.out(cy, (size_t)W * H * 4, &dy));
+    SLR_TRY(st.out(valid, (size_t)W * H, &dv));
+    SLR_TRY(core_gray_decode(c, cam, rectify, dp, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h,
+                             (int32_t *)dx, (int32_t *)dy, (uint8_t *)dv));
+    return st.finish();
+}
+
+int slr_gray_decode(slr_ctx *c, const uint8_t *const *planes, int ncol, int nrow, int pitch, int W, int H,
+                    int black_thr, int white_thr, int scan_w, int scan_h, int32_t *cx, int32_t *cy, uint8_t *valid,
+                    slr_mem mem)
+{
+    return gray_decode_entry(c, 0, false, planes, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx,
+                             cy, valid, mem);
+}
+
+int slr_gray_rectify_decode(slr_ctx *c, int cam, const uint8_t *const *planes, int ncol, int nrow, int pitch, int W,
+                            int H, int black_thr, int white_thr, int scan_w, int scan_h, int32_t *cx, int32_t *cy,
+                            uint8_t *valid, slr_mem mem)
+{
+    return gray_decode_entry(c, cam, true, planes, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx,
+                             cy, valid, mem);
+}
+
+int slr_mf_triangulate(slr_ctx *c, const float *phaseL, const uint8_t *validL, const float *phaseR,
+                       const uint8_t *validR, int W, int H, float *xyz, uint8_t *has, int32_t *match_k, slr_mem mem)
+{
+    if (!c || !phaseL || !validL || !phaseR || !validR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(check_dims(c, W, H, W));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H;
+    const void *pl, *vl, *pr, *vr; void *dx, *dh, *dk;
+    SLR_TRY(st.in(phaseL, n * 4, &pl)); SLR_TRY(st.in(validL, n, &vl));
+    SLR_TRY(st.in(phaseR, n * 4, &pr)); SLR_TRY(st.in(validR, n, &vr));
+    SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh)); SLR_TRY(st.out(match_k, n * 4, &dk));
+    { ProfScope ps(c, K_MF_MATCH);
+      SLR_HIP(c, launch_mf_match((const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
+                                 c->cal, (float *)dx, (uint8_t *)dh, (int32_t *)dk, c->stream)); }
+    return st.finish();
+}
+
+int slr_ge_triangulate(slr_ctx *c, const int32_t *codeL, const uint8_t *validL, const int32_t *codeR,
+                       const uint8_t *validR, int W, int H, const uint8_t *whiteL, const uint8_t *whiteR, float *xyz,
+                       uint8_t *has, uint8_t *color, int32_t *match_k, slr_mem mem)
+{
+    if (!c || !codeL || !validL || !codeR || !validR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (color && (!whiteL || !whiteR)) return fail(c, SLR_ERR_INVALID_ARG, "color output needs both white planes");
+    SLR_TRY(check_dims(c, W, H, W));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H;
+    const void *cl, *vl, *cr, *vr, *wl, *wr; void *dx, *dh, *dc, *dk;
+    SLR_TRY(st.in(codeL, n * 4, &cl)); SLR_TRY(st.in(validL, n, &vl));
+    SLR_TRY(st.in(codeR, n * 4, &cr)); SLR_TRY(st.in(validR, n, &vr));
+    SLR_TRY(st.in(whiteL, n, &wl)); SLR_TRY(st.in(whiteR, n, &wr));
+    SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh));
+    SLR_TRY(st.out(color, n, &dc)); SLR_TRY(st.out(match_k, n * 4, &dk));
+    { ProfScope ps(c, K_GE_MATCH);
+      SLR_HIP(c, launch_ge_match((const int32_t *)cl, (const uint8_t *)vl, (const int32_t *)cr, (const uint8_t *)vr, W, H,
+                                 c->cal, (const uint8_t *)wl, (const uint8_t *)wr, (float *)dx, (uint8_t *)dh,
+                                 (uint8_t *)dc, (int32_t *)dk, c->stream)); }
+    return st.finish();
+}
+
+int slr_ray_triangulate(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *vL, const int32_t *cxR,
+                        const int32_t *cyR, const uint8_t *vR, int W, int H, int scan_w, int scan_h, float *xyz_sum,
+                        uint8_t *count, slr_mem mem)
+{
+    if (!c || !cxL || !cyL || !vL || !cxR || !cyR || !vR || !xyz_sum || !count) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(check_dims(c, W, H, W));
+    if (scan_w <= 0 || scan_h <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bad scan size");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H, nb = (size_t)scan_w * scan_h;
+    const void *a, *b, *d, *e, *f, *g; void *dx, *dc;
+    SLR_TRY(st.in(cxL, n * 4, &a)); SLR_TRY(st.in(cyL, n * 4, &b)); SLR_TRY(st.in(vL, n, &d));
+    SLR_TRY(st.in(cxR, n * 4, &e)); SLR_TRY(st.in(cyR, n * 4, &f)); SLR_TRY(st.in(vR, n, &g));
+    SLR_TRY(st.out(xyz_sum, nb * 12, &dx)); SLR_TRY(st.out(count, nb, &dc));
+    SLR_TRY(core_ray(c, (const int32_t *)a, (const int32_t *)b, (const uint8_t *)d, (const int32_t *)e,
+                     (const int32_t *)f, (const uint8_t *)g, W, H, scan_w, scan_h, (float *)dx, (uint8_t *)dc));
+    return st.finish();
+}
+
+int slr_pointcloud_from_grid(slr_ctx *c, const float *xyz, const uint8_t *has, const uint8_t *color, int W, int H,
+                             int scan_w, int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color, slr_mem mem)
+{
+    if (!c || !xyz || !has || !pc_sum || !pc_count) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(check_dims(c, W, H, W));
+    if (scan_w <= 0 || scan_h <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bad scan size");
+    SLR_TRY(use_device(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H, nb = (size_t)scan_w * scan_h;
+    const void *a, *b, *d; void *ps_, *pc_, *pk_;
+    SLR_TRY(st.in(xyz, n * 12, &a)); SLR_TRY(st.in(has, n, &b)); SLR_TRY(st.in(color, n, &d));
+    SLR_TRY(st.out(pc_sum, nb * 12, &ps_)); SLR_TRY(st.out(pc_count, nb, &pc_)); SLR_TRY(st.out(pc_color, nb, &pk_));
+    { ProfScope ps(c, K_PC_FROM_GRID);
+      SLR_HIP(c, launch_pc_from_grid((const float *)a, (const uint8_t *)b, (const uint8_t *)d, W, H, scan_w, scan_h,
+                                     (float *)ps_, (uint8_t *)pc_, (uint8_t *)pk_, c->stream)); }
+    return st.finish();
+}
+
+int slr_pointcloud_get(slr_ctx *c, const float *pc_sum, const uint8_t *pc_count, size_t n, float *out, slr_mem mem)
+{
+    if (!c || !pc_sum || !pc_count || !out) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return SLR_OK;
+    SLR_TRY(use_device(c));
+    Stage st(c, mem);
+    const void *a, *b; void *o;
+    SLR_TRY(st.in(pc_sum, n * 12, &a)); SLR_TRY(st.in(pc_count, n, &b)); SLR_TRY(st.out(out, n * 12, &o));
+    { ProfScope ps(c, K_PC_GET);
+      SLR_HIP(c, launch_pc_get((const float *)a, (const uint8_t *)b, n, (float *)o, c->stream)); }
+    return st.finish();
+}
+
+// ---- whole-path drop-ins ----------------------------------------------------------------------------------
+static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int pitch, int W, int H,
+                              int black_thr, int rectify, float *xyz, uint8_t *has)
+{
+    const size_t n = (size_t)W * H;
+    void *phL, *vL, *phR, *vR;
+    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL)); SLR_TRY(get_scratch(c, S_VALID_L, n, &vL));
+    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vR));
+    SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
+    SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
+    { ProfScope ps(c, K_MF_MATCH);
+      SLR_HIP(c, launch_mf_match((const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H,
+                                 c->cal, xyz, has, nullptr, c->stream)); }
+    return SLR_OK;
+}
+
+int slr_reconstruct_mf(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
+                       int pitch, int W, int H, int black_thr, int rectify, float *xyz, uint8_t *has, slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < SLR_MF_PLANES; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    Stage st(c, mem);
+    const uint8_t *dl[SLR_MF_PLANES], *dr[SLR_MF_PLANES];
+    void *dx, *dh;
+    SLR_TRY(st.planes(planesL, SLR_MF_PLANES, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, SLR_MF_PLANES, pitch, H, dr));
+    SLR_TRY(st.out(xyz, (size_t)W * H * 12, &dx));
+    SLR_TRY(st.out(has, (size_t)W * H, &dh));
+    SLR_TRY(reconstruct_mf_dev(c, dl, dr, pitch, W, H, black_thr, rectify, (float *)dx, (uint8_t *)dh));
+    return st.finish();
+}
+
+int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int pitch, int W, int H, int black_thr,
+                             int rectify, float *xyz, uint8_t *has)
+{
+    if (!c || !stack || !xyz || !has || n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    const size_t plane = (size_t)pitch * H, n = (size_t)W * H;
+    for (int f = 0; f < n_frames; f++) {
+        const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
+        const uint8_t *base = stack + (size_t)f * 2 * SLR_MF_PLANES * plane;
+        for (int i = 0; i < SLR_MF_PLANES; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (SLR_MF_PLANES + i); }
+        SLR_TRY(reconstruct_mf_dev(c, pl, pr, pitch, W, H, black_thr, rectify, xyz + (size_t)f * n * 3, has + (size_t)f * n));
+    }
+    return SLR_OK;
+}
+
+int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t *const *planesR, int ncol, int pitch,
+                       int W, int H, int black_thr, int white_thr, int scan_w, int rectify, int have_color, float *xyz,
+                       uint8_t *has, uint8_t *color, slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (ncol < 1 || ncol > SLR_MAX_GRAY_BITS) return fail(c, SLR_ERR_INVALID_ARG, "bit count out of range");
+    if (have_color && !color) return fail(c, SLR_ERR_INVALID_ARG, "color buffer required");
+    const int np = 2 + 2 * ncol;
+    for (int i = 0; i < np; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H;
+    const uint8_t *dl[SLR_MAX_GRAY_PLANES], *dr[SLR_MAX_GRAY_PLANES];
+    void *dx, *dh, *dc, *cxl, *vl, *cxr, *vr;
+    SLR_TRY(st.planes(planesL, np, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, np, pitch, H, dr));
+    SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh));
+    SLR_TRY(st.out(have_color ? color : nullptr, n, &dc));
+    SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl)); SLR_TRY(get_scratch(c, S_VALID_L, n, &vl));
+    SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vr));
+    SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
+                             (int32_t *)cxl, nullptr, (uint8_t *)vl));
+    SLR_TRY(core_gray_decode(c, 1, rectify != 0, dr, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
+                             (int32_t *)cxr, nullptr, (uint8_t *)vr));
+    // colour uses the RECTIFIED white images (reconstruct.cpp:193 color = camImgs[0])
+    const uint8_t *wl = nullptr, *wr = nullptr;
+    if (have_color) {
+        if (rectify) {
+            void *a, *b;
+            SLR_TRY(get_scratch(c, S_COLOR, n * 2, &a));
+            b = (uint8_t *)a + n;
+            { ProfScope ps(c, K_REMAP);
+              SLR_HIP(c, launch_remap_u8(dl[0], pitch, (uint8_t *)a, W, W, H, c->d_map_xy[0], c->d_map_frac[0], c->stream)); }
+            { ProfScope ps(c, K_REMAP);
+              SLR_HIP(c, launch_remap_u8(dr[0], pitch, (uint8_t *)b, W, W, H, c->d_map_xy[1], c->d_map_frac[1], c->stream)); }
+            wl = (const uint8_t *)a; wr = (const uint8_t *)b;
+        } else {
+            if (pitch != W) return fail(c, SLR_ERR_UNSUPPORTED, "have_color without rectify needs pitch == W");
+            wl = dl[0]; wr = dr[0];
+        }
+    }
+    { ProfScope ps(c, K_GE_MATCH);
+      SLR_HIP(c, launch_ge_match((const int32_t *)cxl, (const uint8_t *)vl, (const int32_t *)cxr, (const uint8_t *)vr, W, H,
+                                 c->cal, wl, wr, (float *)dx, (uint8_t *)dh, (uint8_t *)dc, nullptr, c->stream)); }
+    return st.finish();
+}
+
+int slr_reconstruct_gray(slr_ctx *c, const uint8_t *const *planesL, const uint8_t *const *planesR, int ncol, int nrow,
+                         int pitch, int W, int H, int black_thr, int white_thr, int scan_w, int scan_h, float *xyz_sum,
+                         uint8_t *count, slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !xyz_sum || !count) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (ncol < 1 || ncol > SLR_MAX_GRAY_BITS || nrow < 1 || nrow > SLR_MAX_GRAY_BITS)
+        return fail(c, SLR_ERR_INVALID_ARG, "bit counts out of range");
+    if (scan_w <= 0 || scan_h <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bad scan size");
+    const int np = 2 + 2 * ncol + 2 * nrow;
+    for (int i = 0; i < np; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H, nb = (size_t)scan_w * scan_h;
+    const uint8_t *dl[SLR_MAX_GRAY_PLANES], *dr[SLR_MAX_GRAY_PLANES];
+    void *dx, *dc, *cxl, *cyl, *vl, *cxr, *cyr, *vr;
+    SLR_TRY(st.planes(planesL, np, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, np, pitch, H, dr));
+    SLR_TRY(st.out(xyz_sum, nb * 12, &dx)); SLR_TRY(st.out(count, nb, &dc));
+    SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl)); SLR_TRY(get_scratch(c, S_CODEY_L, n * 4, &cyl));
+    SLR_TRY(get_scratch(c, S_VALID_L, n, &vl));
+    SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr)); SLR_TRY(get_scratch(c, S_CODEY_R, n * 4, &cyr));
+    SLR_TRY(get_scratch(c, S_VALID_R, n, &vr));
+    SLR_TRY(core_gray_decode(c, 0, false, dl, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h,
+                             (int32_t *)cxl, (int32_t *)cyl, (uint8_t *)vl));
+    SLR_TRY(core_gray_decode(c, 1, false, dr, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h,
+                             (int32_t *)cxr, (int32_t *)cyr, (uint8_t *)vr));
+    SLR_TRY(core_ray(c, (const int32_t *)cxl, (const int32_t *)cyl, (const uint8_t *)vl, (const int32_t *)cxr,
+                     (const int32_t *)cyr, (const uint8_t *)vr, W, H, scan_w, scan_h, (float *)dx, (uint8_t *)dc));
+    return st.finish();
+}
+
+// ---- measurement hooks --------------------------------------------------------------------------------------
+int slr_timer_begin(slr_ctx *c)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, hipEventRecord(c->t0, c->stream));
+    return SLR_OK;
+}
+
+int slr_timer_end(slr_ctx *c, float *ms)
+{
+    if (!c || !ms) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, hipEventRecord(c->t1, c->stream));
+    SLR_HIP(c, hipEventSynchronize(c->t1));
+    SLR_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return SLR_OK;
+}
+
+int slr_profile_enable(slr_ctx *c, int on)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_TRY(prof_drain(c));
+    c->profiling = on != 0;
+    return SLR_OK;
+}
+
+int slr_profile_reset(slr_ctx *c)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_TRY(prof_drain(c));
+    for (int i = 0; i < K_COUNT; i++) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+    return SLR_OK;
+}
+
+int slr_profile_kernel_count(void) { return K_COUNT; }
+
+const char *slr_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+
+int slr_profile_get(slr_ctx *c, int id, double *total_ms, long *launches)
+{
+    if (!c || id < 0 || id >= K_COUNT) return SLR_ERR_INVALID_ARG;
+    SLR_TRY(use_device(c));
+    SLR_TRY(prof_drain(c));
+    if (total_ms) *total_ms = c->prof_ms[id];
+    if (launches) *launches = c->prof_n[id];
+    return SLR_OK;
+}
+
+}  // extern "C"

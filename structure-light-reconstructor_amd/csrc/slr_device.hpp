@@ -1,0 +1,79 @@
+// slr_device.hpp -- shared declarations between the HIP kernels and the C-ABI layer (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slr.h"
+
+namespace slr {
+
+// mfreconstruct.cpp:5 "float PI = 3.1416;" -- an f32 that is not pi.
+constexpr float kPI = 3.1416f;
+constexpr float kTwoPI = 2 * kPI;          // f32 expression, as in the reference (2*PI)
+constexpr float kThreeHalfPI = 3 * kPI / 2;
+constexpr float kHalfPI = kPI / 2;
+constexpr int kAtanLutSize = 511;          // quotient of two ints in [-255,255]
+
+struct MfPlanes { const uint8_t *p[SLR_MF_PLANES]; };
+struct GrayPlanes { const uint8_t *p[SLR_MAX_GRAY_PLANES]; };
+
+// calibration as the kernels consume it (by-value kernel argument)
+struct DevCamera {
+    double fx, fy, ifx, ify, cx, cy;   // utilities.cpp:68-73 (f32 values widened; ifx = 1./fx in f64)
+    double k0, k1, k2, k3;             // utilities.cpp:62-65
+    float fcx, fcy, ccx, ccy;          // f32 originals for pixelToImageSpace (utilities.cpp:51-52)
+    float R[9], t[3];
+};
+struct DevCalib {
+    DevCamera cam[2];
+    double Q[16];
+    float T[12];
+    int has_T;
+};
+
+// kernel ids for the built-in HIP-event profiler (bench.py reads these)
+enum KernelId {
+    K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
+    K_MF_MATCH, K_GE_MATCH, K_RAY_KEYS, K_RAY_SORT, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_COUNT
+};
+
+// ---- launchers (defined in the .hip files; all asynchronous on `s`) -----------------------------------
+hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int dst_pitch, int W, int H,
+                           const int16_t *map_xy, const uint16_t *map_frac, hipStream_t s);
+
+hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr,
+                            const float *atan_lut, float *phase, uint8_t *valid,
+                            const int16_t *map_xy, const uint16_t *map_frac /* null -> no rectify */,
+                            hipStream_t s);
+
+hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
+                              int black_thr, int white_thr, int scan_w, int scan_h,
+                              int32_t *code_x, int32_t *code_y, uint8_t *valid,
+                              const int16_t *map_xy, const uint16_t *map_frac, hipStream_t s);
+
+hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR,
+                           const uint8_t *validR, int W, int H, const DevCalib &cal,
+                           float *xyz, uint8_t *has, int32_t *match_k, hipStream_t s);
+
+hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR,
+                           const uint8_t *validR, int W, int H, const DevCalib &cal,
+                           const uint8_t *whiteL, const uint8_t *whiteR,
+                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s);
+
+// GRAY_ONLY: keys/items in the reference's column-major traversal order, stable sort, per-bucket pairs
+size_t     ray_sort_temp_bytes(size_t n);
+hipError_t launch_ray_keys(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
+                           int scan_w, int scan_h, uint32_t *keys, uint32_t *items, hipStream_t s);
+hipError_t launch_ray_sort(uint32_t *keys_in, uint32_t *keys_out, uint32_t *items_in, uint32_t *items_out,
+                           size_t n, int key_bits, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_ray_triangulate(const uint32_t *keysL, const uint32_t *itemsL, const uint32_t *keysR,
+                                  const uint32_t *itemsR, size_t n, const DevCalib &cal, int scan_w,
+                                  int scan_h, float *xyz_sum, uint8_t *count, hipStream_t s);
+
+hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8_t *color, int W, int H,
+                               int scan_w, int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color,
+                               hipStream_t s);
+hipError_t launch_pc_get(const float *pc_sum, const uint8_t *pc_count, size_t n, float *out, hipStream_t s);
+
+}  // namespace slr

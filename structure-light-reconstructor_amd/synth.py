@@ -1,0 +1,200 @@
+"""Synthetic structured-light stereo scenes (inputs for tests and bench.py; there is no dataset access).
+
+Everything is written with torch ops so the same code renders a 64x48 fixture on the CPU and a 4096x3000x14x2
+stack directly in HBM.  The renderer is NOT part of the hot path and makes no parity claim of its own:
+decode/triangulate parity is always asserted on identical u8 inputs.
+
+Pattern formulas follow the reference encoders:
+  multi-frequency  135 + 79*cos(PI*2*w*freq/projW + PI*phi/2), freq {70,64,59}, PI=3.1416   Duke/multifrequency.cpp:3,27
+  Gray code        plane 2+2c = Gray bit (n-1-c) of the projector column, 3+2c = inverse     Duke/graycodes.cpp:55-114
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+
+PI_REF = 3.1416
+MF_FREQ = (70, 64, 59)
+
+
+def gray_num_bits(n):
+    """graycodes.cpp:24 : (int)ceil(log(n)/log(2))"""
+    return int(math.ceil(math.log(float(n)) / math.log(2.0)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# calibration
+# ---------------------------------------------------------------------------------------------------------
+def make_calibration(W, H, with_T=False, baseline=120.0, theta=0.04):
+    """A plausible horizontal rig.  Q has the cv::stereoRectify form (SURVEY 8c-3 iv):
+    [[1,0,0,-cx1],[0,1,0,-cy],[0,0,0,f],[0,0,-1/Tx,(cx1-cx2)/Tx]]."""
+    f = 1.2 * W
+    cx1, cx2, cy = 0.5 * W + 3.25, 0.5 * W - 2.5, 0.5 * H + 1.75
+    Tx = -baseline
+    Q = np.array([[1, 0, 0, -cx1], [0, 1, 0, -cy], [0, 0, 0, f], [0, 0, -1.0 / Tx, (cx1 - cx2) / Tx]], np.float64)
+    th = theta            # convergence angle of the right camera (ray mode needs > 18.4 deg, utilities.cpp:414)
+    Rr = np.array([[math.cos(th), 0, math.sin(th)], [0, 1, 0], [-math.sin(th), 0, math.cos(th)]], np.float32)
+    camL = capi.make_camera((f * 0.98, f * 1.01), (cx1 - 1.5, cy + 0.75), (-0.11, 0.021, 8e-4, -5e-4, 0.3),
+                            np.eye(3, dtype=np.float32), (0.0, 0.0, 0.0))
+    camR = capi.make_camera((f * 1.02, f * 0.99), (cx2 + 2.0, cy - 1.25), (-0.09, 0.017, -6e-4, 7e-4, -0.2),
+                            Rr, (Tx, 1.5, -2.0))
+    T = None
+    if with_T:
+        a = 0.03
+        T = np.array([[math.cos(a), -math.sin(a), 0, 12.5], [math.sin(a), math.cos(a), 0, -7.25], [0, 0, 1, 3.0]],
+                     np.float32)
+    return capi.make_calib(camL, camR, Q, T), dict(f=f, cx1=cx1, cx2=cx2, cy=cy, Tx=Tx)
+
+
+def make_rectify_maps(W, H, cam, device="cpu", strength=1.0):
+    """Smooth, mildly distorting fixed-point maps in cv::initUndistortRectifyMap's CV_16SC2 + CV_16UC1 layout
+    (map_xy [H][W][2] int16, map_frac [H][W] uint16 = (fy<<5)|fx).  Synthetic, but shaped like a real
+    undistort+rotate map: radial term + small rotation + sub-pixel shift, so source coordinates leave the image
+    near the borders (exercises BORDER_CONSTANT)."""
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device),
+                            torch.arange(W, dtype=torch.float64, device=device), indexing="ij")
+    cx, cy = 0.5 * W + (1.7 if cam == 0 else -2.3), 0.5 * H + (0.9 if cam == 0 else -1.1)
+    fx = 1.2 * W
+    x, y = (xs - cx) / fx, (ys - cy) / fx
+    r2 = x * x + y * y
+    k1 = (-0.08 if cam == 0 else -0.06) * strength
+    ang = (0.004 if cam == 0 else -0.003) * strength
+    kr = 1 + k1 * r2
+    xr = x * kr * math.cos(ang) - y * kr * math.sin(ang)
+    yr = x * kr * math.sin(ang) + y * kr * math.cos(ang)
+    u = fx * xr + cx + (0.37 if cam == 0 else -0.61)
+    v = fx * yr + cy + (0.23 if cam == 0 else 0.41)
+    iu = torch.round(u * 32).to(torch.int64)          # cvRound (half-to-even, like torch.round)
+    iv = torch.round(v * 32).to(torch.int64)
+    sx = torch.clamp(iu >> 5, -32768, 32767).to(torch.int16)
+    sy = torch.clamp(iv >> 5, -32768, 32767).to(torch.int16)
+    map_xy = torch.stack([sx, sy], dim=-1).contiguous()
+    frac = ((iv & 31) * 32 + (iu & 31)).to(torch.int32)
+    map_frac = frac.to(torch.int16).view(torch.int16)   # values < 1024 fit either signedness
+    return map_xy, _as_u16(map_frac)
+
+
+def _as_u16(t):
+    """torch has limited uint16 support; keep int16 storage, expose a uint16 view for numpy / pointers."""
+    try:
+        return t.view(torch.uint16)
+    except Exception:  # pragma: no cover
+        return t
+
+
+def identity_maps(W, H, dx=0, dy=0, fx=0, fy=0, device="cpu"):
+    ys, xs = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    map_xy = torch.stack([(xs + dx).to(torch.int16), (ys + dy).to(torch.int16)], dim=-1).contiguous()
+    map_frac = torch.full((H, W), (fy << 5) | fx, dtype=torch.int16, device=device)
+    return map_xy, _as_u16(map_frac)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# scene
+# ---------------------------------------------------------------------------------------------------------
+def _disparity(i, x, W, H):
+    """smooth disparity field d(i, x) in [~0.02W, ~0.1W] px: tilted plane + gaussian bump (a sphere-ish bulge)"""
+    d0, d1 = 0.02 * W, 0.098 * W
+    plane = d0 + (d1 - d0) * (0.35 + 0.25 * x / W + 0.15 * i / H)
+    bump = 0.18 * (d1 - d0) * torch.exp(-(((x - 0.55 * W) / (0.18 * W)) ** 2 + ((i - 0.45 * H) / (0.22 * H)) ** 2))
+    return plane + bump
+
+
+def projector_columns(W, H, proj_w, device="cpu", dtype=torch.float64):
+    """Projector column seen by every pixel of the (rectified) left and right cameras, plus the left disparity.
+    Left pixel (i,j) and right pixel (i, j - d(i,j)) see the same surface point, hence the same column."""
+    ii, jj = torch.meshgrid(torch.arange(H, dtype=dtype, device=device), torch.arange(W, dtype=dtype, device=device),
+                            indexing="ij")
+    alpha = 0.5                                   # projector sits between the cameras
+    scale = proj_w / (1.05 * W)
+    dL = _disparity(ii, jj, W, H)
+    uL = (jj - alpha * dL) * scale + 0.02 * proj_w
+    # right pixel (i,k): solve x - d(i,x) = k by fixed-point iteration (|dd/dx| << 1 -> contraction)
+    x = jj + 0.06 * W
+    for _ in range(12):
+        x = jj + _disparity(ii, x, W, H)
+    dR = _disparity(ii, x, W, H)
+    uR = (x - alpha * dR) * scale + 0.02 * proj_w
+    return uL, uR, dL
+
+
+def _noise(shape, amp, gen, device):
+    if amp <= 0:
+        return torch.zeros(shape, dtype=torch.int16, device=device)
+    return torch.randint(-amp, amp + 1, shape, generator=gen, device=device, dtype=torch.int16)
+
+
+def _finish(img_f, noise):
+    return torch.clamp(torch.floor(img_f).to(torch.int16) + noise, 0, 255).to(torch.uint8)
+
+
+def _shadow_mask(W, H, device):
+    """1 where the projector lights the pixel; a dark band + a dark disc model shadows (mask==0 there)"""
+    ii, jj = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    lit = torch.ones((H, W), dtype=torch.bool, device=device)
+    lit &= ~((jj > int(0.90 * W)) & (ii < int(0.12 * H)))
+    lit &= ((jj - 0.2 * W) ** 2 + (ii - 0.75 * H) ** 2) > (0.05 * min(W, H)) ** 2
+    return lit
+
+
+def render_mf_stack(W, H, proj_w=None, seed=1234, noise=2, device="cpu"):
+    """[2 cams][14][H][W] u8: white, black, 3 freq x 4 steps (mfreconstruct.cpp:199-200,239-242 plane order)."""
+    proj_w = W if proj_w is None else proj_w
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    uL, uR, _ = projector_columns(W, H, proj_w, device)
+    lit = _shadow_mask(W, H, device)
+    out = torch.empty((2, capi.MF_PLANES, H, W), dtype=torch.uint8, device=device)
+    for cam, u in enumerate((uL, uR)):
+        col = torch.clamp(torch.round(u), 0, proj_w - 1)        # projector pixel (nearest)
+        inside = (u >= 0) & (u <= proj_w - 1) & lit
+        white = torch.where(inside, 215.0, 70.0)
+        black = torch.where(inside, 55.0, 52.0)
+        out[cam, 0] = _finish(white, _noise((H, W), noise, gen, device))
+        out[cam, 1] = _finish(black, _noise((H, W), noise, gen, device))
+        for f in range(3):
+            for s in range(4):
+                arg = (PI_REF * 2 * col * MF_FREQ[f] / proj_w + PI_REF * s / 2).to(torch.float32)
+                img = 135 + 79 * torch.cos(arg)
+                img = torch.where(inside, img.to(torch.float64), torch.full_like(u, 58.0))
+                out[cam, 4 * f + s + 2] = _finish(img, _noise((H, W), noise, gen, device))
+    return out
+
+
+def render_gray_stack(W, H, scan_w, scan_h=None, seed=1234, noise=2, device="cpu", rows=False):
+    """[2 cams][2+2n(+2m)][H][W] u8 Gray-code stack.  rows=True adds the row-bit planes (GRAY_ONLY mode); the
+    projector row seen by a pixel is a smooth function of the image row."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    ncol = gray_num_bits(scan_w)
+    nrow = gray_num_bits(scan_h) if rows else 0
+    uL, uR, _ = projector_columns(W, H, scan_w, device)
+    lit = _shadow_mask(W, H, device)
+    n = 2 + 2 * ncol + 2 * nrow
+    out = torch.empty((2, n, H, W), dtype=torch.uint8, device=device)
+    ii = torch.arange(H, dtype=torch.float64, device=device)[:, None].expand(H, W)
+    for cam, u in enumerate((uL, uR)):
+        col = torch.clamp(torch.round(u), 0, scan_w - 1).to(torch.int64)
+        inside = (u >= 0) & (u <= scan_w - 1) & lit
+        out[cam, 0] = _finish(torch.where(inside, 215.0, 70.0), _noise((H, W), noise, gen, device))
+        out[cam, 1] = _finish(torch.where(inside, 55.0, 52.0), _noise((H, W), noise, gen, device))
+        g = col ^ (col >> 1)
+        for c in range(ncol):
+            bit = ((g >> (ncol - 1 - c)) & 1).to(torch.bool)
+            on = torch.where(inside & bit, 200.0, 60.0)
+            off = torch.where(inside & ~bit, 200.0, 60.0)
+            out[cam, 2 + 2 * c] = _finish(on, _noise((H, W), noise, gen, device))
+            out[cam, 3 + 2 * c] = _finish(off, _noise((H, W), noise, gen, device))
+        if rows:
+            v = ii * (scan_h / (1.04 * H)) + 0.01 * scan_h + (0.0 if cam == 0 else 0.3)
+            rrow = torch.clamp(torch.round(v), 0, scan_h - 1).to(torch.int64)
+            gr = rrow ^ (rrow >> 1)
+            for c in range(nrow):
+                bit = ((gr >> (nrow - 1 - c)) & 1).to(torch.bool)
+                on = torch.where(inside & bit, 200.0, 60.0)
+                off = torch.where(inside & ~bit, 200.0, 60.0)
+                out[cam, 2 + 2 * ncol + 2 * c] = _finish(on, _noise((H, W), noise, gen, device))
+                out[cam, 3 + 2 * ncol + 2 * c] = _finish(off, _noise((H, W), noise, gen, device))
+    return out

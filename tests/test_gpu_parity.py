@@ -1,0 +1,441 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, include/slr.h) against the CPU oracle on the same
+seeded inputs.  Bar (BASELINE.json north_star): Gray-code indices / masks / match columns bit-exact; phase and
+XYZ within 1e-4 relative -- the tolerance is written in util.assert_float_parity.  In practice phase is asserted
+BIT-exact (atanf comes from a host-filled table, all other ops are IEEE f32/f64 without contraction).
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_float_parity, bits_equal, calib_parts, np_of
+
+pytestmark = pytest.mark.gpu
+
+BLACK = 40
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K2
+# ---------------------------------------------------------------------------------------------------------
+def _all_quotient_planes(rng):
+    """511x511 image whose pixel (r,c) has n = r-255, d = c-255 at frequency 0: every (n,d) pair, i.e. every
+    branch of mfreconstruct.cpp:246-261 and every integer quotient.  Frequencies 1,2 are random."""
+    n = np.arange(-255, 256)[:, None] * np.ones((1, 511), int)
+    d = np.ones((511, 1), int) * np.arange(-255, 256)[None, :]
+    pl = rng.integers(0, 256, size=(14, 511, 511), dtype=np.uint8)
+    pl[0] = 230
+    pl[1] = 20
+    pl[2] = np.maximum(d, 0)      # G1
+    pl[4] = np.maximum(-d, 0)     # G3  -> G1-G3 = d
+    pl[5] = np.maximum(n, 0)      # G4
+    pl[3] = np.maximum(-n, 0)     # G2  -> G4-G2 = n
+    return pl
+
+
+def test_mf_decode_every_quotient_and_branch(ctx, oracle):
+    rng = np.random.default_rng(7)
+    pl = _all_quotient_planes(rng)
+    exp_ph, exp_v = oracle.mf_decode(pl, BLACK)
+    ph, v = ctx.mf_decode(pl, BLACK)                 # W=511: generic 1-px kernel, host staging
+    assert bits_equal(v, exp_v)
+    assert bits_equal(ph, exp_ph)
+    # same content padded to W=512 -> 16-px vector kernel; and W=508 crop -> 4-px kernel
+    pad = np.zeros((14, 511, 512), np.uint8)
+    pad[:, :, :511] = pl
+    e2, ev2 = oracle.mf_decode(pad, BLACK)
+    g2, gv2 = ctx.mf_decode(pad, BLACK)
+    assert bits_equal(gv2, ev2) and bits_equal(g2, e2)
+    crop = np.ascontiguousarray(pl[:, :, :508])
+    e3, ev3 = oracle.mf_decode(crop, BLACK)
+    g3, gv3 = ctx.mf_decode(crop, BLACK)
+    assert bits_equal(gv3, ev3) and bits_equal(g3, e3)
+    # the 5 special branches really occur and the Q5 pixel is invalid
+    assert exp_v[255, 255] == 0 and exp_v[255, 300] == 1
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (64, 48), (100, 37), (1, 1), (16, 1), (3, 5)])
+def test_mf_decode_synth_host_and_device(ctx, oracle, synth, W, H):
+    st = synth.render_mf_stack(W, H, seed=1234 + W)
+    for cam in range(2):
+        pl = st[cam].numpy()
+        exp_ph, exp_v = oracle.mf_decode(pl, BLACK)
+        ph, v = ctx.mf_decode(pl, BLACK)
+        assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph)
+        dph, dv = ctx.mf_decode(st[cam].cuda(), BLACK)
+        ctx.synchronize()
+        assert bits_equal(np_of(dv), exp_v) and bits_equal(np_of(dph), exp_ph)
+
+
+def test_mf_decode_pitch_and_random(ctx, oracle):
+    rng = np.random.default_rng(11)
+    H, W, pitch = 33, 96, 128
+    pl = rng.integers(0, 256, size=(14, H, pitch), dtype=np.uint8)
+    exp_ph, exp_v = oracle.mf_decode(pl, BLACK, W=W)
+    ph, v = ctx.mf_decode(pl, BLACK, W=W)
+    assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph)
+    # thresholds at the edge: white-black == thr is NOT lit ('>' in mfreconstruct.cpp:201)
+    pl[0, :, :] = 100
+    pl[1, :, :] = 60
+    _, v2 = ctx.mf_decode(pl, 40, W=W)
+    assert v2.sum() == 0
+    _, v3 = ctx.mf_decode(pl, 39, W=W)
+    e3 = oracle.mf_decode(pl, 39, W=W)[1]
+    assert bits_equal(v3, e3) and v3.sum() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K1 and the fused rectify + decode
+# ---------------------------------------------------------------------------------------------------------
+def test_remap_identity_and_half_pixel(ctx, oracle, synth):
+    rng = np.random.default_rng(3)
+    H, W = 60, 84
+    img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    for cam, (dx, dy, fx, fy) in enumerate([(0, 0, 0, 0), (0, 0, 16, 0)]):
+        mx, mf = synth.identity_maps(W, H, dx, dy, fx, fy)
+        ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
+    out0 = ctx.remap_u8(0, img)
+    assert np.array_equal(out0, img)                               # KA4
+    out1 = ctx.remap_u8(1, img)
+    a = img.astype(np.int64)
+    b = np.concatenate([a[:, 1:], np.zeros((H, 1), np.int64)], axis=1)
+    assert np.array_equal(out1, ((a * 16384 + b * 16384 + 16384) >> 15).astype(np.uint8))   # KA5
+    assert np.array_equal(out1, oracle.remap_u8(img, mx.numpy(), mf.numpy()))
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (101, 67), (64, 48)])
+def test_remap_and_fused_rectify_decode(ctx, oracle, synth, W, H):
+    st = synth.render_mf_stack(W, H, seed=99)
+    maps = [synth.make_rectify_maps(W, H, cam, strength=3.0) for cam in range(2)]
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    for cam in range(2):
+        mx, mf = maps[cam][0].numpy(), maps[cam][1].numpy()
+        raw = st[cam].numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+        got = ctx.remap_u8(cam, raw[5])
+        assert np.array_equal(got, rect[5])
+        assert (rect[5] == 0).any()                                  # border taps were exercised
+        gdev = ctx.remap_u8(cam, st[cam, 5].cuda())
+        ctx.synchronize()
+        assert np.array_equal(np_of(gdev), rect[5])
+        exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
+        ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)
+        assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K3 / K3'
+# ---------------------------------------------------------------------------------------------------------
+def test_gray_roundtrip_every_column(ctx, oracle):
+    """KA1: generateGrays -> decode returns the column, for 1280 (11 bits) and 4096 (12 bits)"""
+    for w in (1280, 4096, 640, 100):
+        g = oracle.gen_graycodes(w, 4, True)
+        n = oracle.gray_num_bits(w)
+        cx, _, v = ctx.gray_decode(g, n, 0, BLACK, 0, w, 4)
+        assert v.all() and np.array_equal(cx, np.broadcast_to(np.arange(w, dtype=np.int32), (4, w)))
+
+
+@pytest.mark.parametrize("W,H,rows", [(640, 480, False), (640, 480, True), (97, 31, True), (64, 48, False)])
+def test_gray_decode_parity(ctx, oracle, synth, W, H, rows):
+    scan_w, scan_h = 600, 450
+    st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=5, noise=6, rows=rows)
+    ncol = synth.gray_num_bits(scan_w)
+    nrow = synth.gray_num_bits(scan_h) if rows else 0
+    for cam in range(2):
+        for white_thr in (0, 9):
+            pl = st[cam].numpy()
+            ex, ey, ev = oracle.gray_decode(pl, ncol, nrow, BLACK, white_thr, scan_w, scan_h)
+            cx, cy, v = ctx.gray_decode(pl, ncol, nrow, BLACK, white_thr, scan_w, scan_h)
+            assert bits_equal(v, ev) and bits_equal(cx, ex)
+            if rows:
+                assert bits_equal(cy, ey)
+            dcx, dcy, dv = ctx.gray_decode(st[cam].cuda(), ncol, nrow, BLACK, white_thr, scan_w, scan_h)
+            ctx.synchronize()
+            assert bits_equal(np_of(dv), ev) and bits_equal(np_of(dcx), ex)
+    assert 0 < ev.mean() < 1
+
+
+def test_gray_range_check_uses_greater_than(ctx, oracle):
+    """Q9: xDec == scan_w passes (reconstruct.cpp:403 uses '>')"""
+    w = 64
+    g = oracle.gen_graycodes(w, 2, True)
+    n = oracle.gray_num_bits(w)
+    for scan_w in (63, 40, 10):
+        ex, _, ev = oracle.gray_decode(g, n, 0, BLACK, 0, scan_w, 2)
+        cx, _, v = ctx.gray_decode(g, n, 0, BLACK, 0, scan_w, 2)
+        assert bits_equal(cx, ex) and bits_equal(v, ev)
+        assert v[0, scan_w] == 1 and v[0, scan_w + 1] == 0
+
+
+def test_gray_rectify_decode(ctx, oracle, synth):
+    W, H, scan_w = 320, 200, 300
+    st = synth.render_gray_stack(W, H, scan_w, seed=8, noise=3)
+    ncol = synth.gray_num_bits(scan_w)
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=2.0)
+        ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=2.0)
+        raw = st[cam].numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx.numpy(), mf.numpy()) for p in range(raw.shape[0])])
+        ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 4, scan_w, 0)
+        cx, _, v = ctx.gray_decode(raw, ncol, 0, BLACK, 4, scan_w, 0, rectify_cam=cam)
+        assert bits_equal(cx, ex) and bits_equal(v, ev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K4
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,with_T", [(640, 480, False), (320, 100, True), (67, 9, True)])
+def test_mf_triangulate_parity(ctx, oracle, synth, W, H, with_T):
+    calib, _ = synth.make_calibration(W, H, with_T=with_T)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    st = synth.render_mf_stack(W, H, seed=21, noise=0 if W == 640 else 2)
+    phL, vL = oracle.mf_decode(st[0].numpy(), BLACK)
+    phR, vR = oracle.mf_decode(st[1].numpy(), BLACK)
+    exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
+    xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
+    assert bits_equal(has, ehas) and bits_equal(mk, emk)            # first-match semantics, exact
+    assert ehas.sum() > 0
+    nb = assert_float_parity(xyz, exyz, 1e-4, "mf xyz")
+    assert nb == 0, "XYZ expected bit-exact, %d elements differ" % nb
+    dx, dh, dk = ctx.mf_triangulate(*[torch.from_numpy(a).cuda() for a in (phL, vL, phR, vR)])
+    ctx.synchronize()
+    assert bits_equal(np_of(dk), emk) and bits_equal(np_of(dx), exyz)
+
+
+def test_mf_triangulate_threshold_edges(ctx, oracle, synth):
+    """|dphi| < 0.1 strict, first k wins, invalid right pixels are skipped (mfreconstruct.cpp:292-295)"""
+    W, H = 16, 2
+    calib, _ = synth.make_calibration(W, H)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    phL = np.full((H, W), 10.0, np.float32)
+    phR = np.full((H, W), 50.0, np.float32)
+    vL = np.ones((H, W), np.uint8)
+    vR = np.ones((H, W), np.uint8)
+    phR[0, 3] = 10.0 + np.float32(0.1)                # not < 0.1 after f32 subtraction? decided by the oracle
+    phR[0, 5] = np.nextafter(np.float32(10.1), np.float32(0))
+    phR[0, 7] = 10.0
+    phR[1, 2] = 10.05
+    vR[1, 2] = 0                                      # skipped
+    phR[1, 9] = 9.95
+    vL[1, 4] = 0
+    exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
+    xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
+    assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz)
+    assert emk[1, 0] == 9 and emk[1, 4] == -1
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K5
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,with_T,color", [(640, 480, False, True), (320, 64, True, False), (70, 5, False, True)])
+def test_ge_triangulate_parity(ctx, oracle, synth, W, H, with_T, color):
+    scan_w = W
+    calib, _ = synth.make_calibration(W, H, with_T=with_T)
+    ctx.set_calibration(calib)
+    _, _, Q, T = calib_parts(oracle, calib)
+    st = synth.render_gray_stack(W, H, scan_w, seed=31, noise=3)
+    ncol = synth.gray_num_bits(scan_w)
+    cL, _, vL = oracle.gray_decode(st[0].numpy(), ncol, 0, BLACK, 0, scan_w, 0)
+    cR, _, vR = oracle.gray_decode(st[1].numpy(), ncol, 0, BLACK, 0, scan_w, 0)
+    wl = st[0, 0].numpy() if color else None
+    wr = st[1, 0].numpy() if color else None
+    exyz, ehas, ecol, emk = oracle.ge_triangulate(cL, vL, cR, vR, Q, T, wl, wr)
+    xyz, has, col, mk = ctx.ge_triangulate(cL, vL, cR, vR, wl, wr)
+    assert bits_equal(mk, emk) and bits_equal(has, ehas)
+    assert ehas.sum() > 0.3 * ehas.size
+    nb = assert_float_parity(xyz, exyz, 1e-4, "ge xyz")
+    assert nb == 0
+    if color:
+        assert bits_equal(col, ecol)
+
+
+def test_ge_kstart_semantics_adversarial(ctx, oracle, synth):
+    """random, non-monotone codes: the sequential kstart carry (reconstruct.cpp:556,561,604) must be reproduced
+    exactly by the wave-parallel speculative walk (many fix-up rounds)"""
+    rng = np.random.default_rng(17)
+    W, H = 300, 40
+    calib, _ = synth.make_calibration(W, H)
+    ctx.set_calibration(calib)
+    _, _, Q, T = calib_parts(oracle, calib)
+    for ncodes in (3, 17, 300):
+        cL = rng.integers(0, ncodes, size=(H, W), dtype=np.int32)
+        cR = rng.integers(0, ncodes, size=(H, W), dtype=np.int32)
+        vL = (rng.random((H, W)) < 0.8).astype(np.uint8)
+        vR = (rng.random((H, W)) < 0.8).astype(np.uint8)
+        cR[3] = np.sort(cR[3])[::-1]
+        cL[4] = np.sort(cL[4])
+        cR[4] = np.sort(cR[4])
+        exyz, ehas, _, emk = oracle.ge_triangulate(cL, vL, cR, vR, Q, T)
+        xyz, has, _, mk = ctx.ge_triangulate(cL, vL, cR, vR)
+        assert bits_equal(mk, emk), ncodes
+        assert bits_equal(has, ehas) and bits_equal(xyz, exyz)
+
+
+def test_ge_reprojection_known_answer(ctx, synth):
+    """KA7: Z = f*Tx / ((cx1-cx2) - d), X = (j-cx1)*Z/f, Y = (i-cy)*Z/f for a constant-disparity scene"""
+    W, H, d = 128, 8, 11
+    calib, info = synth.make_calibration(W, H)
+    ctx.set_calibration(calib)
+    code = np.broadcast_to(np.arange(W, dtype=np.int32), (H, W)).copy()
+    cL = code + 1000
+    cR = code + 1000 + d          # right pixel k shows what left pixel k+d shows -> j-k = d
+    v = np.ones((H, W), np.uint8)
+    xyz, has, _, mk = ctx.ge_triangulate(cL, v, cR, v)
+    j = np.arange(d, W)
+    assert np.array_equal(mk[2, d:], j - d) and not has[:, :d].any()
+    f, cx1, cx2, cy, Tx = info["f"], info["cx1"], info["cx2"], info["cy"], info["Tx"]
+    Wq = (-1.0 / Tx) * d + (cx1 - cx2) / Tx
+    assert np.allclose(xyz[2, d:, 2], f / Wq, rtol=1e-6)
+    assert np.allclose(xyz[2, d:, 0], (j - cx1) / Wq, rtol=1e-5, atol=1e-3)
+    assert np.allclose(xyz[2, d:, 1], (2 - cy) / Wq, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K3' scatter + K6
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,scan_w,scan_h,with_T", [(160, 120, 64, 48, False), (96, 64, 40, 33, True)])
+def test_ray_triangulate_parity(ctx, oracle, synth, W, H, scan_w, scan_h, with_T):
+    calib, _ = synth.make_calibration(W, H, with_T=with_T, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=41, noise=2, rows=True)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    dec = [oracle.gray_decode(st[c].numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h) for c in range(2)]
+    offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.ray_triangulate(dec[0][0], dec[0][1], dec[0][2], dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    assert bits_equal(cnt, ecnt)
+    assert (ecnt > 1).any(), "want buckets with several pairs so the accumulation order matters"
+    nb = assert_float_parity(xyz, exyz, 1e-4, "ray xyz")
+    assert nb == 0
+    # getPoint: sum / count
+    got = ctx.pointcloud_get(xyz, cnt)
+    assert bits_equal(got, oracle.pointcloud_get(exyz, ecnt))
+
+
+def test_ray_count_wraps_like_uchar(ctx, oracle, synth):
+    """> 255 pairs in one bucket: the u8 counter wraps and the next hit restarts the sum (pointcloudimage.cpp:90-95)"""
+    W, H, scan_w, scan_h = 40, 20, 4, 4
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    cx = np.zeros((H, W), np.int32)
+    cy = np.zeros((H, W), np.int32)
+    cx[:, W // 2:] = 2
+    cy[:, W // 2:] = 4                 # y == scan_h aliases bucket (3,0)  (Q9)
+    v = np.ones((H, W), np.uint8)
+    vR = np.zeros((H, W), np.uint8)
+    vR[:, :2] = 1                      # 40 right pixels x 400 left pixels in bucket (0,0) = 16000 pairs
+    vR[:2, W // 2:W // 2 + 3] = 1
+    offL, itL = oracle.gray_bucket(cx, cy, v, scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(cx, cy, vR, scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.ray_triangulate(cx, cy, v, cx, cy, vR, scan_w, scan_h)
+    assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz)
+    assert ecnt[0, 3] > 0               # the aliased bucket (x=3, y=0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# PointCloudImage adaptor (Q11) and whole-path drop-ins
+# ---------------------------------------------------------------------------------------------------------
+def test_pointcloud_from_grid_transpose_and_crop(ctx, oracle):
+    rng = np.random.default_rng(2)
+    W, H = 50, 30
+    xyz = rng.standard_normal((H, W, 3)).astype(np.float32)
+    has = (rng.random((H, W)) < 0.6).astype(np.uint8)
+    color = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    for scan_w, scan_h in [(64, 64), (20, 40), (30, 50), (7, 3)]:
+        es, ec, ek = oracle.pointcloud_from_grid(xyz, has, scan_w, scan_h, color)
+        s, c, k = ctx.pointcloud_from_grid(xyz, has, scan_w, scan_h, color)
+        assert bits_equal(c, ec) and bits_equal(s, es) and bits_equal(k, ek)
+
+
+def test_reconstruct_mf_whole_path(ctx, oracle, synth):
+    W, H = 320, 240
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    st = synth.render_mf_stack(W, H, seed=77)
+    maps = [synth.make_rectify_maps(W, H, cam) for cam in range(2)]
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    for rectify in (False, True):
+        dec = []
+        for cam in range(2):
+            pl = st[cam].numpy()
+            if rectify:
+                pl = np.stack([oracle.remap_u8(pl[p], maps[cam][0].numpy(), maps[cam][1].numpy()) for p in range(14)])
+            dec.append(oracle.mf_decode(pl, BLACK))
+        exyz, ehas, _ = oracle.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q, T)
+        xyz, has = ctx.reconstruct_mf(st[0].numpy(), st[1].numpy(), BLACK, rectify)
+        assert bits_equal(has, ehas) and bits_equal(xyz, exyz)
+        dxyz, dhas = ctx.reconstruct_mf(st[0].cuda(), st[1].cuda(), BLACK, rectify)
+        ctx.synchronize()
+        assert bits_equal(np_of(dhas), ehas) and bits_equal(np_of(dxyz), exyz)
+    # batch fast path: two frames
+    stack = torch.stack([st, synth.render_mf_stack(W, H, seed=78)]).cuda()
+    bx, bh = ctx.reconstruct_mf_batch(stack, BLACK, True)
+    ctx.synchronize()
+    assert bits_equal(np_of(bh[0]), ehas) and bits_equal(np_of(bx[0]), exyz)
+    assert not bits_equal(np_of(bx[1]), exyz)
+
+
+def test_reconstruct_ge_and_gray_whole_path(ctx, oracle, synth):
+    W, H, scan_w, scan_h = 256, 160, 256, 160
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    maps = [synth.make_rectify_maps(W, H, cam) for cam in range(2)]
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    st = synth.render_gray_stack(W, H, scan_w, seed=51, noise=2)
+    for rectify in (False, True):
+        dec, white = [], []
+        for cam in range(2):
+            pl = st[cam].numpy()
+            if rectify:
+                pl = np.stack([oracle.remap_u8(pl[p], maps[cam][0].numpy(), maps[cam][1].numpy())
+                               for p in range(pl.shape[0])])
+            white.append(pl[0])
+            dec.append(oracle.gray_decode(pl, ncol, 0, BLACK, 3, scan_w, 0))
+        exyz, ehas, ecol, _ = oracle.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], Q, T, white[0], white[1])
+        xyz, has, col = ctx.reconstruct_ge(st[0].numpy(), st[1].numpy(), ncol, BLACK, 3, scan_w, rectify, True)
+        assert bits_equal(has, ehas) and bits_equal(xyz, exyz) and bits_equal(col, ecol)
+    # GRAY_ONLY
+    st2 = synth.render_gray_stack(W, H, scan_w, scan_h, seed=52, noise=2, rows=True)
+    dec = [oracle.gray_decode(st2[c].numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h) for c in range(2)]
+    offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.reconstruct_gray(st2[0].numpy(), st2[1].numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h)
+    assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# error behaviour (reference: bool + QMessageBox; here: status codes, never an abort)
+# ---------------------------------------------------------------------------------------------------------
+def test_error_paths(slr, synth):
+    c = slr.Context(0)
+    pl = np.zeros((14, 8, 16), np.uint8)
+    with pytest.raises(slr.SlrError) as e:
+        c.mf_decode(pl, 40, rectify_cam=0)
+    assert e.value.status == slr.capi.ERR_NOT_CONFIGURED
+    with pytest.raises(slr.SlrError) as e:
+        c.mf_triangulate(np.zeros((8, 16), np.float32), np.zeros((8, 16), np.uint8),
+                         np.zeros((8, 16), np.float32), np.zeros((8, 16), np.uint8))
+    assert e.value.status == slr.capi.ERR_NOT_CONFIGURED
+    mx, mf = synth.identity_maps(32, 8)
+    c.set_rectify_maps(0, mx.numpy(), mf.numpy())
+    with pytest.raises(slr.SlrError) as e:
+        c.mf_decode(pl, 40, rectify_cam=0)             # map size != image size
+    assert e.value.status == slr.capi.ERR_INVALID_ARG
+    with pytest.raises(slr.SlrError) as e:
+        c.mf_decode(pl, 40, W=32)                      # pitch < W
+    assert e.value.status == slr.capi.ERR_INVALID_ARG
+    c.close()
