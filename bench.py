@@ -198,6 +198,28 @@ def main():
                     "unit": "GB/s", "frac": k0.get("frac_hbm_peak"), "traffic": traffic,
                     "avg_launch_us": k0["avg_us"], "alg_bytes_per_launch": ALG_BYTES.get(k0["name"], 0) * npix}
 
+    # outside the timed region: the other kernels of the path on the same frame (HIP-event timed, same stream):
+    # the unfused phase-decode+unwrap kernel (north_star's named roofline target), the standalone remap and the
+    # literal linear-sweep form of the match kernel
+    extras = []
+    if rank == 0 and args.profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        reps = 10
+        ph = torch.empty((H, W), dtype=torch.float32, device=dev)
+        vd = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        for _ in range(reps):
+            ctx.mf_decode(stack[0, 0], BLACK_THR, phase=ph, valid=vd)
+        if args.rectify:
+            tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
+            for _ in range(reps):
+                ctx.remap_u8(0, stack[0, 0, 3], out=tmp)
+        for name, (ms, n) in sorted(ctx.profile().items()):
+            gbs = ALG_BYTES[name] * npix / (ms / n * 1e-3) / 1e9
+            extras.append({"name": name, "launches": n, "avg_us": round(ms / n * 1e3, 2), "alg_bytes_per_px": ALG_BYTES[name],
+                           "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        ctx.profile_enable(False)
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         rows = args.cpu_rows or max(8, min(H, int(600 * (4096.0 / W) ** 2)))
@@ -216,7 +238,7 @@ def main():
                        "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", RCCL all-gather of XYZ+mask per step"
                                                                            if do_gather else "")},
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:

@@ -81,6 +81,10 @@ int          slr_destroy(slr_ctx *ctx);                          /* Reconstruct:
 int          slr_set_stream(slr_ctx *ctx, void *hip_stream);     /* borrow a caller stream (NULL -> ctx-owned stream) */
 int          slr_synchronize(slr_ctx *ctx);
 const char  *slr_last_error(const slr_ctx *ctx);
+/* tuning / test knobs.  SLR_OPT_MF_MATCH_ALGO: 0 = auto, 1 = linear LDS sweep (the literal form of
+ * mfreconstruct.cpp:289-331), 2 = indexed exact form (sorted distinct phases).  Both give identical results. */
+#define SLR_OPT_MF_MATCH_ALGO 1
+int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */
 /* replaces MFReconstruct::loadCameras (mfreconstruct.cpp:67-108) / Reconstruct::loadCameras

@@ -1,0 +1,58 @@
+"""Small driver for rocprofv3 runs: launches each kernel of the MF / Gray paths a few times on one 4096x3000 frame.
+Used by profiles/run_profile.sh (kernel-trace stats and separate --pmc passes); not part of the product."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+slr = importlib.import_module("structure-light-reconstructor_amd")
+synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+
+W = int(os.environ.get("SLR_W", "4096"))
+H = int(os.environ.get("SLR_H", "3000"))
+REPS = int(os.environ.get("SLR_REPS", "3"))
+WHAT = os.environ.get("SLR_WHAT", "mf").split(",")
+dev = torch.device("cuda", 0)
+ctx = slr.Context(0)
+calib, _ = synth.make_calibration(W, H)
+ctx.set_calibration(calib)
+maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
+torch.cuda.synchronize()
+for cam in range(2):
+    ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+
+if "mf" in WHAT:
+    st = synth.render_mf_stack(W, H, seed=1234, device=dev)
+    torch.cuda.synchronize()
+    ph = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+    vd = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+    for _ in range(REPS):
+        ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0])                     # K2 unfused
+    for _ in range(REPS):
+        for cam in range(2):
+            ctx.mf_decode(st[cam], 40, rectify_cam=cam, phase=ph[cam], valid=vd[cam])   # fused K1+K2
+    for _ in range(REPS):
+        ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4 indexed
+    tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    for _ in range(REPS):
+        ctx.remap_u8(0, st[0, 3], out=tmp)                                     # K1
+    if "sweep" in WHAT:
+        ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 1)
+        ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4 linear sweep
+        ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
+if "gray" in WHAT:
+    g = synth.render_gray_stack(W, H, W, seed=1234, device=dev)
+    ncol = synth.gray_num_bits(W)
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0) for cam in range(2)]          # K3
+    for _ in range(REPS):
+        dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0, rectify_cam=cam) for cam in range(2)]   # fused K1+K3
+    for _ in range(REPS):
+        ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False)   # K5
+ctx.synchronize()
+ctx.close()
+print("prof_driver done")

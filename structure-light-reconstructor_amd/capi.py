@@ -15,13 +15,14 @@ LIB_PATH = os.path.join(_HERE, "libslr_hip.so")
 MF_PLANES = 14
 MAX_GRAY_BITS = 16
 MEM_HOST, MEM_DEVICE = 0, 1
+OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (sorted distinct phases)
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED, ERR_OOM = 0, -1, -2, -3, -4, -5, -6
 
 # every symbol include/slr.h declares (checked by tests/test_capi_symbols.py without a GPU)
 SYMBOLS = [
     "slr_version", "slr_status_string", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
-    "slr_last_error", "slr_set_calibration", "slr_set_rectify_maps", "slr_remap_u8", "slr_mf_decode",
+    "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_remap_u8", "slr_mf_decode",
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch",
@@ -190,6 +191,9 @@ class Context:
         """stream: raw hipStream_t as int, a torch.cuda.Stream, or None for the ctx-owned stream."""
         raw = getattr(stream, "cuda_stream", stream)
         self._chk(self.lib.slr_set_stream(self.h, C.c_void_p(raw)))
+
+    def set_option(self, option, value):
+        self._chk(self.lib.slr_set_option(self.h, C.c_int(option), C.c_int(value)))
 
     def synchronize(self):
         self._chk(self.lib.slr_synchronize(self.h))

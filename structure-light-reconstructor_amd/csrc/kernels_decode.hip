@@ -274,12 +274,69 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
         }
         float ph[V];
         unsigned vw = 0;
+        Tap taps[V];
+#pragma unroll
+        for (int i = 0; i < V; i++)
+            taps[i] = make_tap((int)(short)(xyw[i] & 0xFFFFu), (int)(short)(xyw[i] >> 16), frw[i], pitch, W, H);
+        // rectified samples of the V pixels, one packed word (V bytes) per plane
+        unsigned packed[SLR_MF_PLANES];
+        bool fast = false;
+        if constexpr (V == 4) {
+            // Fast path (almost every thread of a real map): the four 2x2 footprints share their two source
+            // rows and fit an 8-byte window -> two unaligned 8-byte loads per plane instead of 16 byte loads;
+            // tap pairs are cut out with v_perm_b32 and blended with v_dot4_u32_u8 (weights <= 32 fit u8).
+            const int sy = taps[0].sy;
+            int sxmin = taps[0].sx, sxmax = taps[0].sx;
+            bool same = taps[0].kind == 0;
+#pragma unroll
+            for (int i = 1; i < 4; i++) {
+                same = same && taps[i].kind == 0 && taps[i].sy == sy;
+                sxmin = taps[i].sx < sxmin ? taps[i].sx : sxmin;
+                sxmax = taps[i].sx > sxmax ? taps[i].sx : sxmax;
+            }
+            fast = same && (sxmax - sxmin) <= 6 && (sxmin + 8) <= W;
+            if (fast) {
+                typedef unsigned long long u64u __attribute__((aligned(1)));
+                const int off = sy * pitch + sxmin;
+                unsigned sel[4], wx[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned o = (unsigned)(taps[i].sx - sxmin);
+                    sel[i] = o | ((o + 1) << 8) | 0x0C0C0000u;           // bytes o, o+1 of the window; 0 above
+                    wx[i] = (unsigned)taps[i].wx0 | ((unsigned)taps[i].wx1 << 8);
+                }
+#pragma unroll
+                for (int p = 0; p < SLR_MF_PLANES; p++) {
+                    const unsigned long long r0 = *reinterpret_cast<const u64u *>(pl.p[p] + off);
+                    const unsigned long long r1 = *reinterpret_cast<const u64u *>(pl.p[p] + off + pitch);
+                    unsigned w = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const unsigned p0 = __builtin_amdgcn_perm((unsigned)(r0 >> 32), (unsigned)r0, sel[i]);
+                        const unsigned p1 = __builtin_amdgcn_perm((unsigned)(r1 >> 32), (unsigned)r1, sel[i]);
+                        const unsigned h0 = __builtin_amdgcn_udot4(p0, wx[i], 0u, false);
+                        const unsigned h1 = __builtin_amdgcn_udot4(p1, wx[i], 0u, false);
+                        const unsigned v = (h0 * (unsigned)taps[i].wy0 + h1 * (unsigned)taps[i].wy1 + 512u) >> 10;
+                        w |= v << (8 * i);
+                    }
+                    packed[p] = w;
+                }
+            }
+        }
+        if (!fast) {
+#pragma unroll
+            for (int p = 0; p < SLR_MF_PLANES; p++) {
+                unsigned w = 0;
+#pragma unroll
+                for (int i = 0; i < V; i++) w |= (unsigned)sample(pl.p[p], pitch, W, H, taps[i]) << (8 * i);
+                packed[p] = w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < V; i++) {
-            const Tap t = make_tap((int)(short)(xyw[i] & 0xFFFFu), (int)(short)(xyw[i] >> 16), frw[i], pitch, W, H);
             int gpx[SLR_MF_PLANES];
 #pragma unroll
-            for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = sample(pl.p[p], pitch, W, H, t);
+            for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (packed[p] >> (8 * i)) & 0xFFu;
             int v;
             ph[i] = mf_pixel(gpx, black_thr, lut, v);
             vw |= (unsigned)v << (8 * i);

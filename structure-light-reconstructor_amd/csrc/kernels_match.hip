@@ -14,6 +14,7 @@
 // no FMA contraction changes a rounding.
 #include "slr_device.hpp"
 
+#include <hipcub/hipcub.hpp>
 #include <math.h>
 
 namespace slr {
@@ -122,10 +123,137 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K4 (exact indexed form).  The sweep above is O(W) per left pixel; the same answer is available in
+// O(log W) because "first k (ascending) with |phiL - phiR[k]| < 0.1" only ever selects, for each DISTINCT
+// right phase value, that value's smallest column:
+//   1. one workgroup per row radix-sorts the right row's (sortable(phi), k) pairs in LDS (stable, so equal
+//      phases stay in ascending k); invalid / NaN pixels get the maximal key;
+//   2. run heads (phi != predecessor) are compacted -> D_phi[] ascending distinct values, D_k[] their min k;
+//   3. every left pixel binary-searches the first distinct value >= phiL - 0.1001 (compared in f64, exact) and
+//      walks forward while <= phiL + 0.1001, applying the reference's own f32 predicate
+//      fabsf(phiL - phiR) < 0.1f and keeping the smallest k.  The window is a strict superset of every value
+//      that can satisfy the predicate, so the result is identical to the linear sweep (asserted against both
+//      the oracle and the brute-force kernel in tests).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned sortable_key(float f)
+{
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(unsigned k)
+{
+    return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+template <int IPT>
+__global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                              const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                              int W, int H, DevCalib cal, float *__restrict__ xyz,
+                                                              uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int N = 256 * IPT;
+    typedef hipcub::BlockRadixSort<unsigned, 256, IPT, unsigned short> Sort;
+    typedef hipcub::BlockScan<int, 256> Scan;
+    __shared__ union {
+        typename Sort::TempStorage sort;
+        struct { float phi[N]; unsigned short k[N]; } d;
+    } sh;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ unsigned last_key[256];
+    __shared__ int n_distinct;
+
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)row * W;
+
+    unsigned keys[IPT];
+    unsigned short vals[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const int k = tid * IPT + i;                     // blocked arrangement: stable order == ascending k
+        unsigned key = 0xFFFFFFFFu;
+        if (k < W && validR[base + k]) {
+            const float p = phaseR[base + k];
+            if (p == p) key = sortable_key(p);           // NaN can never satisfy the predicate
+        }
+        keys[i] = key;
+        vals[i] = (unsigned short)k;
+    }
+    Sort(sh.sort).Sort(keys, vals);
+    last_key[tid] = keys[IPT - 1];
+    __syncthreads();                                     // also: everybody is done with sh.sort
+    unsigned prev = tid ? last_key[tid - 1] : 0xFFFFFFFFu;
+    int heads = 0;
+    unsigned headmask = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const bool h = keys[i] != 0xFFFFFFFFu && (keys[i] != prev || (tid == 0 && i == 0));
+        prev = keys[i];
+        headmask |= h ? (1u << i) : 0u;
+        heads += h ? 1 : 0;
+    }
+    int pos, total;
+    Scan(scan_tmp).ExclusiveSum(heads, pos, total);
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (headmask & (1u << i)) { sh.d.phi[pos] = key_to_float(keys[i]); sh.d.k[pos] = vals[i]; pos++; }
+    if (tid == 0) n_distinct = total;
+    __syncthreads();
+    const int nd = n_distinct;
+
+    for (int j0 = 0; j0 < W; j0 += 256) {
+        const int j = j0 + tid;
+        if (j >= W) break;
+        int best = -1;
+        if (validL[base + j]) {
+            const float pl = phaseL[base + j];
+            const double lo_v = (double)pl - 0.1001, hi_v = (double)pl + 0.1001;
+            int lo = 0, hi = nd;                         // first index with D_phi >= lo_v (false for NaN pl)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((double)sh.d.phi[mid] < lo_v) lo = mid + 1; else hi = mid;
+            }
+            unsigned bk = 0xFFFFFFFFu;
+            for (int idx = lo; idx < nd; idx++) {
+                const float pr = sh.d.phi[idx];
+                if (!((double)pr <= hi_v)) break;
+                if (fabsf(pl - pr) < 0.1f) { const unsigned kk = sh.d.k[idx]; bk = kk < bk ? kk : bk; }
+            }
+            best = bk == 0xFFFFFFFFu ? -1 : (int)bk;
+        }
+        float X[3] = {0.0f, 0.0f, 0.0f};
+        if (best >= 0) {
+            float ulx, uly, urx, ury;
+            undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);
+            undistort_point((float)best, (float)row, cal.cam[1], urx, ury);
+            reproject(cal.Q, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);
+            if (cal.has_T) apply_T(cal.T, X);
+        }
+        float *o = xyz + 3 * (base + j);
+        o[0] = X[0]; o[1] = X[1]; o[2] = X[2];
+        has[base + j] = best >= 0 ? 1 : 0;
+        if (match_k) match_k[base + j] = best;
+    }
+}
+
+// algo: 0 = auto (indexed form when the row fits 256 x 32 items, else the sweep), 1 = sweep, 2 = indexed
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
-                           hipStream_t s)
+                           int algo, hipStream_t s)
 {
+    if (algo != 1 && W <= 256 * 32) {
+#define SLR_SORTED(IPT)                                                                                          \
+    hipLaunchKernelGGL(mf_match_sorted_kernel<IPT>, dim3(H), dim3(256), 0, s, phaseL, validL, phaseR, validR, W, \
+                       H, cal, xyz, has, match_k)
+        if (W <= 256) SLR_SORTED(1);
+        else if (W <= 512) SLR_SORTED(2);
+        else if (W <= 1024) SLR_SORTED(4);
+        else if (W <= 2048) SLR_SORTED(8);
+        else if (W <= 4096) SLR_SORTED(16);
+        else SLR_SORTED(32);
+#undef SLR_SORTED
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);
     hipLaunchKernelGGL(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, cal,
                        xyz, has, match_k);

@@ -48,6 +48,7 @@ struct slr_ctx {
     int16_t *d_map_xy[2] = {nullptr, nullptr};
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     int map_w = 0, map_h = 0;
+    int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     void *scratch[S_COUNT] = {};
     size_t scratch_cap[S_COUNT] = {};
     // profiler
@@ -526,7 +527,7 @@ int slr_mf_triangulate(slr_ctx *c, const float *phaseL, const uint8_t *validL, c
     SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh)); SLR_TRY(st.out(match_k, n * 4, &dk));
     { ProfScope ps(c, K_MF_MATCH);
       SLR_HIP(c, launch_mf_match((const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
-                                 c->cal, (float *)dx, (uint8_t *)dh, (int32_t *)dk, c->stream)); }
+                                 c->cal, (float *)dx, (uint8_t *)dh, (int32_t *)dk, c->opt_mf_match_algo, c->stream)); }
     return st.finish();
 }
 
@@ -618,7 +619,7 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
     SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
     { ProfScope ps(c, K_MF_MATCH);
       SLR_HIP(c, launch_mf_match((const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H,
-                                 c->cal, xyz, has, nullptr, c->stream)); }
+                                 c->cal, xyz, has, nullptr, c->opt_mf_match_algo, c->stream)); }
     return SLR_OK;
 }
 
@@ -744,6 +745,19 @@ int slr_reconstruct_gray(slr_ctx *c, const uint8_t *const *planesL, const uint8_
     SLR_TRY(core_ray(c, (const int32_t *)cxl, (const int32_t *)cyl, (const uint8_t *)vl, (const int32_t *)cxr,
                      (const int32_t *)cyr, (const uint8_t *)vr, W, H, scan_w, scan_h, (float *)dx, (uint8_t *)dc));
     return st.finish();
+}
+
+int slr_set_option(slr_ctx *c, int option, int value)
+{
+    if (!c) return SLR_ERR_INVALID_ARG;
+    switch (option) {
+        case SLR_OPT_MF_MATCH_ALGO:
+            if (value < 0 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0, 1 or 2");
+            c->opt_mf_match_algo = value;
+            return SLR_OK;
+        default:
+            return fail(c, SLR_ERR_INVALID_ARG, "unknown option");
+    }
 }
 
 // ---- measurement hooks --------------------------------------------------------------------------------------

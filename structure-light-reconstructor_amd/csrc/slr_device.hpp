@@ -54,7 +54,7 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
 
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
-                           float *xyz, uint8_t *has, int32_t *match_k, hipStream_t s);
+                           float *xyz, uint8_t *has, int32_t *match_k, int algo, hipStream_t s);
 
 hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
