@@ -1,0 +1,69 @@
+"""Per-kernel micro-benchmark (HIP-event timed through the library's own profiler) used while tuning.
+usage: python profiles/microbench.py [W H reps]   -- prints one line per kernel/variant."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+slr = importlib.import_module("structure-light-reconstructor_amd")
+synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+cap = slr.capi
+
+W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+dev = torch.device("cuda", 0)
+ctx = slr.Context(0)
+calib, _ = synth.make_calibration(W, H)
+ctx.set_calibration(calib)
+maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
+torch.cuda.synchronize()
+for cam in range(2):
+    ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+st = synth.render_mf_stack(W, H, seed=1234, device=dev)
+torch.cuda.synchronize()
+npx = float(W) * H
+
+
+def run(label, fn, bytes_per_px, warm=2):
+    for _ in range(warm):
+        fn()
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    for _ in range(REPS):
+        fn()
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+    for name, (ms, n) in prof.items():
+        us = ms / n * 1e3
+        print("%-34s %-28s %9.1f us  %8.1f GB/s (alg %4.1f B/px)  %5.1f %% of 8 TB/s" %
+              (label, name, us, bytes_per_px * npx / us / 1e3, bytes_per_px, bytes_per_px * npx / us / 1e3 / 80.0))
+
+
+ph = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+vd = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
+for vec in (16, 8, 4):
+    ctx.set_option(cap.OPT_MF_DECODE_VEC, vec)
+    run("mf_decode vec=%d" % vec, lambda: ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0]), 19.0)
+ctx.set_option(cap.OPT_MF_DECODE_VEC, 0)
+run("mf_rectify_decode", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+ctx.mf_decode(st[1], 40, rectify_cam=1, phase=ph[1], valid=vd[1])
+tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
+run("remap", lambda: ctx.remap_u8(0, st[0, 3], out=tmp), 8.0)
+run("mf_match indexed", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0)
+if "--sweep" in sys.argv:
+    ctx.set_option(cap.OPT_MF_MATCH_ALGO, 1)
+    run("mf_match sweep", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0, warm=0)
+    ctx.set_option(cap.OPT_MF_MATCH_ALGO, 0)
+if "--gray" in sys.argv:
+    g = synth.render_gray_stack(W, H, W, seed=1234, device=dev)
+    ncol = synth.gray_num_bits(W)
+    torch.cuda.synchronize()
+    run("gray_decode", lambda: ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0), 2 + 2 * ncol + 5.0)
+    run("gray_rectify_decode", lambda: ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0, rectify_cam=0), 2 + 2 * ncol + 6 + 5.0)
+    dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0) for cam in range(2)]
+    run("ge_match", lambda: ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False), 23.0)
+ctx.close()

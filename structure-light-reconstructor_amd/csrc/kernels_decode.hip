@@ -259,7 +259,13 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
     load_lut(lut, lut_g);
     const int gpr = W / V;
     const unsigned total = (unsigned)gpr * (unsigned)H;
-    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+    // XCD-aware block order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed only).  Give
+    // every XCD a contiguous band of the image so that the two source rows shared by vertically adjacent
+    // destination rows are served by ONE XCD's L2 instead of being fetched from HBM by two.
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    unsigned vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (nb % 8 != 0) vb = blockIdx.x;                       // launcher keeps nb a multiple of 8; safety net
+    for (unsigned g = vb * 256u + threadIdx.x; g < total; g += nb * 256u) {
         const unsigned row = g / gpr, col0 = (g - row * gpr) * V;
         const size_t m = (size_t)row * W + col0;
         unsigned xyw[V], frw[V];
@@ -285,37 +291,49 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
             // Fast path (almost every thread of a real map): the four 2x2 footprints share their two source
             // rows and fit an 8-byte window -> two unaligned 8-byte loads per plane instead of 16 byte loads;
             // tap pairs are cut out with v_perm_b32 and blended with v_dot4_u32_u8 (weights <= 32 fit u8).
-            const int sy = taps[0].sy;
+            // The four footprints of a smooth map cover at most three source rows (sy changes by <= 1 inside
+            // the group) and an 8-byte column window: three unaligned 8-byte loads per plane, no branches, so
+            // all 42 loads of a thread are in flight together.
+            int symin = taps[0].sy, symax = taps[0].sy;
             int sxmin = taps[0].sx, sxmax = taps[0].sx;
-            bool same = taps[0].kind == 0;
+            bool inl = taps[0].kind == 0;
 #pragma unroll
             for (int i = 1; i < 4; i++) {
-                same = same && taps[i].kind == 0 && taps[i].sy == sy;
+                inl = inl && taps[i].kind == 0;
+                symin = taps[i].sy < symin ? taps[i].sy : symin;
+                symax = taps[i].sy > symax ? taps[i].sy : symax;
                 sxmin = taps[i].sx < sxmin ? taps[i].sx : sxmin;
                 sxmax = taps[i].sx > sxmax ? taps[i].sx : sxmax;
             }
-            fast = same && (sxmax - sxmin) <= 6 && (sxmin + 8) <= W;
+            fast = inl && (symax - symin) <= 1 && (sxmax - sxmin) <= 6 && (sxmin + 8) <= W;
             if (fast) {
                 typedef unsigned long long u64u __attribute__((aligned(1)));
-                const int off = sy * pitch + sxmin;
+                const int off0 = symin * pitch + sxmin;
+                // third row only matters when some footprint starts at symin+1 (then symin+2 <= H-1 because that
+                // tap is an inlier); otherwise re-read row symin+1 so the address is always inside the image
+                const int off2 = off0 + ((symax > symin) ? 2 : 1) * pitch;
                 unsigned sel[4], wx[4];
+                bool dy[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const unsigned o = (unsigned)(taps[i].sx - sxmin);
                     sel[i] = o | ((o + 1) << 8) | 0x0C0C0000u;           // bytes o, o+1 of the window; 0 above
                     wx[i] = (unsigned)taps[i].wx0 | ((unsigned)taps[i].wx1 << 8);
+                    dy[i] = taps[i].sy != symin;
                 }
 #pragma unroll
                 for (int p = 0; p < SLR_MF_PLANES; p++) {
-                    const unsigned long long r0 = *reinterpret_cast<const u64u *>(pl.p[p] + off);
-                    const unsigned long long r1 = *reinterpret_cast<const u64u *>(pl.p[p] + off + pitch);
+                    const unsigned long long r0 = *reinterpret_cast<const u64u *>(pl.p[p] + off0);
+                    const unsigned long long r1 = *reinterpret_cast<const u64u *>(pl.p[p] + off0 + pitch);
+                    const unsigned long long r2 = *reinterpret_cast<const u64u *>(pl.p[p] + off2);
                     unsigned w = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const unsigned p0 = __builtin_amdgcn_perm((unsigned)(r0 >> 32), (unsigned)r0, sel[i]);
-                        const unsigned p1 = __builtin_amdgcn_perm((unsigned)(r1 >> 32), (unsigned)r1, sel[i]);
-                        const unsigned h0 = __builtin_amdgcn_udot4(p0, wx[i], 0u, false);
-                        const unsigned h1 = __builtin_amdgcn_udot4(p1, wx[i], 0u, false);
+                        const unsigned q0 = __builtin_amdgcn_perm((unsigned)(r0 >> 32), (unsigned)r0, sel[i]);
+                        const unsigned q1 = __builtin_amdgcn_perm((unsigned)(r1 >> 32), (unsigned)r1, sel[i]);
+                        const unsigned q2 = __builtin_amdgcn_perm((unsigned)(r2 >> 32), (unsigned)r2, sel[i]);
+                        const unsigned h0 = __builtin_amdgcn_udot4(dy[i] ? q1 : q0, wx[i], 0u, false);
+                        const unsigned h1 = __builtin_amdgcn_udot4(dy[i] ? q2 : q1, wx[i], 0u, false);
                         const unsigned v = (h0 * (unsigned)taps[i].wy0 + h1 * (unsigned)taps[i].wy1 + 512u) >> 10;
                         w |= v << (8 * i);
                     }
@@ -354,14 +372,16 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
 
 static unsigned pick_blocks(size_t groups)
 {
-    // memory-bound streaming: cap at 256 CUs x 8 workgroups and grid-stride the rest
+    // One workgroup per 256 work items (no persistent grid-stride): with a capped grid the last sweep leaves
+    // CUs idle (12.3 Mpx / (2048 x 256 x 16 px) = 1.46 sweeps -> 27 % of the machine-time wasted); small blocks
+    // let the dispatcher back-fill.  Rounded up to a multiple of 8 for the XCD band mapping of the fused kernel.
     const size_t b = (groups + 255) / 256;
-    return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
+    return (unsigned)(((b ? b : 1) + 7) & ~(size_t)7);
 }
 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
-                            hipStream_t s)
+                            int vec_hint, hipStream_t s)
 {
     if (map_xy) {
         const bool vec = (W % 4 == 0);
@@ -378,7 +398,15 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
     }
     a16 = a16 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 16 == 0);
     a4 = a4 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0);
-    if (a16)      hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 16) * H)), dim3(256), 0, s,
+    const bool a8 = a4 && (W % 8 == 0) && (pitch % 8 == 0) && ((uintptr_t)valid % 8 == 0) && [&] {
+        for (int p = 0; p < SLR_MF_PLANES; p++) if ((uintptr_t)pl.p[p] % 8) return false;
+        return true; }();
+    if (vec_hint == 4) a16 = false;
+    if (a16 && vec_hint != 8)
+                  hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 16) * H)), dim3(256), 0, s,
+                                     pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    else if (a8 && vec_hint == 8)
+                  hipLaunchKernelGGL(mf_decode_kernel<2>, dim3(pick_blocks((size_t)(W / 8) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);

@@ -149,7 +149,9 @@ __device__ __forceinline__ float key_to_float(unsigned k)
 template <int IPT>
 __global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
-                                                              int W, int H, DevCalib cal, float *__restrict__ xyz,
+                                                              int W, int H, DevCalib cal,
+                                                              const float2 *__restrict__ undL, const float *__restrict__ undRx,
+                                                              float *__restrict__ xyz,
                                                               uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
 {
     constexpr int N = 256 * IPT;
@@ -224,8 +226,14 @@ __global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__res
         float X[3] = {0.0f, 0.0f, 0.0f};
         if (best >= 0) {
             float ulx, uly, urx, ury;
-            undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);
-            undistort_point((float)best, (float)row, cal.cam[1], urx, ury);
+            if (undL) {                                  // per-pixel values precomputed by undistort_table_kernel
+                const float2 u = undL[base + j];
+                ulx = u.x; uly = u.y;
+                urx = undRx[base + best];
+            } else {
+                undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);
+                undistort_point((float)best, (float)row, cal.cam[1], urx, ury);
+            }
             reproject(cal.Q, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);
             if (cal.has_T) apply_T(cal.T, X);
         }
@@ -236,15 +244,41 @@ __global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__res
     }
 }
 
+// Utilities::undistortPoints depends only on the pixel position and the camera, so its 5 f64 fixed-point
+// iterations (utilities.cpp:83-91) are evaluated once per (calibration, image size) into tables -- bit-identical
+// values, ~550 f64-heavy instructions per matched pixel removed from K4.  left: (x,y); right: x only (:299).
+__global__ __launch_bounds__(256) void undistort_table_kernel(DevCalib cal, int W, int H, float2 *__restrict__ undL,
+                                                              float *__restrict__ undRx)
+{
+    const unsigned total = (unsigned)W * (unsigned)H;
+    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+        const unsigned row = g / W, col = g - row * W;
+        float x, y, rx, ry;
+        undistort_point((float)col, (float)row, cal.cam[0], x, y);
+        undistort_point((float)col, (float)row, cal.cam[1], rx, ry);
+        undL[g] = make_float2(x, y);
+        undRx[g] = rx;
+    }
+}
+
+hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *undL_xy, float *undRx, hipStream_t s)
+{
+    const size_t n = (size_t)W * H;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(undistort_table_kernel, dim3(blocks), dim3(256), 0, s, cal, W, H, (float2 *)undL_xy, undRx);
+    return hipGetLastError();
+}
+
 // algo: 0 = auto (indexed form when the row fits 256 x 32 items, else the sweep), 1 = sweep, 2 = indexed
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
-                           int algo, hipStream_t s)
+                           int algo, const float *undL_xy, const float *undRx, hipStream_t s)
 {
+    const float2 *undL = (const float2 *)undL_xy;
     if (algo != 1 && W <= 256 * 32) {
 #define SLR_SORTED(IPT)                                                                                          \
     hipLaunchKernelGGL(mf_match_sorted_kernel<IPT>, dim3(H), dim3(256), 0, s, phaseL, validL, phaseR, validR, W, \
-                       H, cal, xyz, has, match_k)
+                       H, cal, undL, undRx, xyz, has, match_k)
         if (W <= 256) SLR_SORTED(1);
         else if (W <= 512) SLR_SORTED(2);
         else if (W <= 1024) SLR_SORTED(4);
@@ -288,21 +322,29 @@ __device__ __forceinline__ void bitonic_sort_lds(unsigned *S, int N)
 
 __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
                                                        const int32_t *__restrict__ codeR, const uint8_t *__restrict__ validR,
-                                                       int W, int H, int N, DevCalib cal,
+                                                       int W, int H, int N, int TC, DevCalib cal,
                                                        const uint8_t *__restrict__ whiteL, const uint8_t *__restrict__ whiteR,
                                                        float *__restrict__ xyz, uint8_t *__restrict__ has,
                                                        uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
 {
-    extern __shared__ unsigned S[];                // N = next pow2 >= W keys
-    const int row = blockIdx.x;
+    extern __shared__ unsigned S[];                // N = next pow2 >= W sorted keys, then TC u16 list heads
+    unsigned short *first = reinterpret_cast<unsigned short *>(S + N);   // first[code] = index of the code's
+    const int row = blockIdx.x;                                          // smallest column in S (0xFFFF = none)
     const size_t base = (size_t)row * W;
     for (int k = threadIdx.x; k < N; k += 256) {
         unsigned key = 0xFFFFFFFFu;
         if (k < W && validR[base + k]) key = ((unsigned)codeR[base + k] << 16) | (unsigned)k;
         S[k] = key;
     }
+    for (int t = threadIdx.x; t < TC; t += 256) first[t] = 0xFFFFu;
     __syncthreads();
     bitonic_sort_lds(S, N);
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const unsigned v = S[i];
+        if (v != 0xFFFFFFFFu && (v >> 16) < (unsigned)TC && (i == 0 || (S[i - 1] >> 16) != (v >> 16)))
+            first[v >> 16] = (unsigned short)i;
+    }
+    __syncthreads();
     if (threadIdx.x >= 64) return;                 // wave 0 walks; no barrier below this line
 
     const int lane = threadIdx.x;
@@ -317,6 +359,15 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
             if (c >= 0) {
                 const unsigned target = ((unsigned)c << 16) | (unsigned)my_ks;
                 int lo = 0, hi = N;                // first index with S[idx] >= target
+                if (c < TC) {
+                    // direct list head, then a short forward scan over the code's ascending columns; only long
+                    // lists (degenerate rows) fall back to the binary search, restricted to [lo, N)
+                    const unsigned f = first[c];
+                    lo = f == 0xFFFFu ? N : (int)f;
+                    int steps = 0;
+                    while (lo < N && S[lo] < target && steps < 6) { lo++; steps++; }
+                    if (lo >= N || S[lo] >= target) hi = lo;
+                }
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (S[mid] < target) lo = mid + 1; else hi = mid;
@@ -364,8 +415,9 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
 {
     int N = 2;
     while (N < W) N <<= 1;
-    hipLaunchKernelGGL(ge_match_kernel, dim3(H), dim3(256), (size_t)N * sizeof(unsigned), s, codeL, validL, codeR,
-                       validR, W, H, N, cal, whiteL, whiteR, xyz, has, color, match_k);
+    const int TC = 8192;                           // codes below this use the direct list-head table (16 KB LDS)
+    hipLaunchKernelGGL(ge_match_kernel, dim3(H), dim3(256), (size_t)N * sizeof(unsigned) + (size_t)TC * 2, s, codeL,
+                       validL, codeR, validR, W, H, N, TC, cal, whiteL, whiteR, xyz, has, color, match_k);
     return hipGetLastError();
 }
 

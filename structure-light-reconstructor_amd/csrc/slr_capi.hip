@@ -21,7 +21,7 @@ namespace {
 const char *kKernelNames[K_COUNT] = {
     "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_keys", "slr_ray_sort", "slr_ray_triangulate",
-    "slr_pc_from_grid", "slr_pc_get"};
+    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -29,7 +29,7 @@ enum Slot {
     S_PHASE_L = 16, S_VALID_L, S_PHASE_R, S_VALID_R,
     S_CODEX_L, S_CODEY_L, S_CODEX_R, S_CODEY_R,
     S_KEYS_A, S_KEYS_B, S_ITEMS_A, S_ITEMS_B, S_KEYS_L, S_ITEMS_L, S_SORT_TMP,
-    S_XYZ, S_HAS, S_COLOR,
+    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R,
     S_COUNT
 };
 
@@ -49,6 +49,9 @@ struct slr_ctx {
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
+    int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
+    bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
+    int und_w = 0, und_h = 0;
     void *scratch[S_COUNT] = {};
     size_t scratch_cap[S_COUNT] = {};
     // profiler
@@ -232,7 +235,31 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
     ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
-                                c->stream));
+                                c->opt_mf_decode_vec, c->stream));
+    return SLR_OK;
+}
+
+// K4 with the per-(calibration,size) undistortion tables (built lazily, invalidated by slr_set_calibration)
+int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *phR, const uint8_t *vR, int W, int H,
+                  float *xyz, uint8_t *has, int32_t *match_k)
+{
+    const size_t n = (size_t)W * H;
+    const float *undL = nullptr, *undR = nullptr;
+    if (c->opt_mf_match_algo != 1 && W <= 256 * 32) {
+        void *a, *b;
+        if (c->scratch_cap[S_UND_L] < n * 8 || c->scratch_cap[S_UND_R] < n * 4) c->und_valid = false;   // will realloc
+        SLR_TRY(get_scratch(c, S_UND_L, n * 8, &a));
+        SLR_TRY(get_scratch(c, S_UND_R, n * 4, &b));
+        if (!c->und_valid || c->und_w != W || c->und_h != H) {
+            ProfScope ps(c, K_UNDISTORT_TABLE);
+            SLR_HIP(c, launch_undistort_tables(c->cal, W, H, (float *)a, (float *)b, c->stream));
+            c->und_valid = true; c->und_w = W; c->und_h = H;
+        }
+        undL = (const float *)a; undR = (const float *)b;
+    }
+    ProfScope ps(c, K_MF_MATCH);
+    SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, H, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
+                               c->stream));
     return SLR_OK;
 }
 
@@ -394,6 +421,7 @@ int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
     memcpy(c->cal.T, cal->T, sizeof(c->cal.T));
     c->cal.has_T = cal->has_T ? 1 : 0;
     c->has_calib = true;
+    c->und_valid = false;
     return SLR_OK;
 }
 
@@ -525,9 +553,8 @@ int slr_mf_triangulate(slr_ctx *c, const float *phaseL, const uint8_t *validL, c
     SLR_TRY(st.in(phaseL, n * 4, &pl)); SLR_TRY(st.in(validL, n, &vl));
     SLR_TRY(st.in(phaseR, n * 4, &pr)); SLR_TRY(st.in(validR, n, &vr));
     SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh)); SLR_TRY(st.out(match_k, n * 4, &dk));
-    { ProfScope ps(c, K_MF_MATCH);
-      SLR_HIP(c, launch_mf_match((const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
-                                 c->cal, (float *)dx, (uint8_t *)dh, (int32_t *)dk, c->opt_mf_match_algo, c->stream)); }
+    SLR_TRY(core_mf_match(c, (const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
+                          (float *)dx, (uint8_t *)dh, (int32_t *)dk));
     return st.finish();
 }
 
@@ -617,10 +644,8 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
     SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vR));
     SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
     SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
-    { ProfScope ps(c, K_MF_MATCH);
-      SLR_HIP(c, launch_mf_match((const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H,
-                                 c->cal, xyz, has, nullptr, c->opt_mf_match_algo, c->stream)); }
-    return SLR_OK;
+    return core_mf_match(c, (const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H, xyz,
+                         has, nullptr);
 }
 
 int slr_reconstruct_mf(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
@@ -754,6 +779,11 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_MF_MATCH_ALGO:
             if (value < 0 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0, 1 or 2");
             c->opt_mf_match_algo = value;
+            return SLR_OK;
+        case SLR_OPT_MF_DECODE_VEC:
+            if (value != 0 && value != 4 && value != 8 && value != 16)
+                return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_DECODE_VEC must be 0, 4, 8 or 16");
+            c->opt_mf_decode_vec = value;
             return SLR_OK;
         default:
             return fail(c, SLR_ERR_INVALID_ARG, "unknown option");

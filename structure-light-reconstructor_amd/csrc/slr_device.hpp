@@ -35,7 +35,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_KEYS, K_RAY_SORT, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_KEYS, K_RAY_SORT, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_COUNT
 };
 
 // ---- launchers (defined in the .hip files; all asynchronous on `s`) -----------------------------------
@@ -45,7 +45,7 @@ hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr,
                             const float *atan_lut, float *phase, uint8_t *valid,
                             const int16_t *map_xy, const uint16_t *map_frac /* null -> no rectify */,
-                            hipStream_t s);
+                            int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */, hipStream_t s);
 
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
@@ -54,7 +54,11 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
 
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
-                           float *xyz, uint8_t *has, int32_t *match_k, int algo, hipStream_t s);
+                           float *xyz, uint8_t *has, int32_t *match_k, int algo,
+                           const float *undL_xy /* [H][W][2] or null */, const float *undRx /* [H][W] or null */,
+                           hipStream_t s);
+// per-pixel Utilities::undistortPoints tables for a (calibration, W, H): left (x,y), right x
+hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *undL_xy, float *undRx, hipStream_t s);
 
 hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
