@@ -1,0 +1,269 @@
+"""The C++ host mirror (structure-light-reconstructor_amd/host: VirtualCamera, stereoRect, PointCloudImage, GrayCodes,
+MultiFrequency, Reconstruct, MFReconstruct, MeshCreator) driven through libslr_host.so's extern "C" hooks.
+CPU half: encoders, matrix text I/O (6-digit precision loss, Q14), PNG/PGM I/O, map builder, PointCloudImage semantics,
+stereoRectify sanity.  GPU half: a synthetic project directory in the reference's layout through all three modes."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (HIP runtime first)
+
+from util import bits_equal
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_host.so")
+
+
+@pytest.fixture(scope="module")
+def host(slr):
+    slr.capi.load_library()
+    assert os.path.exists(LIB), "build it: make -C structure-light-reconstructor_amd/host"
+    return C.CDLL(LIB)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def test_encoders_match_oracle(host, oracle):
+    for (w, h, epi) in ((64, 24, True), (100, 37, False), (1280, 4, True)):
+        exp = oracle.gen_graycodes(w, h, epi)
+        assert host.duke_gray_num_imgs(w, h, int(epi)) == exp.shape[0]
+        out = np.zeros_like(exp)
+        assert host.duke_gen_graycodes(w, h, int(epi), _p(out)) == exp.shape[0]
+        assert np.array_equal(out, exp)
+    exp = oracle.gen_multifreq(1280, 3)
+    out = np.zeros_like(exp)
+    host.duke_gen_multifreq(1280, 3, _p(out))
+    assert np.array_equal(out, exp)
+    for bits in ([1, 0, 0], [1, 1, 0], [0, 1, 1, 1, 0, 1]):
+        b = np.array(bits, np.uint8)
+        assert host.duke_gray_to_dec(_p(b), len(bits)) == oracle.gray_to_dec(bits)
+
+
+def test_matrix_text_io_keeps_the_float_round_trip(host, tmp_path):
+    m = np.array([[1234.56789012, 0.000123456789, 321.987654321], [0, 987.654321987, 255.5], [0, 0, 1]], np.float64)
+    path = str(tmp_path / "cam_matrix.txt").encode()
+    assert host.duke_export_mat(path, _p(m), 3, 3) == 1
+    text = open(path).read()
+    assert "1234.57\t" in text and "0.000123457\t" in text            # default ostream precision: 6 significant digits
+    out = np.zeros((3, 3), np.float32)
+    assert host.duke_load_matrix(path, 3, 3, _p(out)) == 1
+    assert out[0, 0] == np.float32(1234.57) and out[1, 1] == np.float32(987.654)
+    assert host.duke_load_matrix(str(tmp_path / "missing.txt").encode(), 3, 3, _p(out)) == -1
+
+
+def _png_bytes(img, filt):
+    """minimal PNG writer with a chosen filter type per row (exercises the decoder's unfilter paths)"""
+    h, w = img.shape
+    raw = bytearray()
+    prev = np.zeros(w, np.int32)
+    for y in range(h):
+        cur = img[y].astype(np.int32)
+        f = filt[y % len(filt)]
+        left = np.concatenate([[0], cur[:-1]])
+        upleft = np.concatenate([[0], prev[:-1]])
+        if f == 0: enc = cur
+        elif f == 1: enc = cur - left
+        elif f == 2: enc = cur - prev
+        elif f == 3: enc = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            enc = cur - pred
+        raw.append(f)
+        raw.extend((enc & 255).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+def test_png_and_pgm_io(host, tmp_path):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(37, 53), dtype=np.uint8)
+    for png in (0, 1):
+        path = str(tmp_path / ("a.png" if png else "a.pgm")).encode()
+        assert host.duke_imwrite(path, _p(img), 53, 37, png) == 1
+        out = np.zeros_like(img)
+        w, h = C.c_int(0), C.c_int(0)
+        assert host.duke_imread(path, _p(out), out.size, C.byref(w), C.byref(h)) == 1
+        assert (w.value, h.value) == (53, 37) and np.array_equal(out, img)
+    path = str(tmp_path / "filters.png")
+    open(path, "wb").write(_png_bytes(img, [0, 1, 2, 3, 4]))
+    out = np.zeros_like(img)
+    w, h = C.c_int(0), C.c_int(0)
+    assert host.duke_imread(path.encode(), _p(out), out.size, C.byref(w), C.byref(h)) == 1
+    assert np.array_equal(out, img)
+    assert host.duke_imread(str(tmp_path / "nope.png").encode(), _p(out), out.size, C.byref(w), C.byref(h)) == 0
+
+
+def test_map_builder_matches_oracle(host, oracle):
+    W, H = 96, 64
+    M = np.array([[110.0, 0, 47.3], [0, 112.0, 31.8], [0, 0, 1]])
+    D = np.array([-0.12, 0.03, 1e-3, -7e-4, 0.01])
+    th = 0.02
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    P = np.array([[105.0, 0, 48.0, 0], [0, 105.0, 32.0, 0], [0, 0, 1, 0]])
+    exy, efr = oracle.init_undistort_rectify_map(M, D, R, P, W, H)
+    xy = np.zeros((H, W, 2), np.int16)
+    fr = np.zeros((H, W), np.uint16)
+    host.duke_init_undistort_rectify_map(_p(M.reshape(-1)), _p(D), _p(R.reshape(-1)), _p(P.reshape(-1)), W, H, _p(xy), _p(fr))
+    assert np.array_equal(xy, exy) and np.array_equal(fr, efr)
+    assert (fr < 1024).all() and abs(int(xy[H // 2, W // 2, 0]) - W // 2) < 4
+
+
+def test_pointcloudimage_semantics(host, oracle):
+    """first hit sets, later hits add and count+1 (u8 wrap), out-of-range dropped, getPoint = sum/count"""
+    w, h = 5, 4
+    pts = []
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        pts.append([rng.integers(0, 7), rng.integers(0, 6)] + list(rng.standard_normal(3)))
+    pts += [[2, 1, 1.5, -2.0, 0.25]] * 300                                 # wraps the u8 counter
+    pts = np.array(pts, np.float32)
+    s = np.zeros((h, w, 3), np.float32); c = np.zeros((h, w), np.uint8); m = np.zeros((h, w, 3), np.float32)
+    host.duke_pointcloud_accumulate(w, h, _p(pts), len(pts), _p(s), _p(c), _p(m))
+    es = np.zeros((h, w, 3), np.float32); ec = np.zeros((h, w), np.uint8)
+    for i_w, j_h, x, y, z in pts:
+        i_w, j_h = int(i_w), int(j_h)
+        if i_w >= w or j_h >= h:
+            continue
+        p = np.array([x, y, z], np.float32)
+        if ec[j_h, i_w] == 0:
+            es[j_h, i_w] = p; ec[j_h, i_w] = 1
+        else:
+            es[j_h, i_w] = p + es[j_h, i_w]; ec[j_h, i_w] = np.uint8((int(ec[j_h, i_w]) + 1) & 255)
+    assert np.array_equal(c, ec) and bits_equal(s, es)
+    assert bits_equal(m, oracle.pointcloud_get(es, ec))
+
+
+def _write_project(host, tmp_path, synth, W, H, calib, st_by_mode, sn=0):
+    proj = str(tmp_path)
+    for d in ("calib/left", "calib/right", "scan/left/%d" % sn, "scan/right/%d" % sn, "reconstruction"):
+        os.makedirs(os.path.join(proj, d), exist_ok=True)
+
+    def put(rel, arr):
+        a = np.ascontiguousarray(np.asarray(arr, np.float64))
+        a2 = a.reshape(a.shape[0], -1)
+        assert host.duke_export_mat(os.path.join(proj, rel).encode(), _p(a2), a2.shape[0], a2.shape[1]) == 1
+    for side, cam in (("left", calib.cam[0]), ("right", calib.cam[1])):
+        K = np.array([[cam.fc[0], 0, cam.cc[0]], [0, cam.fc[1], cam.cc[1]], [0, 0, 1]])
+        put("calib/%s/cam_matrix.txt" % side, K)
+        put("calib/%s/cam_distortion.txt" % side, np.array(list(cam.k)).reshape(5, 1))
+        put("calib/%s/cam_rotation_matrix.txt" % side, np.array(list(cam.R)).reshape(3, 3))
+        put("calib/%s/cam_trans_vectror.txt" % side, np.array(list(cam.t)).reshape(3, 1))
+        put("calib/%s/cam_stereo.txt" % side, K)
+        put("calib/%s/distortion_stereo.txt" % side, np.array(list(cam.k)).reshape(5, 1))
+    th = 0.01
+    put("calib/R_stereo.txt", np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]]))
+    put("calib/T_stereo.txt", np.array([[-120.0], [0.8], [-1.5]]))
+    put("calib/fundamental_stereo.txt", np.eye(3))
+    put("calib/H1_mat.txt", np.eye(3)); put("calib/H2_mat.txt", np.eye(3))
+    for cam, side, pre in ((0, "left", "L"), (1, "right", "R")):
+        st = st_by_mode[cam]
+        for i in range(st.shape[0]):
+            path = os.path.join(proj, "scan/%s/%d/%s%d.png" % (side, sn, pre, i)).encode()
+            assert host.duke_imwrite(path, _p(np.ascontiguousarray(st[i])), W, H, 1) == 1
+    return proj
+
+
+def _float_text(path, shape):
+    return np.array(open(path).read().split(), np.float32).reshape(shape)
+
+
+def _oracle_calib_from_project(O, proj):
+    cams = []
+    for side in ("left", "right"):
+        K = _float_text(os.path.join(proj, "calib/%s/cam_matrix.txt" % side), (3, 3))
+        cams.append(O.Camera.make((K[0, 0], K[1, 1]), (K[0, 2], K[1, 2]),
+                                  _float_text(os.path.join(proj, "calib/%s/cam_distortion.txt" % side), (5,)),
+                                  _float_text(os.path.join(proj, "calib/%s/cam_rotation_matrix.txt" % side), (3, 3)),
+                                  _float_text(os.path.join(proj, "calib/%s/cam_trans_vectror.txt" % side), (3,))))
+    return cams
+
+
+def test_stereo_rectify_sanity(host, synth, tmp_path):
+    W, H = 128, 96
+    calib, _ = synth.make_calibration(W, H)
+    proj = _write_project(host, tmp_path, synth, W, H, calib, [np.zeros((0, H, W), np.uint8)] * 2)
+    R1, R2, P1, P2, Q = np.zeros(9), np.zeros(9), np.zeros(12), np.zeros(12), np.zeros(16)
+    assert host.duke_stereo_rect(proj.encode(), W, H, _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), None, None, None, None) == 1
+    R1, R2, P1, P2, Q = R1.reshape(3, 3), R2.reshape(3, 3), P1.reshape(3, 4), P2.reshape(3, 4), Q.reshape(4, 4)
+    for R in (R1, R2):
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(R) - 1) < 1e-9
+    T = _float_text(os.path.join(proj, "calib/T_stereo.txt"), (3,)).astype(np.float64)
+    t = R2 @ T
+    assert abs(t[1]) < 1e-6 * abs(t[0]) and abs(t[2]) < 1e-6 * abs(t[0])          # baseline on the new x axis
+    f = P1[0, 0]
+    assert P1[1, 1] == f and P2[0, 0] == f and np.isclose(P2[0, 3], t[0] * f) and P1[1, 2] == P2[1, 2]
+    assert np.allclose(Q, [[1, 0, 0, -P1[0, 2]], [0, 1, 0, -P1[1, 2]], [0, 0, 0, f], [0, 0, -1 / t[0], (P1[0, 2] - P2[0, 2]) / t[0]]])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 1, 0])
+def test_project_directory_through_the_host_mirror(host, oracle, synth, tmp_path, mode):
+    """mode 2 = MFReconstruct::runReconstruction, 1 = Reconstruct::runReconstruction_GE, 0 = runReconstruction"""
+    W, H, scan_w, scan_h, BLACK, WHITE = 160, 96, 120, 150, 40, 3
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    if mode == 2:
+        st = synth.render_mf_stack(W, H, seed=5).numpy()
+    else:
+        st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=5, noise=2, rows=(mode == 0)).numpy()
+    proj = _write_project(host, tmp_path, synth, W, H, calib, st, sn=0)
+    pc_sum = np.zeros((scan_h, scan_w, 3), np.float32)
+    pc_cnt = np.zeros((scan_h, scan_w), np.uint8)
+    pc_col = np.zeros((scan_h, scan_w, 3), np.uint8)
+    err = C.create_string_buffer(512)
+    ply = os.path.join(proj, "reconstruction", "0.ply")
+    ok = host.duke_run_project(proj.encode(), mode, 0, scan_w, scan_h, W, H, BLACK, WHITE, 1 if mode == 1 else 0, b".png",
+                               ply.encode(), _p(pc_sum), _p(pc_cnt), _p(pc_col), err, 512)
+    assert ok == 1, err.value
+    camL, camR = _oracle_calib_from_project(oracle, proj)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    if mode == 0:
+        dec = [oracle.gray_decode(st[c], ncol, nrow, BLACK, WHITE, scan_w, scan_h) for c in range(2)]
+        offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+        offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+        es, ec = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, None)
+    else:
+        R1, R2, P1, P2, Q = np.zeros(9), np.zeros(9), np.zeros(12), np.zeros(12), np.zeros(16)
+        m11 = np.zeros((H, W, 2), np.int16); m12 = np.zeros((H, W), np.uint16)
+        m21 = np.zeros((H, W, 2), np.int16); m22 = np.zeros((H, W), np.uint16)
+        assert host.duke_stereo_rect(proj.encode(), W, H, _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), _p(m11), _p(m12), _p(m21), _p(m22)) == 1
+        maps = [(m11, m12), (m21, m22)]
+        rect = [np.stack([oracle.remap_u8(st[c][p], maps[c][0], maps[c][1]) for p in range(st[c].shape[0])]) for c in range(2)]
+        if mode == 2:
+            dec = [oracle.mf_decode(rect[c], BLACK) for c in range(2)]
+            xyz, has, _ = oracle.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q.reshape(4, 4), None)
+            col = None
+        else:
+            dec = [oracle.gray_decode(rect[c], ncol, 0, BLACK, WHITE, scan_w, 0) for c in range(2)]
+            xyz, has, col, _ = oracle.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], Q.reshape(4, 4), None,
+                                                     rect[0][0], rect[1][0])
+        es, ec, ecol = oracle.pointcloud_from_grid(xyz, has, scan_w, scan_h, col)
+        if mode == 1:
+            assert np.array_equal(pc_col[..., 0], ecol) and np.array_equal(pc_col[..., 2], ecol)
+    assert np.array_equal(pc_cnt, ec) and bits_equal(pc_sum, es)
+    assert ec.sum() > 50
+    # PLY written by MeshCreator::exportPlyMesh: header vertex count == number of cells with a point
+    head = open(ply).read(400).split("\n")
+    assert head[0] == "ply" and head[2] == "element vertex %d" % int((ec > 0).sum())
+
+
+@pytest.mark.gpu
+def test_missing_images_fail_like_the_reference(host, synth, tmp_path):
+    W, H = 64, 48
+    calib, _ = synth.make_calibration(W, H)
+    proj = _write_project(host, tmp_path, synth, W, H, calib, [np.zeros((3, H, W), np.uint8)] * 2)   # only 3 of 14 images
+    err = C.create_string_buffer(512)
+    ok = host.duke_run_project(proj.encode(), 2, 0, 64, 64, W, H, 40, 0, 0, b".png", None, None, None, None, err, 512)
+    assert ok == 0 and b"not found" in err.value
+    ok = host.duke_run_project(str(tmp_path / "nowhere").encode(), 2, 0, 64, 64, W, H, 40, 0, 0, b".png", None, None, None, None, err, 512)
+    assert ok == 0 and b"Calibration" in err.value
