@@ -222,7 +222,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
-        rows = args.cpu_rows or max(8, min(H, int(600 * (4096.0 / W) ** 2)))
+        rows = args.cpu_rows or H          # whole frame: ~8 s of single-thread CPU work at 4096x3000
         maps_cpu = None if maps is None else [(m[0].cpu().numpy(), m[1].cpu().numpy()) for m in maps]
         cpu = cpu_baseline(synth, W, H, stack[0].cpu().numpy(), maps_cpu, calib, rows)
 

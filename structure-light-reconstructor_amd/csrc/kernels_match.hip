@@ -146,51 +146,108 @@ __device__ __forceinline__ float key_to_float(unsigned k)
     return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
+constexpr int kBins = 4096;                              // 0.25-wide bins over [-512, 512), clamped outside
+__device__ __forceinline__ int phase_bin(float p)
+{
+    const float t = fminf(fmaxf((p + 512.0f) * 4.0f, 0.0f), (float)(kBins - 1));
+    return (int)t;                                       // t >= 0: truncation == floor
+}
+
+// row I/O helpers: thread t owns the IPT consecutive pixels [t*IPT, (t+1)*IPT) ("blocked" arrangement), so a
+// row is read and written with a few wide, mutually independent vector accesses per thread
 template <int IPT>
-__global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+__device__ __forceinline__ void load_f32_blocked(const float *__restrict__ p, int k0, int W, bool vec, float out[IPT])
+{
+    if (vec && IPT >= 4 && k0 + IPT <= W) {
+#pragma unroll
+        for (int i = 0; i < IPT; i += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + k0 + i);
+            out[i] = v.x; out[i + 1] = v.y; out[i + 2] = v.z; out[i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) out[i] = (k0 + i < W) ? p[k0 + i] : 0.0f;
+    }
+}
+template <int IPT>
+__device__ __forceinline__ void load_u8_blocked(const uint8_t *__restrict__ p, int k0, int W, bool vec, unsigned out[IPT])
+{
+    if (vec && IPT >= 4 && k0 + IPT <= W) {
+#pragma unroll
+        for (int i = 0; i < IPT; i += 4) {
+            const unsigned v = *reinterpret_cast<const unsigned *>(p + k0 + i);
+            out[i] = v & 0xFFu; out[i + 1] = (v >> 8) & 0xFFu; out[i + 2] = (v >> 16) & 0xFFu; out[i + 3] = v >> 24;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) out[i] = (k0 + i < W) ? p[k0 + i] : 0u;
+    }
+}
+
+template <int BLOCK, int IPT>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
-                                                              int W, int H, DevCalib cal,
+                                                              int W, int H, DevCalib cal, int vec_ok,
                                                               const float2 *__restrict__ undL, const float *__restrict__ undRx,
                                                               float *__restrict__ xyz,
                                                               uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
 {
-    constexpr int N = 256 * IPT;
-    typedef hipcub::BlockRadixSort<unsigned, 256, IPT, unsigned short> Sort;
-    typedef hipcub::BlockScan<int, 256> Scan;
+    constexpr int N = BLOCK * IPT;
+    typedef hipcub::BlockRadixSort<unsigned, BLOCK, IPT> Sort;     // keys only: (group << 16) | k
+    typedef hipcub::BlockScan<int, BLOCK> Scan;
+    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
     __shared__ union {
         typename Sort::TempStorage sort;
         struct { float phi[N]; unsigned short k[N]; } d;
     } sh;
+    __shared__ float phR[N];                             // right-row phases, gathered by column after the sort
     __shared__ typename Scan::TempStorage scan_tmp;
-    __shared__ unsigned last_key[256];
+    __shared__ unsigned last_key[BLOCK];
     __shared__ int n_distinct;
+    __shared__ unsigned short binfirst[kBins + 1];
+    __shared__ unsigned chunk_min[BLOCK];
+    __shared__ typename ScanU::TempStorage scanu_tmp;
 
     const int row = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)row * W;
+    const int k0 = tid * IPT;
+    const bool vec = vec_ok != 0;
 
+    // all row loads of this thread are issued here, before the sort, and are independent of each other
+    float pr[IPT], pl[IPT];
+    unsigned vr[IPT], vl[IPT];
+    load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
+    load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+    load_f32_blocked<IPT>(phaseL + base, k0, W, vec, pl);
+    load_u8_blocked<IPT>(validL + base, k0, W, vec, vl);
+
+    // Sort key: any function of phi works for correctness (equal phases share a key, and the stable order keeps
+    // ascending k inside a key).  16 bits = 12-bit bin + 4-bit hash of the value: two 8-bit radix passes instead
+    // of four, and the result is already grouped by bin for the candidate index below.  Distinct values that
+    // collide on a key merely produce a few extra run heads.
     unsigned keys[IPT];
-    unsigned short vals[IPT];
 #pragma unroll
-    for (int i = 0; i < IPT; i++) {
-        const int k = tid * IPT + i;                     // blocked arrangement: stable order == ascending k
-        unsigned key = 0xFFFFFFFFu;
-        if (k < W && validR[base + k]) {
-            const float p = phaseR[base + k];
-            if (p == p) key = sortable_key(p);           // NaN can never satisfy the predicate
-        }
-        keys[i] = key;
-        vals[i] = (unsigned short)k;
+    for (int i = 0; i < IPT; i++) {                      // blocked arrangement: stable order == ascending k
+        const bool ok = (k0 + i < W) && vr[i] && (pr[i] == pr[i]);   // NaN can never satisfy the predicate
+        const unsigned b = __float_as_uint(pr[i]);
+        const unsigned h4 = (b ^ (b >> 4) ^ (b >> 8) ^ (b >> 12) ^ (b >> 16) ^ (b >> 20)) & 0xFu;
+        keys[i] = ok ? ((((unsigned)phase_bin(pr[i]) << 4) | h4) << 16) | (unsigned)(k0 + i) : 0xFFFFFFFFu;
+        phR[k0 + i] = pr[i];
     }
-    Sort(sh.sort).Sort(keys, vals);
-    last_key[tid] = keys[IPT - 1];
-    __syncthreads();                                     // also: everybody is done with sh.sort
+    Sort(sh.sort).Sort(keys, 16, 32);
+    __syncthreads();                                     // phR visible; everybody is done with sh.sort
+    unsigned phb[IPT];                                   // phase bits of the sorted items (0xFFFFFFFF = none)
+#pragma unroll
+    for (int i = 0; i < IPT; i++) phb[i] = keys[i] != 0xFFFFFFFFu ? __float_as_uint(phR[keys[i] & 0xFFFFu]) : 0xFFFFFFFFu;
+    last_key[tid] = phb[IPT - 1];
+    __syncthreads();
     unsigned prev = tid ? last_key[tid - 1] : 0xFFFFFFFFu;
     int heads = 0;
     unsigned headmask = 0;
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
-        const bool h = keys[i] != 0xFFFFFFFFu && (keys[i] != prev || (tid == 0 && i == 0));
-        prev = keys[i];
+        const bool h = phb[i] != 0xFFFFFFFFu && phb[i] != prev;      // run head: value differs from its predecessor
+        prev = phb[i];
         headmask |= h ? (1u << i) : 0u;
         heads += h ? 1 : 0;
     }
@@ -198,51 +255,120 @@ __global__ __launch_bounds__(256) void mf_match_sorted_kernel(const float *__res
     Scan(scan_tmp).ExclusiveSum(heads, pos, total);
 #pragma unroll
     for (int i = 0; i < IPT; i++)
-        if (headmask & (1u << i)) { sh.d.phi[pos] = key_to_float(keys[i]); sh.d.k[pos] = vals[i]; pos++; }
+        if (headmask & (1u << i)) { sh.d.phi[pos] = __uint_as_float(phb[i]); sh.d.k[pos] = (unsigned short)(keys[i] & 0xFFFFu); pos++; }
     if (tid == 0) n_distinct = total;
+    for (int b = tid; b <= kBins; b += BLOCK) binfirst[b] = 0xFFFFu;
     __syncthreads();
     const int nd = n_distinct;
 
-    for (int j0 = 0; j0 < W; j0 += 256) {
-        const int j = j0 + tid;
-        if (j >= W) break;
-        int best = -1;
-        if (validL[base + j]) {
-            const float pl = phaseL[base + j];
-            const double lo_v = (double)pl - 0.1001, hi_v = (double)pl + 0.1001;
-            int lo = 0, hi = nd;                         // first index with D_phi >= lo_v (false for NaN pl)
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if ((double)sh.d.phi[mid] < lo_v) lo = mid + 1; else hi = mid;
-            }
-            unsigned bk = 0xFFFFFFFFu;
-            for (int idx = lo; idx < nd; idx++) {
-                const float pr = sh.d.phi[idx];
-                if (!((double)pr <= hi_v)) break;
-                if (fabsf(pl - pr) < 0.1f) { const unsigned kk = sh.d.k[idx]; bk = kk < bk ? kk : bk; }
-            }
-            best = bk == 0xFFFFFFFFu ? -1 : (int)bk;
+    // Bin index over the distinct values: bin(phi) = clamp(floor((phi + 512) * 4)) is monotone and two values
+    // closer than 0.1001 land at most one bin apart, so bins [b-1, b+1] of phiL hold a superset of its
+    // candidates.  binfirst[b] = first distinct index whose bin is >= b (suffix-min fill), binfirst[kBins] = nd.
+    for (int i = tid; i < nd; i += BLOCK) {
+        const int b = phase_bin(sh.d.phi[i]);
+        if (i == 0 || phase_bin(sh.d.phi[i - 1]) != b) binfirst[b] = (unsigned short)i;
+    }
+    __syncthreads();
+    {
+        constexpr int kPer = kBins / BLOCK;              // bins per thread (kBins is a multiple of BLOCK)
+        unsigned m = 0xFFFFu;
+#pragma unroll
+        for (int q = kPer - 1; q >= 0; q--) { const unsigned v = binfirst[tid * kPer + q]; m = v < m ? v : m; }
+        chunk_min[tid] = m;                              // min over this thread's bins
+        __syncthreads();
+        // exclusive suffix-min over threads = exclusive prefix-min in reversed thread order
+        unsigned carry;
+        ScanU(scanu_tmp).ExclusiveScan(chunk_min[BLOCK - 1 - tid], carry, 0xFFFFu, hipcub::Min());
+        __syncthreads();
+        chunk_min[BLOCK - 1 - tid] = carry;
+        __syncthreads();
+        carry = chunk_min[tid];
+        carry = carry < (unsigned)nd ? carry : (unsigned)nd;     // nothing later -> end sentinel
+#pragma unroll
+        for (int q = kPer - 1; q >= 0; q--) {
+            const unsigned v = binfirst[tid * kPer + q];
+            carry = v < carry ? v : carry;
+            binfirst[tid * kPer + q] = (unsigned short)carry;
         }
-        float X[3] = {0.0f, 0.0f, 0.0f};
-        if (best >= 0) {
-            float ulx, uly, urx, ury;
-            if (undL) {                                  // per-pixel values precomputed by undistort_table_kernel
-                const float2 u = undL[base + j];
-                ulx = u.x; uly = u.y;
-                urx = undRx[base + best];
-            } else {
-                undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);
-                undistort_point((float)best, (float)row, cal.cam[1], urx, ury);
-            }
-            reproject(cal.Q, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);
-            if (cal.has_T) apply_T(cal.T, X);
+        if (tid == 0) binfirst[kBins] = (unsigned short)nd;
+    }
+    __syncthreads();
+
+    // queries: exact reference predicate over the <= 3-bin candidate window, smallest column wins
+    int best[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        unsigned bk = 0xFFFFFFFFu;
+        if (k0 + i < W && vl[i] && pl[i] == pl[i]) {
+            const int b = phase_bin(pl[i]);
+            const int i0 = binfirst[b > 0 ? b - 1 : 0], i1 = binfirst[b + 2 < kBins ? b + 2 : kBins];
+            for (int idx = i0; idx < i1; idx++)
+                if (fabsf(pl[i] - sh.d.phi[idx]) < 0.1f) { const unsigned kk = sh.d.k[idx]; bk = kk < bk ? kk : bk; }
         }
-        float *o = xyz + 3 * (base + j);
-        o[0] = X[0]; o[1] = X[1]; o[2] = X[2];
-        has[base + j] = best >= 0 ? 1 : 0;
-        if (match_k) match_k[base + j] = best;
+        best[i] = bk == 0xFFFFFFFFu ? -1 : (int)bk;
+    }
+
+    // triangulate: gather the table values for all IPT pixels first (independent loads), then the f64 math
+    float ulx[IPT], uly[IPT], urx[IPT];
+    if (undL) {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            ulx[i] = uly[i] = urx[i] = 0.0f;
+            if (best[i] >= 0) {
+                const float2 u = undL[base + k0 + i];
+                ulx[i] = u.x; uly[i] = u.y;
+                urx[i] = undRx[base + best[i]];
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < IPT; i++) {
+            ulx[i] = uly[i] = urx[i] = 0.0f;
+            if (best[i] >= 0) {
+                float ury;
+                undistort_point((float)(k0 + i), (float)row, cal.cam[0], ulx[i], uly[i]);
+                undistort_point((float)best[i], (float)row, cal.cam[1], urx[i], ury);
+            }
+        }
+    }
+    const bool full = vec && IPT >= 4 && k0 + IPT <= W;
+#pragma unroll
+    for (int i0 = 0; i0 < IPT; i0 += 4) {
+        float out[12];
+        unsigned hw = 0;
+        int mk[4];
+#pragma unroll
+        for (int q = 0; q < 4 && i0 + q < IPT; q++) {
+            const int i = i0 + q;
+            float X[3] = {0.0f, 0.0f, 0.0f};
+            if (best[i] >= 0) {
+                reproject(cal.Q, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
+                if (cal.has_T) apply_T(cal.T, X);
+            }
+            out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
+            hw |= (best[i] >= 0 ? 1u : 0u) << (8 * q);
+            mk[q] = best[i];
+        }
+        const size_t o = base + k0 + i0;
+        if (full) {
+            float4 *dst = reinterpret_cast<float4 *>(xyz + 3 * o);
+            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+            *reinterpret_cast<unsigned *>(has + o) = hw;
+            if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(mk[0], mk[1], mk[2], mk[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4 && i0 + q < IPT; q++) {
+                if (k0 + i0 + q >= W) break;
+                xyz[3 * (o + q)] = out[3 * q]; xyz[3 * (o + q) + 1] = out[3 * q + 1]; xyz[3 * (o + q) + 2] = out[3 * q + 2];
+                has[o + q] = (uint8_t)((hw >> (8 * q)) & 1u);
+                if (match_k) match_k[o + q] = mk[q];
+            }
+        }
     }
 }
+
 
 // Utilities::undistortPoints depends only on the pixel position and the camera, so its 5 f64 fixed-point
 // iterations (utilities.cpp:83-91) are evaluated once per (calibration, image size) into tables -- bit-identical
@@ -276,15 +402,19 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 {
     const float2 *undL = (const float2 *)undL_xy;
     if (algo != 1 && W <= 256 * 32) {
-#define SLR_SORTED(IPT)                                                                                          \
-    hipLaunchKernelGGL(mf_match_sorted_kernel<IPT>, dim3(H), dim3(256), 0, s, phaseL, validL, phaseR, validR, W, \
-                       H, cal, undL, undRx, xyz, has, match_k)
-        if (W <= 256) SLR_SORTED(1);
-        else if (W <= 512) SLR_SORTED(2);
-        else if (W <= 1024) SLR_SORTED(4);
-        else if (W <= 2048) SLR_SORTED(8);
-        else if (W <= 4096) SLR_SORTED(16);
-        else SLR_SORTED(32);
+        const int vec_ok = (W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
+                           ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
+                           ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0);
+#define SLR_SORTED(BLOCK, IPT)                                                                                     \
+    hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
+                       W, H, cal, vec_ok, undL, undRx, xyz, has, match_k)
+        // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
+        if (W <= 256) SLR_SORTED(256, 1);
+        else if (W <= 512) SLR_SORTED(256, 2);
+        else if (W <= 1024) SLR_SORTED(256, 4);
+        else if (W <= 2048) SLR_SORTED(1024, 2);
+        else if (W <= 4096) SLR_SORTED(1024, 4);
+        else SLR_SORTED(1024, 8);
 #undef SLR_SORTED
         return hipGetLastError();
     }
