@@ -49,7 +49,10 @@ for vec in (16, 8, 4):
     ctx.set_option(cap.OPT_MF_DECODE_VEC, vec)
     run("mf_decode vec=%d" % vec, lambda: ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0]), 19.0)
 ctx.set_option(cap.OPT_MF_DECODE_VEC, 0)
-run("mf_rectify_decode", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+run("mf_rectify_decode lds", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 1)
+run("mf_rectify_decode gather", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 0)
 ctx.mf_decode(st[1], 40, rectify_cam=1, phase=ph[1], valid=vd[1])
 tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
 run("remap", lambda: ctx.remap_u8(0, st[0, 3], out=tmp), 8.0)

@@ -370,6 +370,194 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fused K1+K2, LDS-tiled form (the default): one workgroup rectifies + decodes a 64 x 16 destination tile.
+//   1. every thread loads the map entries of its 4 pixels; a wave-shuffle + LDS reduction gives the tile's source
+//      bounding box (a smooth map turns a 64x16 tile into roughly 70x19 source pixels);
+//   2. the box of all 14 planes is copied HBM -> LDS once, with coalesced dword loads (14 independent loads in
+//      flight per thread); everything outside the image is stored as 0, which IS cv::remap's BORDER_CONSTANT, so
+//      the border cases need no special code at all;
+//   3. the 2x2 taps come from LDS (two dwords per source row, v_alignbyte to the tap pair, v_dot4_u32_u8 blend),
+//      then the same per-pixel decode as K2.
+// Square-ish tiles keep the halo small under rotation; an XCD-banded tile order keeps vertically adjacent tiles
+// (which share source rows) on one L2.  A box that does not fit the LDS budget (wild maps) falls back, per
+// workgroup, to the direct gather of the generic kernel.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 16;
+
+struct TileBox { int x0, y0, LP, BH, PS; bool any, fits; };
+
+// block-wide bounding box of the footprints (taps that are completely outside the image are ignored)
+template <int V>
+__device__ __forceinline__ TileBox tile_box(const Tap (&taps)[V], bool active, int nplanes, int budget, int (*red)[4])
+{
+    int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < V; i++)
+            if (taps[i].kind != 1) {
+                mnx = taps[i].sx < mnx ? taps[i].sx : mnx; mxx = taps[i].sx > mxx ? taps[i].sx : mxx;
+                mny = taps[i].sy < mny ? taps[i].sy : mny; mxy = taps[i].sy > mxy ? taps[i].sy : mxy;
+            }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        int t;
+        t = __shfl_xor(mnx, d); mnx = t < mnx ? t : mnx;
+        t = __shfl_xor(mxx, d); mxx = t > mxx ? t : mxx;
+        t = __shfl_xor(mny, d); mny = t < mny ? t : mny;
+        t = __shfl_xor(mxy, d); mxy = t > mxy ? t : mxy;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
+        mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+    }
+    TileBox b;
+    b.any = mnx <= mxx;
+    b.x0 = mnx & ~3;                                        // dword-aligned origin (also for negative x)
+    b.y0 = mny;
+    b.LP = b.any ? (((mxx + 1) - b.x0 + 1) + 3) & ~3 : 4;  // columns x0 .. mxx+1, rounded up to dwords
+    b.BH = b.any ? (mxy + 1) - mny + 1 : 1;                 // rows    y0 .. mxy+1
+    b.PS = b.LP * b.BH;
+    b.fits = b.any && (long long)b.PS * nplanes <= budget && b.LP <= 1024 && b.BH <= 1024;
+    return b;
+}
+
+// one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
+__device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ plane, int pitch, int W, int H, int gx,
+                                                   int gy, bool aligned)
+{
+    if ((unsigned)gy >= (unsigned)H) return 0u;
+    const uint8_t *q = plane + (size_t)gy * pitch + gx;
+    if (gx >= 0 && gx + 3 < W) {
+        if (aligned) return *reinterpret_cast<const unsigned *>(q);
+        return (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
+    }
+    unsigned v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if ((unsigned)(gx + b) < (unsigned)W) v |= (unsigned)q[b] << (8 * b);
+    return v;
+}
+
+// blended sample of one plane for one pixel out of the LDS tile
+__device__ __forceinline__ unsigned tile_sample(const uint8_t *tile_plane, int LP, int base, unsigned wxp, unsigned wy0,
+                                                unsigned wy1)
+{
+    const int a = base & ~3;
+    const unsigned sh = (unsigned)(base & 3);
+    const unsigned *r0 = reinterpret_cast<const unsigned *>(tile_plane + a);
+    const unsigned *r1 = reinterpret_cast<const unsigned *>(tile_plane + a + LP);
+    const unsigned p0 = __builtin_amdgcn_alignbyte(r0[1], r0[0], sh);   // bytes base, base+1 in the low half
+    const unsigned p1 = __builtin_amdgcn_alignbyte(r1[1], r1[0], sh);
+    const unsigned h0 = __builtin_amdgcn_udot4(p0, wxp, 0u, false);    // wxp = wx0 | wx1<<8, upper bytes 0
+    const unsigned h1 = __builtin_amdgcn_udot4(p1, wxp, 0u, false);
+    return (h0 * wy0 + h1 * wy1 + 512u) >> 10;
+}
+
+__global__ __launch_bounds__(256, 4) void mf_rect_decode_lds_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+                                                                 const float *__restrict__ lut_g,
+                                                                 const int16_t *__restrict__ map_xy,
+                                                                 const uint16_t *__restrict__ map_frac,
+                                                                 float *__restrict__ phase, uint8_t *__restrict__ valid,
+                                                                 int tiles_x, int tiles_y, int budget, int aligned)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    __shared__ float lut[512];
+    __shared__ int red[4][4];
+    load_lut(lut, lut_g);
+    // XCD band order (see mf_rect_decode_kernel): consecutive virtual ids walk tiles row-major inside a band
+    const unsigned nb = gridDim.x, per = nb / 8;
+    const unsigned vb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    const int ty = (int)(vb / (unsigned)tiles_x), tx = (int)(vb - (unsigned)ty * tiles_x);
+    if (ty >= tiles_y) return;                              // padding blocks (whole workgroup leaves together)
+    // lane -> pixel: a wave owns 64 consecutive pixels of one tile row; 4 passes of 4 rows cover the 64x16 tile.
+    // One pixel per lane per pass keeps the live state small (14 samples) and makes every store a coalesced run.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = tx * kTileW + lane;
+    Tap taps[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int row = ty * kTileH + 4 * q + wv;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
+            taps[q] = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
+        } else {
+            taps[q] = make_tap(0, 0, 0, pitch, W, H);
+            taps[q].kind = 1;
+        }
+    }
+    const TileBox box = tile_box<4>(taps, true, SLR_MF_PLANES, budget, red);
+
+    if (box.fits) {
+        // ---- HBM -> LDS: each dword of the box once per plane -------------------------------------------
+        const int BW4 = box.LP >> 2, E = box.BH * BW4;
+        const float inv = 1.0f / (float)BW4;
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const int rr = (int)(((float)e + 0.5f) * inv);  // e / BW4 (exact: e < 2^20, remainder margin 0.5/BW4)
+            const int cc = e - rr * BW4;
+            const int gx = box.x0 + 4 * cc, gy = box.y0 + rr;
+            unsigned v[SLR_MF_PLANES];
+            // the in/out-of-image decision is the same for all planes: decide once, then 14 independent loads
+            if (aligned && (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W) {
+                const size_t off = (size_t)gy * pitch + gx;
+#pragma unroll
+                for (int p = 0; p < SLR_MF_PLANES; p++) v[p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
+            } else {
+#pragma unroll 1
+                for (int p = 0; p < SLR_MF_PLANES; p++) v[p] = load_src_dword(pl.p[p], pitch, W, H, gx, gy, false);
+            }
+#pragma unroll
+            for (int p = 0; p < SLR_MF_PLANES; p++)
+                *reinterpret_cast<unsigned *>(tile + p * box.PS + rr * box.LP + 4 * cc) = v[p];
+        }
+        __syncthreads();
+    }
+    // ---- per pass: 14 blended samples (from LDS, or by direct gather when the box did not fit), decode, store ----
+#pragma unroll 1
+    for (int q = 0; q < 4; q++) {
+        const int row = ty * kTileH + 4 * q + wv;
+        // re-read this pass's map entry (L2/L1 hit: it was fetched for the bounding box a moment ago) instead of
+        // keeping four Tap records alive across the fill phase (they would be indexed dynamically -> scratch)
+        Tap t = make_tap(0, 0, 0, pitch, W, H);
+        t.kind = 1;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
+            t = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
+        }
+        int gpx[SLR_MF_PLANES];
+        if (box.fits) {
+            const bool out = t.kind == 1;                   // completely outside: zero weights -> every sample is 0
+            const int base = out ? 0 : (t.sy - box.y0) * box.LP + (t.sx - box.x0);
+            const unsigned wxp = out ? 0u : ((unsigned)t.wx0 | ((unsigned)t.wx1 << 8));
+#pragma unroll
+            for (int p = 0; p < SLR_MF_PLANES; p++)
+                gpx[p] = (int)tile_sample(tile + p * box.PS, box.LP, base, wxp, (unsigned)t.wy0, (unsigned)t.wy1);
+        } else {
+#pragma unroll 1
+            for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = box.any ? sample(pl.p[p], pitch, W, H, t) : 0;
+        }
+        int v;
+        const float ph = mf_pixel(gpx, black_thr, lut, v);
+        // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane
+        unsigned vw = (unsigned)v;
+        vw |= (unsigned)__shfl_down(v, 1) << 8;
+        vw |= (unsigned)__shfl_down(v, 2) << 16;
+        vw |= (unsigned)__shfl_down(v, 3) << 24;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            __builtin_nontemporal_store(ph, phase + m);
+            if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+        }
+    }
+}
+
 static unsigned pick_blocks(size_t groups)
 {
     // One workgroup per 256 work items (no persistent grid-stride): with a capped grid the last sweep leaves
@@ -381,8 +569,18 @@ static unsigned pick_blocks(size_t groups)
 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
-                            int vec_hint, hipStream_t s)
+                            int vec_hint, int rect_algo, hipStream_t s)
 {
+    if (map_xy && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0)) {
+        bool aligned = pitch % 4 == 0;
+        for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+        const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
+        const int budget = 24 * 1024;                        // 14 planes x ~72 x 23 source bytes; 6 workgroups per CU
+        hipLaunchKernelGGL(mf_rect_decode_lds_kernel, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl, pitch, W, H,
+                           black_thr, atan_lut, map_xy, map_frac, phase, valid, tiles_x, tiles_y, budget, aligned ? 1 : 0);
+        return hipGetLastError();
+    }
     if (map_xy) {
         const bool vec = (W % 4 == 0);
         if (vec) hipLaunchKernelGGL(mf_rect_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,

@@ -50,6 +50,7 @@ struct slr_ctx {
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
+    int opt_rect_algo = 0;         // SLR_OPT_RECT_DECODE_ALGO
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     void *scratch[S_COUNT] = {};
@@ -235,7 +236,7 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
     ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
-                                c->opt_mf_decode_vec, c->stream));
+                                c->opt_mf_decode_vec, c->opt_rect_algo, c->stream));
     return SLR_OK;
 }
 
@@ -784,6 +785,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
             if (value != 0 && value != 4 && value != 8 && value != 16)
                 return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_DECODE_VEC must be 0, 4, 8 or 16");
             c->opt_mf_decode_vec = value;
+            return SLR_OK;
+        case SLR_OPT_RECT_DECODE_ALGO:
+            if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0 or 1");
+            c->opt_rect_algo = value;
             return SLR_OK;
         default:
             return fail(c, SLR_ERR_INVALID_ARG, "unknown option");

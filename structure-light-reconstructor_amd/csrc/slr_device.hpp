@@ -45,7 +45,8 @@ hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr,
                             const float *atan_lut, float *phase, uint8_t *valid,
                             const int16_t *map_xy, const uint16_t *map_frac /* null -> no rectify */,
-                            int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */, hipStream_t s);
+                            int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */,
+                            int rect_algo /* fused form: 0 = LDS-tiled, 1 = direct gather */, hipStream_t s);
 
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,

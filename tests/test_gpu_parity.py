@@ -123,7 +123,7 @@ def test_remap_border_constant(ctx, oracle, synth, dx, dy, fx, fy):
 
 
 @pytest.mark.parametrize("W,H", [(640, 480), (101, 67), (64, 48)])
-def test_remap_and_fused_rectify_decode(ctx, oracle, synth, W, H):
+def test_remap_and_fused_rectify_decode(ctx, oracle, synth, slr, W, H):
     st = synth.render_mf_stack(W, H, seed=99)
     maps = [synth.make_rectify_maps(W, H, cam, strength=3.0) for cam in range(2)]
     for cam in range(2):
@@ -138,8 +138,38 @@ def test_remap_and_fused_rectify_decode(ctx, oracle, synth, W, H):
         ctx.synchronize()
         assert np.array_equal(np_of(gdev), rect[5])
         exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
-        ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)
-        assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph)
+        for algo in (0, 1):                                          # LDS-tiled form and direct-gather form
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+            ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)
+            assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+
+
+def test_fused_rectify_decode_wild_maps(ctx, oracle, synth, slr):
+    """maps whose tile bounding boxes do not fit the LDS budget (random scatter) or leave the image entirely must
+    take the per-workgroup fallback and still match the oracle"""
+    rng = np.random.default_rng(9)
+    W, H = 192, 80
+    st = synth.render_mf_stack(W, H, seed=4)
+    raw = st[0].numpy()
+    mxs = []
+    mx = np.stack([rng.integers(-20, W + 20, size=(H, W)), rng.integers(-20, H + 20, size=(H, W))], -1).astype(np.int16)
+    mxs.append(mx)                                                   # random scatter: huge boxes -> fallback
+    ys, xs = np.mgrid[0:H, 0:W]
+    mxs.append(np.stack([xs + 5000, ys], -1).astype(np.int16))       # everything outside
+    mxs.append(np.stack([(xs * 3) % W, (ys * 2) % H], -1).astype(np.int16))   # 3x/2x stretch: wide boxes
+    mxs.append(np.stack([W - 1 - xs, H - 1 - ys], -1).astype(np.int16))       # mirrored (sx decreasing)
+    for mx in mxs:
+        mf = rng.integers(0, 1024, size=(H, W)).astype(np.uint16)
+        ctx.set_rectify_maps(0, np.ascontiguousarray(mx), mf)
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+        exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
+        for algo in (0, 1):
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+            ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
+            assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+        assert np.array_equal(ctx.remap_u8(0, raw[3]), rect[3])
 
 
 # ---------------------------------------------------------------------------------------------------------
