@@ -19,7 +19,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-baseline 0 \
     > "$OUT/bench_stdout.log" 2>&1
 cp "$OUT"/bench/*kernel_stats.csv "$SUM/${TAG}_bench_kernel_stats.csv" 2>/dev/null
-tail -1 "$OUT/bench_stdout.log" > "$SUM/${TAG}_bench_line.json"
+grep '^{"metric"' "$OUT/bench_stdout.log" | tail -1 > "$SUM/${TAG}_bench_line.json"
 
 # 2. kernel trace + stats of the per-kernel driver
 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1

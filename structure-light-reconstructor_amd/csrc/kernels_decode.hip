@@ -24,25 +24,34 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // per-pixel math
 // ------------------------------------------------------------------------------------------------------
 
-// mfreconstruct.cpp:246-261.  n = G4-G2, d = G1-G3.  The branch chain collapses to: d==0 special cases,
-// otherwise a = atanf((float)(n / d)) [C integer division] and the quadrant offset; the n==0 cases of the
-// reference (:246-249) equal the general formula because atanf(0)==0 exactly.
-// Integer division without the ~30-instruction idiv: |n|,|d| <= 255, so floor(|n|/|d|) ==
-// (int)((|n|+0.5f) * rcp(|d|)) -- the true value stays >= 0.5/255 away from any integer, far more than the
-// 1-ulp error of v_rcp_f32 (verified exhaustively over all 511x511 pairs by tests/test_gpu_parity.py).
-__device__ __forceinline__ float wrapped_phase(int G1, int G2, int G3, int G4, const float *lut, int &ok)
+// mfreconstruct.cpp:246-261.  n = G4-G2, d = G1-G3.  These kernels turned out to be VALU-bound on MI355X (PMC: ~140
+// integer/f32 instructions per pixel at 16 lanes/clk, HBM traffic already at the algorithmic minimum), so the branch
+// chain is folded into three small LDS tables (LDS reads run on their own pipe) filled by the host:
+//   lutA[q + 255]   = atanf((float)q), q = the C integer quotient n / d in [-255, 255]
+//   lutR[d + 255]   = 65536 / |d| + 1 (0 for d == 0):  floor(|n| / |d|) == (|n| * R) >> 16 exactly for |n|,|d| <= 255
+//                     (checked for all 256 x 255 pairs in tests/test_oracle_known_answers.py and, on the device, by the
+//                     exhaustive 511 x 511 image of tests/test_gpu_parity.py)
+//   lutO[3*(sgn d + 1) + (sgn n + 1)] = the quadrant offset: d<0 -> PI; d>0 -> (n>0 ? 2PI : 0);
+//                     d==0 -> (n<0 ? PI/2 : n>0 ? 3PI/2 : 0)
+// P = a + offset reproduces every branch: for d == 0 the quotient is forced to 0 (R = 0), atanf(0) = +0 and +0 + x = x;
+// the n == 0 branches (:246-249) equal the general formula for the same reason; a + 0.0f == a for the no-offset branch.
+constexpr int kLutA = 0, kLutR = 511, kLutO = 1022, kLutWords = 1031;
+
+__device__ __forceinline__ float wrapped_phase(int G1, int G2, int G3, int G4, const float *lut, int &nz)
 {
+    const unsigned *lutu = reinterpret_cast<const unsigned *>(lut);
     const int n = G4 - G2, d = G1 - G3;
-    const int an = n < 0 ? -n : n, ad = d < 0 ? -d : d;
-    const int qa = (int)(((float)an + 0.5f) * __builtin_amdgcn_rcpf((float)(ad == 0 ? 1 : ad)));
-    const int q = ((n ^ d) < 0) ? -qa : qa;
-    const float a = lut[(ad == 0 ? 0 : q) + 255];
-    float P = (d < 0) ? (a + kPI) : ((n > 0) ? (a + kTwoPI) : a);
-    if (d == 0) {
-        P = (n > 0) ? kThreeHalfPI : kHalfPI;         // :250-253
-        if (n == 0) { P = 0.0f; ok = 0; }             // :254-255 (Q5 rule: P=0, pixel invalid)
-    }
-    return P;
+    const int an = n < 0 ? -n : n;
+    const unsigned R = lutu[kLutR + 255 + d];
+    const int qa = (int)(__umul24((unsigned)an, R) >> 16);           // |n| <= 255, R <= 65537: 24-bit multiply is exact
+    const int m = (n ^ d) >> 31;                      // 0 or -1: the quotient's sign
+    const float a = lut[kLutA + 255 + ((qa ^ m) - m)];
+    int sd, sn;                                       // sign() = clamp to [-1, 1] = one v_med3_i32 (hipcc otherwise
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sd) : "v"(d));      // emits two compares and two selects per sign)
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sn) : "v"(n));
+    const float off = lut[kLutO + 4 + __mul24(3, sd) + sn];
+    nz = n | d;                                       // == 0 <=> the reference leaves P[count] undefined (:254-255, Q5)
+    return a + off;
 }
 
 // mfreconstruct.cpp:265-268: P[] are doubles, P12/P23 computed in f64 and narrowed once, rest f32.
@@ -60,13 +69,13 @@ __device__ __forceinline__ float heterodyne(float P0f, float P1f, float P2f)
 __device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const float *lut, int &valid)
 {
     // computeShadows :198-204: (float)white - (float)black > blackThreshold (exact in integers)
-    const int mask = (g[0] - g[1] > black_thr) ? 1 : 0;
-    int ok = 1;
-    const float P0 = wrapped_phase(g[2], g[3], g[4], g[5], lut, ok);
-    const float P1 = wrapped_phase(g[6], g[7], g[8], g[9], lut, ok);
-    const float P2 = wrapped_phase(g[10], g[11], g[12], g[13], lut, ok);
+    const bool mask = g[0] - g[1] > black_thr;
+    int nz0, nz1, nz2;
+    const float P0 = wrapped_phase(g[2], g[3], g[4], g[5], lut, nz0);
+    const float P1 = wrapped_phase(g[6], g[7], g[8], g[9], lut, nz1);
+    const float P2 = wrapped_phase(g[10], g[11], g[12], g[13], lut, nz2);
     const float ph = heterodyne(P0, P1, P2);
-    valid = mask & ok;
+    valid = (mask && nz0 != 0 && nz1 != 0 && nz2 != 0) ? 1 : 0;   // Q5 rule: an undefined P makes the pixel invalid
     return mask ? ph : 0.0f;
 }
 
@@ -177,7 +186,7 @@ __device__ __forceinline__ unsigned word_of(const u32x4 &v, int k) { return v[k]
 
 __device__ __forceinline__ void load_lut(float *lut, const float *__restrict__ lut_g)
 {
-    for (int i = threadIdx.x; i < kAtanLutSize; i += blockDim.x) lut[i] = lut_g[i];
+    for (int i = threadIdx.x; i < kLutWords; i += blockDim.x) lut[i] = lut_g[i];
     __syncthreads();
 }
 
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
                                                         const float *__restrict__ lut_g,
                                                         float *__restrict__ phase, uint8_t *__restrict__ valid)
 {
-    __shared__ float lut[512];
+    __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
     typedef typename WordVec<NW>::type vec_t;
     constexpr int V = 4 * NW;
@@ -196,7 +205,9 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
         unsigned row, col0;
         if (pitch == W) { row = 0; col0 = g * V; }          // flat image: no row arithmetic
         else { row = g / gpr; col0 = (g - row * gpr) * V; }
-        const size_t so = (size_t)row * pitch + col0, oo = (size_t)row * W + col0;
+        // 32-bit byte offsets (image < 2 GiB, checked by the C ABI): lets the compiler use the SGPR-base + VGPR-offset
+        // addressing form instead of a 64-bit add per plane
+        const unsigned so = row * (unsigned)pitch + col0, oo = row * (unsigned)W + col0;
         vec_t w[SLR_MF_PLANES];
 #pragma unroll
         for (int p = 0; p < SLR_MF_PLANES; p++)
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256) void mf_decode_scalar_kernel(MfPlanes pl, int 
                                                                const float *__restrict__ lut_g,
                                                                float *__restrict__ phase, uint8_t *__restrict__ valid)
 {
-    __shared__ float lut[512];
+    __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
     const unsigned total = (unsigned)W * (unsigned)H;
     for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
                                                              const uint16_t *__restrict__ map_frac,
                                                              float *__restrict__ phase, uint8_t *__restrict__ valid)
 {
-    __shared__ float lut[512];
+    __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
     const int gpr = W / V;
     const unsigned total = (unsigned)gpr * (unsigned)H;
@@ -372,33 +383,43 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
 
 // ------------------------------------------------------------------------------------------------------
 // fused K1+K2, LDS-tiled form (the default): one workgroup rectifies + decodes a 64 x 16 destination tile.
-//   1. every thread loads the map entries of its 4 pixels; a wave-shuffle + LDS reduction gives the tile's source
-//      bounding box (a smooth map turns a 64x16 tile into roughly 70x19 source pixels);
-//   2. the box of all 14 planes is copied HBM -> LDS once, with coalesced dword loads (14 independent loads in
+//   0. (once per map, at slr_set_rectify_maps) tile_boxes_kernel reduces every tile's map entries to the bounding
+//      box of its source footprints with wave shuffles (a smooth map turns 64x16 into roughly 70x19 source pixels);
+//   1. the box of all 14 planes is copied HBM -> LDS once, with coalesced dword loads (14 independent loads in
 //      flight per thread); everything outside the image is stored as 0, which IS cv::remap's BORDER_CONSTANT, so
-//      the border cases need no special code at all;
-//   3. the 2x2 taps come from LDS (two dwords per source row, v_alignbyte to the tap pair, v_dot4_u32_u8 blend),
-//      then the same per-pixel decode as K2.
+//      the border cases need no special code at all.  LDS layout: [row][dword column][plane], i.e. the 14 planes
+//      of one source dword sit next to each other -> every tap read is base + immediate (ds_read2_b32);
+//   2. per pixel the 2x2 footprint of each plane is two dword pairs; v_perm_b32 cuts the two bytes out as a u16
+//      pair and two v_dot2_u32_u16 with the 16-bit weights wx*wy accumulate the whole bilinear sum:
+//      (dot2(row1, w1, dot2(row0, w0, 512))) >> 10 == OpenCV's (sum tap*w + 16384) >> 15 exactly;
+//   3. the same per-pixel decode as K2.
+// One pixel per lane and four passes of four rows: a wave writes 64 consecutive pixels, live state stays small.
 // Square-ish tiles keep the halo small under rotation; an XCD-banded tile order keeps vertically adjacent tiles
-// (which share source rows) on one L2.  A box that does not fit the LDS budget (wild maps) falls back, per
-// workgroup, to the direct gather of the generic kernel.
+// (which share source rows) on one L2 (PMC: 248 MB fetched per camera vs 246 MB ideal).  A box that does not fit
+// the LDS budget (wild maps) falls back, per workgroup, to the direct gather of the generic kernel.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 16;
 
-struct TileBox { int x0, y0, LP, BH, PS; bool any, fits; };
-
-// block-wide bounding box of the footprints (taps that are completely outside the image are ignored)
-template <int V>
-__device__ __forceinline__ TileBox tile_box(const Tap (&taps)[V], bool active, int nplanes, int budget, int (*red)[4])
+// int4 per tile: x = x0 (multiple of 4), y = y0, z = BW4 (dwords per row), w = BH (rows); z == 0: no footprint
+__global__ __launch_bounds__(256) void tile_boxes_kernel(const int16_t *__restrict__ map_xy, int W, int H, int tiles_x,
+                                                         int tiles_y, int4 *__restrict__ boxes)
 {
+    __shared__ int red[4][4];
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = tx * kTileW + lane;
     int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
-    if (active) {
 #pragma unroll
-        for (int i = 0; i < V; i++)
-            if (taps[i].kind != 1) {
-                mnx = taps[i].sx < mnx ? taps[i].sx : mnx; mxx = taps[i].sx > mxx ? taps[i].sx : mxx;
-                mny = taps[i].sy < mny ? taps[i].sy : mny; mxy = taps[i].sy > mxy ? taps[i].sy : mxy;
+    for (int q = 0; q < 4; q++) {
+        const int row = ty * kTileH + 4 * q + wv;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+            if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {       // footprints completely outside read 0
+                mnx = sx < mnx ? sx : mnx; mxx = sx > mxx ? sx : mxx;
+                mny = sy < mny ? sy : mny; mxy = sy > mxy ? sy : mxy;
             }
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -408,35 +429,40 @@ __device__ __forceinline__ TileBox tile_box(const Tap (&taps)[V], bool active, i
         t = __shfl_xor(mny, d); mny = t < mny ? t : mny;
         t = __shfl_xor(mxy, d); mxy = t > mxy ? t : mxy;
     }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
+    if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
     __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
-        mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
+            mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+        }
+        int4 b = make_int4(0, 0, 0, 0);
+        if (mnx <= mxx) {
+            b.x = mnx & ~3;                                  // dword-aligned origin (also for negative x)
+            b.y = mny;
+            b.z = (((mxx + 1) - b.x + 1) + 3) >> 2;          // columns x0 .. mxx+1 in dwords
+            b.w = (mxy + 1) - mny + 1;                       // rows    y0 .. mxy+1
+        }
+        boxes[blockIdx.x] = b;
     }
-    TileBox b;
-    b.any = mnx <= mxx;
-    b.x0 = mnx & ~3;                                        // dword-aligned origin (also for negative x)
-    b.y0 = mny;
-    b.LP = b.any ? (((mxx + 1) - b.x0 + 1) + 3) & ~3 : 4;  // columns x0 .. mxx+1, rounded up to dwords
-    b.BH = b.any ? (mxy + 1) - mny + 1 : 1;                 // rows    y0 .. mxy+1
-    b.PS = b.LP * b.BH;
-    b.fits = b.any && (long long)b.PS * nplanes <= budget && b.LP <= 1024 && b.BH <= 1024;
-    return b;
+}
+
+hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s)
+{
+    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, s, map_xy, W, H, tiles_x, tiles_y, boxes);
+    return hipGetLastError();
+}
+size_t tile_boxes_bytes(int W, int H)
+{
+    return (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH) * sizeof(int4);
 }
 
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
-__device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ plane, int pitch, int W, int H, int gx,
-                                                   int gy, bool aligned)
+__device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ plane, int pitch, int W, int H, int gx, int gy)
 {
     if ((unsigned)gy >= (unsigned)H) return 0u;
     const uint8_t *q = plane + (size_t)gy * pitch + gx;
-    if (gx >= 0 && gx + 3 < W) {
-        if (aligned) return *reinterpret_cast<const unsigned *>(q);
-        return (unsigned)q[0] | ((unsigned)q[1] << 8) | ((unsigned)q[2] << 16) | ((unsigned)q[3] << 24);
-    }
     unsigned v = 0;
 #pragma unroll
     for (int b = 0; b < 4; b++)
@@ -444,77 +470,89 @@ __device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ p
     return v;
 }
 
-// blended sample of one plane for one pixel out of the LDS tile
-__device__ __forceinline__ unsigned tile_sample(const uint8_t *tile_plane, int LP, int base, unsigned wxp, unsigned wy0,
-                                                unsigned wy1)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int NP>
+struct TileTaps {                        // per-pixel tap state shared by all planes
+    int a0, a1;                          // LDS byte addresses of the dword pair in source rows sy and sy+1 (plane 0)
+    unsigned sel;                        // v_perm selector: bytes (sh, 0, sh+1, 0) -> u16 pair of the two taps
+    u16x2 w0, w1;                        // wx0*wy0, wx1*wy0 | wx0*wy1, wx1*wy1 (<= 1024 each)
+};
+
+template <int NP>
+__device__ __forceinline__ TileTaps<NP> tile_taps(const Tap &t, int x0, int y0, int BW4)
 {
-    const int a = base & ~3;
-    const unsigned sh = (unsigned)(base & 3);
-    const unsigned *r0 = reinterpret_cast<const unsigned *>(tile_plane + a);
-    const unsigned *r1 = reinterpret_cast<const unsigned *>(tile_plane + a + LP);
-    const unsigned p0 = __builtin_amdgcn_alignbyte(r0[1], r0[0], sh);   // bytes base, base+1 in the low half
-    const unsigned p1 = __builtin_amdgcn_alignbyte(r1[1], r1[0], sh);
-    const unsigned h0 = __builtin_amdgcn_udot4(p0, wxp, 0u, false);    // wxp = wx0 | wx1<<8, upper bytes 0
-    const unsigned h1 = __builtin_amdgcn_udot4(p1, wxp, 0u, false);
-    return (h0 * wy0 + h1 * wy1 + 512u) >> 10;
+    TileTaps<NP> k;
+    const bool out = t.kind == 1;        // completely outside: zero weights, any valid address
+    const int bx = out ? 0 : t.sx - x0, r0 = out ? 0 : t.sy - y0;
+    const unsigned sh = (unsigned)bx & 3u;
+    k.a0 = __mul24(__mul24(r0, BW4) + (bx >> 2), NP * 4);
+    k.a1 = k.a0 + __mul24(BW4, NP * 4);
+    k.sel = sh | 0x0C000C00u | ((sh + 1u) << 16);
+    const unsigned wx0 = out ? 0u : (unsigned)t.wx0, wx1 = out ? 0u : (unsigned)t.wx1;
+    k.w0.x = (unsigned short)__umul24(wx0, (unsigned)t.wy0); k.w0.y = (unsigned short)__umul24(wx1, (unsigned)t.wy0);
+    k.w1.x = (unsigned short)__umul24(wx0, (unsigned)t.wy1); k.w1.y = (unsigned short)__umul24(wx1, (unsigned)t.wy1);
+    return k;
 }
 
-__global__ __launch_bounds__(256, 4) void mf_rect_decode_lds_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+// blended sample of plane p: LDS reads are (base + immediate), 2 perms, 2 dot2, 1 shift
+template <int NP>
+__device__ __forceinline__ int tile_sample(const uint8_t *tile, const TileTaps<NP> &k, int p)
+{
+    const unsigned *q0 = reinterpret_cast<const unsigned *>(tile + k.a0);
+    const unsigned *q1 = reinterpret_cast<const unsigned *>(tile + k.a1);
+    const unsigned p0 = __builtin_amdgcn_perm(q0[p + NP], q0[p], k.sel);
+    const unsigned p1 = __builtin_amdgcn_perm(q1[p + NP], q1[p], k.sel);
+    unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), k.w0, 512u, false);
+    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), k.w1, acc, false);
+    return (int)(acc >> 10);
+}
+
+__global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                                  const float *__restrict__ lut_g,
                                                                  const int16_t *__restrict__ map_xy,
                                                                  const uint16_t *__restrict__ map_frac,
+                                                                 const int4 *__restrict__ boxes,
                                                                  float *__restrict__ phase, uint8_t *__restrict__ valid,
                                                                  int tiles_x, int tiles_y, int budget, int aligned)
 {
+    constexpr int NP = SLR_MF_PLANES;
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
-    __shared__ float lut[512];
-    __shared__ int red[4][4];
+    __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
     // XCD band order (see mf_rect_decode_kernel): consecutive virtual ids walk tiles row-major inside a band
     const unsigned nb = gridDim.x, per = nb / 8;
     const unsigned vb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
     const int ty = (int)(vb / (unsigned)tiles_x), tx = (int)(vb - (unsigned)ty * tiles_x);
     if (ty >= tiles_y) return;                              // padding blocks (whole workgroup leaves together)
-    // lane -> pixel: a wave owns 64 consecutive pixels of one tile row; 4 passes of 4 rows cover the 64x16 tile.
-    // One pixel per lane per pass keeps the live state small (14 samples) and makes every store a coalesced run.
+    const int4 box = boxes[ty * tiles_x + tx];
+    const int x0 = box.x, y0 = box.y, BW4 = box.z, BH = box.w;
+    const bool any = BW4 > 0;
+    const bool fits = any && (long long)BW4 * BH * (NP * 4) <= budget;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = tx * kTileW + lane;
-    Tap taps[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int row = ty * kTileH + 4 * q + wv;
-        if (row < H && col < W) {
-            const size_t m = (size_t)row * W + col;
-            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
-            taps[q] = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
-        } else {
-            taps[q] = make_tap(0, 0, 0, pitch, W, H);
-            taps[q].kind = 1;
-        }
-    }
-    const TileBox box = tile_box<4>(taps, true, SLR_MF_PLANES, budget, red);
 
-    if (box.fits) {
+    if (fits) {
         // ---- HBM -> LDS: each dword of the box once per plane -------------------------------------------
-        const int BW4 = box.LP >> 2, E = box.BH * BW4;
+        const int E = BH * BW4;
         const float inv = 1.0f / (float)BW4;
         for (int e = threadIdx.x; e < E; e += 256) {
             const int rr = (int)(((float)e + 0.5f) * inv);  // e / BW4 (exact: e < 2^20, remainder margin 0.5/BW4)
             const int cc = e - rr * BW4;
-            const int gx = box.x0 + 4 * cc, gy = box.y0 + rr;
-            unsigned v[SLR_MF_PLANES];
+            const int gx = x0 + 4 * cc, gy = y0 + rr;
+            unsigned v[NP];
             // the in/out-of-image decision is the same for all planes: decide once, then 14 independent loads
             if (aligned && (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W) {
-                const size_t off = (size_t)gy * pitch + gx;
+                const unsigned off = (unsigned)gy * (unsigned)pitch + (unsigned)gx;
 #pragma unroll
-                for (int p = 0; p < SLR_MF_PLANES; p++) v[p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
+                for (int p = 0; p < NP; p++) v[p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
             } else {
 #pragma unroll 1
-                for (int p = 0; p < SLR_MF_PLANES; p++) v[p] = load_src_dword(pl.p[p], pitch, W, H, gx, gy, false);
+                for (int p = 0; p < NP; p++) v[p] = load_src_dword(pl.p[p], pitch, W, H, gx, gy);
             }
+            u32x2 *dst = reinterpret_cast<u32x2 *>(tile + (size_t)e * (NP * 4));
 #pragma unroll
-            for (int p = 0; p < SLR_MF_PLANES; p++)
-                *reinterpret_cast<unsigned *>(tile + p * box.PS + rr * box.LP + 4 * cc) = v[p];
+            for (int p = 0; p < NP; p += 2) { u32x2 w2; w2.x = v[p]; w2.y = v[p + 1]; dst[p >> 1] = w2; }
         }
         __syncthreads();
     }
@@ -522,26 +560,22 @@ __global__ __launch_bounds__(256, 4) void mf_rect_decode_lds_kernel(MfPlanes pl,
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
         const int row = ty * kTileH + 4 * q + wv;
-        // re-read this pass's map entry (L2/L1 hit: it was fetched for the bounding box a moment ago) instead of
-        // keeping four Tap records alive across the fill phase (they would be indexed dynamically -> scratch)
         Tap t = make_tap(0, 0, 0, pitch, W, H);
         t.kind = 1;
-        if (row < H && col < W) {
-            const size_t m = (size_t)row * W + col;
-            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
+        const bool inb = row < H && col < W;
+        const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+        if (inb) {
+            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * (size_t)m);
             t = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
         }
-        int gpx[SLR_MF_PLANES];
-        if (box.fits) {
-            const bool out = t.kind == 1;                   // completely outside: zero weights -> every sample is 0
-            const int base = out ? 0 : (t.sy - box.y0) * box.LP + (t.sx - box.x0);
-            const unsigned wxp = out ? 0u : ((unsigned)t.wx0 | ((unsigned)t.wx1 << 8));
+        int gpx[NP];
+        if (fits) {
+            const TileTaps<NP> k = tile_taps<NP>(t, x0, y0, BW4);
 #pragma unroll
-            for (int p = 0; p < SLR_MF_PLANES; p++)
-                gpx[p] = (int)tile_sample(tile + p * box.PS, box.LP, base, wxp, (unsigned)t.wy0, (unsigned)t.wy1);
+            for (int p = 0; p < NP; p++) gpx[p] = tile_sample<NP>(tile, k, p);
         } else {
 #pragma unroll 1
-            for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = box.any ? sample(pl.p[p], pitch, W, H, t) : 0;
+            for (int p = 0; p < NP; p++) gpx[p] = any ? sample(pl.p[p], pitch, W, H, t) : 0;
         }
         int v;
         const float ph = mf_pixel(gpx, black_thr, lut, v);
@@ -550,8 +584,7 @@ __global__ __launch_bounds__(256, 4) void mf_rect_decode_lds_kernel(MfPlanes pl,
         vw |= (unsigned)__shfl_down(v, 1) << 8;
         vw |= (unsigned)__shfl_down(v, 2) << 16;
         vw |= (unsigned)__shfl_down(v, 3) << 24;
-        if (row < H && col < W) {
-            const size_t m = (size_t)row * W + col;
+        if (inb) {
             __builtin_nontemporal_store(ph, phase + m);
             if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
         }
@@ -569,16 +602,17 @@ static unsigned pick_blocks(size_t groups)
 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
-                            int vec_hint, int rect_algo, hipStream_t s)
+                            const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
-    if (map_xy && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0)) {
+    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0)) {
         bool aligned = pitch % 4 == 0;
         for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
         const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
         const int budget = 24 * 1024;                        // 14 planes x ~72 x 23 source bytes; 6 workgroups per CU
         hipLaunchKernelGGL(mf_rect_decode_lds_kernel, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl, pitch, W, H,
-                           black_thr, atan_lut, map_xy, map_frac, phase, valid, tiles_x, tiles_y, budget, aligned ? 1 : 0);
+                           black_thr, atan_lut, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, tiles_x, tiles_y,
+                           budget, aligned ? 1 : 0);
         return hipGetLastError();
     }
     if (map_xy) {

@@ -47,6 +47,7 @@ struct slr_ctx {
     float *d_lut = nullptr;
     int16_t *d_map_xy[2] = {nullptr, nullptr};
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
+    void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
@@ -236,7 +237,7 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
     ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
-                                c->opt_mf_decode_vec, c->opt_rect_algo, c->stream));
+                                rectify ? c->d_tile_box[cam] : nullptr, c->opt_mf_decode_vec, c->opt_rect_algo, c->stream));
     return SLR_OK;
 }
 
@@ -348,10 +349,19 @@ int slr_create(int device_id, slr_ctx **out)
         if (hipSetDevice(device_id) != hipSuccess) { st = SLR_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { st = SLR_ERR_HIP; break; }
         c->own_stream = true;
-        // 511-entry atanf table over the integer quotients; the host libm fills it so the
-        // device never evaluates a transcendental (no libm-vs-ocml ULP drift)
-        float lut[kAtanLutSize];
-        for (int q = -255; q <= 255; q++) lut[q + 255] = atanf((float)q);
+        // decode tables (kernels_decode.hip, wrapped_phase): atanf over the integer quotients -- filled by
+        // the host libm so the device never evaluates a transcendental (no libm-vs-ocml ULP drift) -- the 16-bit
+        // reciprocals of |d| and the 3x3 quadrant offsets of mfreconstruct.cpp:246-261
+        union { float f; unsigned u; } lut[kDecodeLutWords];
+        for (int q = -255; q <= 255; q++) lut[q + 255].f = atanf((float)q);
+        for (int d = -255; d <= 255; d++) lut[511 + d + 255].u = d == 0 ? 0u : 65536u / (unsigned)(d < 0 ? -d : d) + 1u;
+        {
+            const float PI = kPI;
+            const float off[9] = {PI, PI, PI,                      /* d < 0 : atan + PI             (:256-257) */
+                                  PI / 2, 0.0f, 3 * PI / 2,        /* d == 0: n<0 PI/2, n==0 undefined, n>0 3PI/2 (:250-255) */
+                                  0.0f, 0.0f, 2 * PI};             /* d > 0 : n>0 atan + 2PI else atan (:258-261, :246-247) */
+            for (int i = 0; i < 9; i++) lut[1022 + i].f = off[i];
+        }
         if (hipMalloc(&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
         if (hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) { st = SLR_ERR_HIP; break; }
         if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) { st = SLR_ERR_HIP; break; }
@@ -371,7 +381,7 @@ int slr_destroy(slr_ctx *c)
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     for (int i = 0; i < S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); }
+    for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -438,15 +448,18 @@ int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint1
         for (int k = 0; k < 2; k++) {
             if (c->d_map_xy[k]) { SLR_HIP(c, hipFree(c->d_map_xy[k])); c->d_map_xy[k] = nullptr; }
             if (c->d_map_frac[k]) { SLR_HIP(c, hipFree(c->d_map_frac[k])); c->d_map_frac[k] = nullptr; }
+            if (c->d_tile_box[k]) { SLR_HIP(c, hipFree(c->d_tile_box[k])); c->d_tile_box[k] = nullptr; }
         }
         c->map_w = W; c->map_h = H;
     }
     const size_t n = (size_t)W * H;
     if (!c->d_map_xy[cam]) SLR_HIP(c, hipMalloc(&c->d_map_xy[cam], n * 4));
     if (!c->d_map_frac[cam]) SLR_HIP(c, hipMalloc(&c->d_map_frac[cam], n * 2));
+    if (!c->d_tile_box[cam]) SLR_HIP(c, hipMalloc(&c->d_tile_box[cam], tile_boxes_bytes(W, H)));
     const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
     SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }

@@ -13,7 +13,7 @@ constexpr float kPI = 3.1416f;
 constexpr float kTwoPI = 2 * kPI;          // f32 expression, as in the reference (2*PI)
 constexpr float kThreeHalfPI = 3 * kPI / 2;
 constexpr float kHalfPI = kPI / 2;
-constexpr int kAtanLutSize = 511;          // quotient of two ints in [-255,255]
+constexpr int kDecodeLutWords = 1031;      // 511 atanf + 511 reciprocals + 9 quadrant offsets (kernels_decode.hip)
 
 struct MfPlanes { const uint8_t *p[SLR_MF_PLANES]; };
 struct GrayPlanes { const uint8_t *p[SLR_MAX_GRAY_PLANES]; };
@@ -45,8 +45,13 @@ hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int 
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr,
                             const float *atan_lut, float *phase, uint8_t *valid,
                             const int16_t *map_xy, const uint16_t *map_frac /* null -> no rectify */,
+                            const void *tile_boxes /* launch_tile_boxes output for this map, or null */,
                             int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */,
                             int rect_algo /* fused form: 0 = LDS-tiled, 1 = direct gather */, hipStream_t s);
+
+// per-tile source bounding boxes of a rectification map (64x16 destination tiles), int4 per tile
+size_t     tile_boxes_bytes(int W, int H);
+hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s);
 
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
