@@ -402,16 +402,15 @@ constexpr int kTileW = 64, kTileH = 16;
 
 // int4 per tile: x = x0 (multiple of 4), y = y0, z = BW4 (dwords per row), w = BH (rows); z == 0: no footprint
 __global__ __launch_bounds__(256) void tile_boxes_kernel(const int16_t *__restrict__ map_xy, int W, int H, int tiles_x,
-                                                         int tiles_y, int4 *__restrict__ boxes)
+                                                         int tile_h, int4 *__restrict__ boxes)
 {
     __shared__ int red[4][4];
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int col = tx * kTileW + lane;
     int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int row = ty * kTileH + 4 * q + wv;
+    for (int q = 0; q < tile_h / 4; q++) {
+        const int row = ty * tile_h + 4 * q + wv;
         if (row < H && col < W) {
             const size_t m = (size_t)row * W + col;
             const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
@@ -447,15 +446,24 @@ __global__ __launch_bounds__(256) void tile_boxes_kernel(const int16_t *__restri
     }
 }
 
+// two tables in one buffer: 64x16 tiles (multi-frequency kernel: 14 planes) then 64x4 tiles (Gray kernel: 22..66 planes)
+constexpr int kGrayTileH = 4;
+static size_t tile_count(int W, int H, int tile_h)
+{
+    return (size_t)((W + kTileW - 1) / kTileW) * ((H + tile_h - 1) / tile_h);
+}
 hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s)
 {
-    const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-    hipLaunchKernelGGL(tile_boxes_kernel, dim3(tiles_x * tiles_y), dim3(256), 0, s, map_xy, W, H, tiles_x, tiles_y, boxes);
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+                       kTileH, boxes);
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kGrayTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+                       kGrayTileH, boxes + tile_count(W, H, kTileH));
     return hipGetLastError();
 }
 size_t tile_boxes_bytes(int W, int H)
 {
-    return (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH) * sizeof(int4);
+    return (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH)) * sizeof(int4);
 }
 
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
@@ -743,12 +751,142 @@ __global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fused K1+K3, LDS-tiled form: same scheme as mf_rect_decode_lds_kernel with 64 x 4 tiles (one pixel per lane, one
+// pass) because a Gray stack has 22..66 planes.  LDS layout [row][plane][dword column] (the plane count is a run-time
+// value, so the per-plane step is one v_add instead of an immediate).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl, int n_col_bits, int n_row_bits, int pitch,
+                                                                   int W, int H, int black_thr, int white_thr, int scan_w,
+                                                                   int scan_h, const int16_t *__restrict__ map_xy,
+                                                                   const uint16_t *__restrict__ map_frac,
+                                                                   const int4 *__restrict__ boxes,
+                                                                   int32_t *__restrict__ code_x, int32_t *__restrict__ code_y,
+                                                                   uint8_t *__restrict__ valid, int tiles_x, int tiles_y,
+                                                                   int budget, int aligned)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const int NP = 2 + 2 * n_col_bits + 2 * n_row_bits;
+    const unsigned nb = gridDim.x, per = nb / 8;
+    const unsigned vb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
+    const int ty = (int)(vb / (unsigned)tiles_x), tx = (int)(vb - (unsigned)ty * tiles_x);
+    if (ty >= tiles_y) return;
+    const int4 box = boxes[ty * tiles_x + tx];
+    const int x0 = box.x, y0 = box.y, BW4 = box.z, BH = box.w;
+    const bool any = BW4 > 0;
+    const bool fits = any && (long long)BW4 * BH * 4 * NP <= budget;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = tx * kTileW + lane, row = ty * kGrayTileH + wv;
+    const int rowstep = BW4 * 4;                            // bytes per (row, plane) line
+
+    if (fits) {
+        const int E = BH * BW4;
+        const float inv = 1.0f / (float)BW4;
+        for (int e = threadIdx.x; e < E; e += 256) {
+            const int rr = (int)(((float)e + 0.5f) * inv);
+            const int cc = e - rr * BW4;
+            const int gx = x0 + 4 * cc, gy = y0 + rr;
+            uint8_t *dst = tile + (size_t)(rr * NP) * rowstep + 4 * cc;
+            if (aligned && (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W) {
+                const unsigned off = (unsigned)gy * (unsigned)pitch + (unsigned)gx;
+                // 16 independent loads in flight per thread, then 16 LDS stores (a plain p-loop waits per load)
+                for (int pb = 0; pb < NP; pb += 16) {
+                    unsigned v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        v[i] = (pb + i < NP) ? *reinterpret_cast<const unsigned *>(pl.p[pb + i] + off) : 0u;
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = v[i];
+                }
+            } else {
+#pragma unroll 1
+                for (int p = 0; p < NP; p++)
+                    *reinterpret_cast<unsigned *>(dst + p * rowstep) = load_src_dword(pl.p[p], pitch, W, H, gx, gy);
+            }
+        }
+        __syncthreads();
+    }
+    const bool inb = row < H && col < W;
+    const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+    Tap t = make_tap(0, 0, 0, pitch, W, H);
+    t.kind = 1;
+    if (inb) {
+        const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * (size_t)m);
+        t = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
+    }
+    // tap state shared by all planes
+    const bool out = t.kind == 1;
+    const int bx = out ? 0 : t.sx - x0, r0 = out ? 0 : t.sy - y0;
+    const unsigned sh = (unsigned)bx & 3u;
+    const unsigned sel = sh | 0x0C000C00u | ((sh + 1u) << 16);
+    const unsigned wx0 = out ? 0u : (unsigned)t.wx0, wx1 = out ? 0u : (unsigned)t.wx1;
+    u16x2 w0, w1;
+    w0.x = (unsigned short)__umul24(wx0, (unsigned)t.wy0); w0.y = (unsigned short)__umul24(wx1, (unsigned)t.wy0);
+    w1.x = (unsigned short)__umul24(wx0, (unsigned)t.wy1); w1.y = (unsigned short)__umul24(wx1, (unsigned)t.wy1);
+    const int a0 = fits ? (r0 * NP) * rowstep + (bx & ~3) : 0;
+    const int rowjump = NP * rowstep;                       // same plane, next source row
+    auto fetch = [&](int p) -> int {
+        if (fits) {
+            const unsigned *q0 = reinterpret_cast<const unsigned *>(tile + a0 + p * rowstep);
+            const unsigned *q1 = reinterpret_cast<const unsigned *>(tile + a0 + p * rowstep + rowjump);
+            const unsigned p0 = __builtin_amdgcn_perm(q0[1], q0[0], sel);
+            const unsigned p1 = __builtin_amdgcn_perm(q1[1], q1[0], sel);
+            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), w0, 512u, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), w1, acc, false);
+            return (int)(acc >> 10);
+        }
+        return any ? sample(pl.p[p], pitch, W, H, t) : 0;
+    };
+    const int wv_ = fetch(0), bv = fetch(1);
+    int gx_ = 0, gy_ = 0, err = 0;
+#pragma unroll 4
+    for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
+        const int v1 = fetch(2 * c + 2), v2 = fetch(2 * c + 3);
+        const int df = v1 - v2;
+        err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+        gx_ = (gx_ << 1) | (v1 > v2 ? 1 : 0);
+    }
+    for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
+        const int v1 = fetch(2 * c + 2 + 2 * n_col_bits), v2 = fetch(2 * c + 3 + 2 * n_col_bits);
+        const int df = v1 - v2;
+        err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+        gy_ = (gy_ << 1) | (v1 > v2 ? 1 : 0);
+    }
+    const int mask = (wv_ - bv > black_thr) ? 1 : 0;
+    const int x = gray_to_binary(gx_), y = gray_to_binary(gy_);
+    if (n_row_bits > 0) err |= (y > scan_h || x > scan_w) ? 1 : 0;   // reconstruct.cpp:364 (Q9 '>')
+    else err |= (x > scan_w) ? 1 : 0;                                // reconstruct.cpp:403
+    const int ok = mask & (err ^ 1);
+    unsigned vw = (unsigned)ok;
+    vw |= (unsigned)__shfl_down(ok, 1) << 8;
+    vw |= (unsigned)__shfl_down(ok, 2) << 16;
+    vw |= (unsigned)__shfl_down(ok, 3) << 24;
+    if (inb) {
+        __builtin_nontemporal_store(ok ? x : -1, code_x + m);
+        if (code_y) __builtin_nontemporal_store((ok && n_row_bits > 0) ? y : -1, code_y + m);
+        if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+    }
+}
+
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h, int32_t *code_x,
                               int32_t *code_y, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
-                              hipStream_t s)
+                              const void *tile_boxes, int rect_algo, hipStream_t s)
 {
     const int nplanes = 2 + 2 * n_col_bits + 2 * n_row_bits;
+    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)valid % 4 == 0)) {
+        bool aligned = pitch % 4 == 0;
+        for (int p = 0; p < nplanes; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kGrayTileH - 1) / kGrayTileH;
+        const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
+        const int budget = 32 * 1024;
+        const int4 *boxes = (const int4 *)tile_boxes + tile_count(W, H, kTileH);
+        hipLaunchKernelGGL(gray_rect_decode_lds_kernel, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl, n_col_bits,
+                           n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac, boxes, code_x,
+                           code_y, valid, tiles_x, tiles_y, budget, aligned ? 1 : 0);
+        return hipGetLastError();
+    }
     bool a4 = (W % 4 == 0) && ((uintptr_t)code_x % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
               (!code_y || (uintptr_t)code_y % 16 == 0);
     if (!map_xy) {

@@ -434,49 +434,43 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 //      lane the kstart it would really have seen; lanes whose kstart moved re-search.  Lane l is final after
 //      at most l rounds, a fixed point equals the sequential answer, and monotone rows finish in one round.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bitonic_sort_lds(unsigned *S, int N)
-{
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int t = threadIdx.x; t < (N >> 1); t += blockDim.x) {
-                const int i = 2 * t - (t & (jj - 1));       // index with bit jj clear
-                const int p = i + jj;
-                const unsigned a = S[i], b = S[p];
-                const bool up = ((i & k) == 0);
-                if ((a > b) == up) { S[i] = b; S[p] = a; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
+template <int IPT>
 __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
                                                        const int32_t *__restrict__ codeR, const uint8_t *__restrict__ validR,
-                                                       int W, int H, int N, int TC, DevCalib cal,
+                                                       int W, int H, int TC, DevCalib cal,
                                                        const uint8_t *__restrict__ whiteL, const uint8_t *__restrict__ whiteR,
                                                        float *__restrict__ xyz, uint8_t *__restrict__ has,
                                                        uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
 {
-    extern __shared__ unsigned S[];                // N = next pow2 >= W sorted keys, then TC u16 list heads
-    unsigned short *first = reinterpret_cast<unsigned short *>(S + N);   // first[code] = index of the code's
-    const int row = blockIdx.x;                                          // smallest column in S (0xFFFF = none)
+    constexpr int N = 256 * IPT;
+    typedef hipcub::BlockRadixSort<unsigned, 256, IPT> Sort;
+    __shared__ union { typename Sort::TempStorage sort; unsigned S[N]; } sh;
+    __shared__ short mk[N];                        // match column per left pixel (-1 = none), written by the walk
+    extern __shared__ unsigned short first[];      // TC list heads: first[code] = index in S of the code's smallest
+    unsigned *S = sh.S;                            // column (0xFFFF = none)
+    const int row = blockIdx.x;
     const size_t base = (size_t)row * W;
-    for (int k = threadIdx.x; k < N; k += 256) {
-        unsigned key = 0xFFFFFFFFu;
-        if (k < W && validR[base + k]) key = ((unsigned)codeR[base + k] << 16) | (unsigned)k;
-        S[k] = key;
+    // keys (code << 16 | k) in blocked order (= ascending k); a stable radix sort on the 16 code bits alone keeps the
+    // columns of every code ascending: 2 passes of 8 bits instead of a 78-stage bitonic network
+    unsigned keys[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const int k = threadIdx.x * IPT + i;
+        keys[i] = (k < W && validR[base + k]) ? (((unsigned)codeR[base + k] << 16) | (unsigned)k) : 0xFFFFFFFFu;
     }
     for (int t = threadIdx.x; t < TC; t += 256) first[t] = 0xFFFFu;
+    Sort(sh.sort).Sort(keys, 16, 32);
+    __syncthreads();                               // everybody is done with sh.sort before S aliases it
+#pragma unroll
+    for (int i = 0; i < IPT; i++) S[threadIdx.x * IPT + i] = keys[i];
     __syncthreads();
-    bitonic_sort_lds(S, N);
     for (int i = threadIdx.x; i < N; i += 256) {
         const unsigned v = S[i];
         if (v != 0xFFFFFFFFu && (v >> 16) < (unsigned)TC && (i == 0 || (S[i - 1] >> 16) != (v >> 16)))
             first[v >> 16] = (unsigned short)i;
     }
     __syncthreads();
-    if (threadIdx.x >= 64) return;                 // wave 0 walks; no barrier below this line
-
+    if (threadIdx.x < 64) {                        // wave 0 walks the row; the matches go to LDS
     const int lane = threadIdx.x;
     int ks = 0;                                    // reconstruct.cpp:556
     for (int j0 = 0; j0 < W; j0 += 64) {
@@ -522,8 +516,13 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
         }
         const int last = __shfl(inc, 63);
         ks = ks > last ? ks : last;                // kstart = k of the last match (reconstruct.cpp:604)
-
-        if (!inb) continue;
+        if (inb) mk[j] = (short)m;                 // W <= 32768: columns fit 15 bits, -1 = no match
+    }
+    }
+    __syncthreads();
+    // all four waves: reprojection + coalesced stores
+    for (int j = threadIdx.x; j < W; j += 256) {
+        const int m = mk[j];
         float X[3] = {0.0f, 0.0f, 0.0f};
         int col = 0;
         if (m >= 0) {
@@ -543,11 +542,19 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
                            int W, int H, const DevCalib &cal, const uint8_t *whiteL, const uint8_t *whiteR,
                            float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s)
 {
-    int N = 2;
-    while (N < W) N <<= 1;
     const int TC = 8192;                           // codes below this use the direct list-head table (16 KB LDS)
-    hipLaunchKernelGGL(ge_match_kernel, dim3(H), dim3(256), (size_t)N * sizeof(unsigned) + (size_t)TC * 2, s, codeL,
-                       validL, codeR, validR, W, H, N, TC, cal, whiteL, whiteR, xyz, has, color, match_k);
+#define SLR_GE(IPT)                                                                                                    \
+    hipLaunchKernelGGL(ge_match_kernel<IPT>, dim3(H), dim3(256), (size_t)TC * 2, s, codeL, validL, codeR, validR, W, H, TC, \
+                       cal, whiteL, whiteR, xyz, has, color, match_k)
+    if (W <= 256) SLR_GE(1);
+    else if (W <= 512) SLR_GE(2);
+    else if (W <= 1024) SLR_GE(4);
+    else if (W <= 2048) SLR_GE(8);
+    else if (W <= 4096) SLR_GE(16);
+    else if (W <= 8192) SLR_GE(32);
+    else if (W <= 16384) SLR_GE(64);
+    else return hipErrorInvalidValue;              // the C ABI rejects wider Gray rows (LDS: keys + matches + heads)
+#undef SLR_GE
     return hipGetLastError();
 }
 

@@ -275,7 +275,7 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
     ProfScope ps(c, rectify ? K_GRAY_RECT_DECODE : K_GRAY_DECODE);
     SLR_HIP(c, launch_gray_decode(gp, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx, cy, valid,
                                   rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
-                                  c->stream));
+                                  rectify ? c->d_tile_box[cam] : nullptr, c->opt_rect_algo, c->stream));
     return SLR_OK;
 }
 
@@ -579,7 +579,7 @@ int slr_ge_triangulate(slr_ctx *c, const int32_t *codeL, const uint8_t *validL, 
     if (!c || !codeL || !validL || !codeR || !validR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
     if (color && (!whiteL || !whiteR)) return fail(c, SLR_ERR_INVALID_ARG, "color output needs both white planes");
     SLR_TRY(check_dims(c, W, H, W));
-    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    if (W > 16384) return fail(c, SLR_ERR_UNSUPPORTED, "W > 16384 does not fit the LDS row (Gray-code match)");
     SLR_TRY(use_device(c));
     SLR_TRY(need_calib(c));
     Stage st(c, mem);
@@ -712,7 +712,7 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
     const int np = 2 + 2 * ncol;
     for (int i = 0; i < np; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
     SLR_TRY(check_dims(c, W, H, pitch));
-    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    if (W > 16384) return fail(c, SLR_ERR_UNSUPPORTED, "W > 16384 does not fit the LDS row (Gray-code match)");
     SLR_TRY(use_device(c));
     SLR_TRY(need_calib(c));
     if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }

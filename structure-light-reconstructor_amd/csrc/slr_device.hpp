@@ -56,7 +56,8 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, h
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,
-                              const int16_t *map_xy, const uint16_t *map_frac, hipStream_t s);
+                              const int16_t *map_xy, const uint16_t *map_frac, const void *tile_boxes, int rect_algo,
+                              hipStream_t s);
 
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,

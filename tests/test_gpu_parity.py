@@ -216,7 +216,7 @@ def test_gray_range_check_uses_greater_than(ctx, oracle):
         assert v[0, scan_w] == 1 and v[0, scan_w + 1] == 0
 
 
-def test_gray_rectify_decode(ctx, oracle, synth):
+def test_gray_rectify_decode(ctx, oracle, synth, slr):
     W, H, scan_w = 320, 200, 300
     st = synth.render_gray_stack(W, H, scan_w, seed=8, noise=3)
     ncol = synth.gray_num_bits(scan_w)
@@ -228,8 +228,27 @@ def test_gray_rectify_decode(ctx, oracle, synth):
         raw = st[cam].numpy()
         rect = np.stack([oracle.remap_u8(raw[p], mx.numpy(), mf.numpy()) for p in range(raw.shape[0])])
         ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 4, scan_w, 0)
-        cx, _, v = ctx.gray_decode(raw, ncol, 0, BLACK, 4, scan_w, 0, rectify_cam=cam)
-        assert bits_equal(cx, ex) and bits_equal(v, ev)
+        for algo in (0, 1):                                          # LDS-tiled and direct-gather forms
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+            cx, _, v = ctx.gray_decode(raw, ncol, 0, BLACK, 4, scan_w, 0, rectify_cam=cam)
+            assert bits_equal(cx, ex) and bits_equal(v, ev), algo
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+    # rows too (GRAY_ONLY never rectifies in the reference, but the entry point allows it), odd size, wild map
+    W2, H2, sw, sh = 132, 37, 100, 90
+    st2 = synth.render_gray_stack(W2, H2, sw, sh, seed=9, noise=3, rows=True)
+    nc, nr = synth.gray_num_bits(sw), synth.gray_num_bits(sh)
+    rng = np.random.default_rng(3)
+    maps = [synth.make_rectify_maps(W2, H2, 0, strength=4.0),
+            (torch.from_numpy(np.stack([rng.integers(-9, W2 + 9, (H2, W2)), rng.integers(-9, H2 + 9, (H2, W2))], -1).astype(np.int16)),
+             torch.from_numpy(rng.integers(0, 1024, (H2, W2)).astype(np.uint16).view(np.int16)).view(torch.uint16))]
+    for mx, mf in maps:
+        mxn, mfn = mx.numpy(), mf.numpy()
+        ctx.set_rectify_maps(0, mxn, mfn)
+        raw = st2[0].numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mxn, mfn) for p in range(raw.shape[0])])
+        ex, ey, ev = oracle.gray_decode(rect, nc, nr, BLACK, 3, sw, sh)
+        cx, cy, v = ctx.gray_decode(raw, nc, nr, BLACK, 3, sw, sh, rectify_cam=0)
+        assert bits_equal(cx, ex) and bits_equal(cy, ey) and bits_equal(v, ev)
 
 
 # ---------------------------------------------------------------------------------------------------------
