@@ -9,8 +9,10 @@ frame.  Inputs are resident in HBM when the timed region starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): frames shard across ranks (weak scaling, no
 data-path collective inside the kernels); the per-step point cloud is assembled on every rank with one RCCL
-all-gather on a side stream, overlapped with the next step's compute (north_star: "RCCL all-gather over xGMI only
-to assemble the final point cloud").  --gather off measures the sharded path alone.
+all-gather (north_star: "RCCL all-gather over xGMI only to assemble the final point cloud"): by default once per job,
+inside the timed region (--gather final); --gather step gathers after every step on a side stream, double-buffered so it
+overlaps the next step's compute (160 MB per frame per peer: that mode measures xGMI, not the kernels); --gather off
+measures the sharded path alone.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed inside the timed
 region on the kernels' own stream), "kernels" (all kernels), "cpu_baseline" (the CPU oracle on a bounded sample).
@@ -46,7 +48,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--rectify", type=int, default=1, help="1: raw planes + fused rectification (the reference path)")
-    ap.add_argument("--gather", choices=["on", "off"], default="on", help="N>1: all-gather the point cloud every step")
+    ap.add_argument("--gather", choices=["final", "step", "off"], default="final",
+                    help="N>1: RCCL all-gather of the point cloud: once per job (the final assembly, inside the timed region), "
+                         "after every step (overlapped with the next step's compute), or never")
     ap.add_argument("--profile", type=int, default=1, help="bracket every kernel with HIP events (roofline)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU triangulation sample (0 = auto)")
@@ -98,10 +102,16 @@ def main():
                          (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    if os.environ.get("SLR_BENCH_ONE_DEVICE"):       # dry-run of the N>1 code path on a 1-GPU box (with gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SLR_BENCH_BACKEND", "nccl")     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     slr = importlib.import_module("structure-light-reconstructor_amd")
     synth = importlib.import_module("structure-light-reconstructor_amd.synth")
@@ -124,11 +134,13 @@ def main():
     nbuf = 2
     xyz = [torch.empty((1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
     has = [torch.empty((1, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    do_gather = world > 1 and args.gather == "on"
-    if do_gather:
+    do_gather = world > 1 and args.gather == "step"
+    final_gather = world > 1 and args.gather == "final"
+    if do_gather or final_gather:
         comm = torch.cuda.Stream(device=dev)
-        g_xyz = torch.empty((world, H, W, 3), dtype=torch.float32, device=dev)
-        g_has = torch.empty((world, H, W), dtype=torch.uint8, device=dev)
+        # output = concatenation of the per-rank clouds along dim 0 (the form every backend accepts)
+        g_xyz = torch.empty((world * H, W, 3), dtype=torch.float32, device=dev)
+        g_has = torch.empty((world * H, W), dtype=torch.uint8, device=dev)
         done_compute = [torch.cuda.Event() for _ in range(nbuf)]
         done_gather = [torch.cuda.Event() for _ in range(nbuf)]
 
@@ -163,6 +175,13 @@ def main():
     for i in range(args.steps):
         step(i)
     ev_ms = ctx.timer_end()
+    if final_gather:                                    # assemble the final point cloud on every rank (north_star)
+        b = (args.steps - 1) % nbuf
+        done_compute[b].record(compute)
+        comm.wait_event(done_compute[b])
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(g_xyz, xyz[b][0])
+            dist.all_gather_into_tensor(g_has, has[b][0])
     sync_all()
     elapsed = time.perf_counter() - t0
     prof = ctx.profile() if args.profile else {}
@@ -235,8 +254,9 @@ def main():
             "config": {"workload": "1x %dx%d stereo, 3-freq x 4-step (14 planes/camera) rectify+decode+unwrap+match+"
                                    "triangulate per GPU per step" % (W, H),
                        "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify),
-                       "parallelism": "frames sharded over %d GPU(s)%s" % (world, ", RCCL all-gather of XYZ+mask per step"
-                                                                           if do_gather else "")},
+                       "parallelism": "frames sharded over %d GPU(s)%s" % (
+                           world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else
+                           (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else ""))},
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4),
             "roofline": roofline, "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
         }
