@@ -1,8 +1,9 @@
 // kernels_decode.hip -- K1 (rectification remap), K2 (multi-frequency phase decode + heterodyne unwrap),
 // K3/K3' (Gray-code decode) and the fused rectify+decode variants.  gfx950 (MI355X) only.
 //
-// All three are HBM-bound streaming kernels over N separate u8 planes: no MFMA, plain integer/f32 ALU,
-// wide coalesced loads, a 511-entry atanf table in LDS (the reference's quotient is an integer).
+// Streaming kernels over N separate u8 planes: no MFMA, plain integer/f32 ALU, wide coalesced loads.  PMC shows they
+// move exactly the algorithmic HBM bytes and are bound by VALU issue, so the per-pixel branch chains live in small
+// LDS tables (the reference's quotient is an integer) and the bilinear blend uses v_perm / v_dot2.
 //
 // Reference behaviour restated (never copied):
 //   K1  stereoRect::doStereoRectify -> cv::remap(CV_16SC2,CV_16UC1,INTER_LINEAR)   Duke/stereorect.cpp:26-34

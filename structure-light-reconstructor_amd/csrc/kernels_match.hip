@@ -2,9 +2,9 @@
 // epipolar match + Q-matrix triangulation).  gfx950 (MI355X) only.
 //
 // Both search along one rectified image row, so a row of the right camera lives in LDS and rows are the
-// unit of parallelism (one workgroup per row).  Neither is HBM-bound: K4 is an LDS-broadcast/VALU sweep with
-// exact first-match semantics, K5 is an LDS sort + wave-parallel speculative walk that reproduces the
-// reference's sequential `kstart` dependency exactly (wavefront shuffles do the prefix-max).
+// unit of parallelism (one workgroup per row).  Neither is HBM-bound (PMC: VALU issue + LDS): K4 is an exact
+// indexed first-match search (LDS radix sort + bin index), K5 an LDS sort + wave-parallel speculative walk that
+// reproduces the reference's sequential `kstart` dependency exactly (wavefront shuffles do the prefix-max).
 //
 // Reference behaviour restated (never copied):
 //   K4  MFReconstruct::triangulation                    Duke/mfreconstruct.cpp:272-334
@@ -16,6 +16,7 @@
 
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 
 namespace slr {
 
@@ -38,18 +39,28 @@ __device__ __forceinline__ void undistort_point(float px, float py, const DevCam
     oy = (float)((double)(float)(y * c.fy) + c.cy);
 }
 
-// p3D = Q * p2D (cv::Mat f64 GEMM, sequential accumulation), X = (float)(xyz / w)
-__device__ __forceinline__ void reproject(const double *Q, double p0, double p1, double p2, float X[3])
+// p3D = Q * p2D (cv::Mat f64 GEMM, sequential accumulation), X = (float)(xyz / w).
+// simple != 0: Q has cv::stereoRectify's pattern [[1,0,0,a],[0,1,0,b],[0,0,0,c],[0,0,d,e]] (checked on the host); the
+// products with the structural zeros/ones are exact no-ops (0*x = 0, s + 0 = s, 1*x = x for finite x), so the short
+// form gives the same bits with 1 multiply + 3 adds instead of 16 + 16.
+__device__ __forceinline__ void reproject(const double *Q, int simple, double p0, double p1, double p2, float X[3])
 {
     double r[4];
+    if (simple) {
+        r[0] = p0 + Q[3];
+        r[1] = p1 + Q[7];
+        r[2] = Q[11];
+        r[3] = Q[14] * p2 + Q[15];
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        double s = 0;
-        s += Q[i * 4 + 0] * p0;
-        s += Q[i * 4 + 1] * p1;
-        s += Q[i * 4 + 2] * p2;
-        s += Q[i * 4 + 3] * 1.0;
-        r[i] = s;
+        for (int i = 0; i < 4; i++) {
+            double s = 0;
+            s += Q[i * 4 + 0] * p0;
+            s += Q[i * 4 + 1] * p1;
+            s += Q[i * 4 + 2] * p2;
+            s += Q[i * 4 + 3] * 1.0;
+            r[i] = s;
+        }
     }
     X[0] = (float)(r[0] / r[3]);
     X[1] = (float)(r[1] / r[3]);
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
             float ulx, uly, urx, ury;
             undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);      // mfreconstruct.cpp:297
             undistort_point((float)best, (float)row, cal.cam[1], urx, ury);   // :298
-            reproject(cal.Q, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);   // :299-311
+            reproject(cal.Q, 0, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);   // :299-311 (literal form)
             if (cal.has_T) apply_T(cal.T, X);                                 // :315-323
         }
         float *o = xyz + 3 * (base + j);
@@ -125,16 +136,20 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
 
 // ------------------------------------------------------------------------------------------------------
 // K4 (exact indexed form).  The sweep above is O(W) per left pixel; the same answer is available in
-// O(log W) because "first k (ascending) with |phiL - phiR[k]| < 0.1" only ever selects, for each DISTINCT
-// right phase value, that value's smallest column:
-//   1. one workgroup per row radix-sorts the right row's (sortable(phi), k) pairs in LDS (stable, so equal
-//      phases stay in ascending k); invalid / NaN pixels get the maximal key;
-//   2. run heads (phi != predecessor) are compacted -> D_phi[] ascending distinct values, D_k[] their min k;
-//   3. every left pixel binary-searches the first distinct value >= phiL - 0.1001 (compared in f64, exact) and
-//      walks forward while <= phiL + 0.1001, applying the reference's own f32 predicate
-//      fabsf(phiL - phiR) < 0.1f and keeping the smallest k.  The window is a strict superset of every value
-//      that can satisfy the predicate, so the result is identical to the linear sweep (asserted against both
-//      the oracle and the brute-force kernel in tests).
+// O(1) expected because "first k (ascending) with |phiL - phiR[k]| < 0.1" only ever selects, for each DISTINCT
+// right phase value, that value's smallest column.  One 1024-thread workgroup per row (4 pixels per thread, all
+// row I/O vectorised and issued up front):
+//   1. the right row's keys (12-bit phase bin, 4-bit hash of the value, column) are radix-sorted in LDS on the 16
+//      group bits only (2 passes, stable -> ascending column inside a group).  Any function of phi is a valid group
+//      key: equal phases share it, and colliding distinct values merely yield a few extra run heads;
+//   2. run heads (phase differs from its predecessor) are compacted -> (phi, min column) pairs grouped by bin;
+//   3. a suffix-min scan builds binfirst[b] = first pair whose bin >= b; two values closer than 0.1001 are at most
+//      one 0.25-wide bin apart, so bins [b-1, b+1] of phiL are a superset of its candidates;
+//   4. every left pixel applies the reference's own f32 predicate fabsf(phiL - phiR) < 0.1f to that window
+//      (~6 pairs, four per LDS round trip) and keeps the smallest column -- identical to the linear sweep (asserted
+//      against the oracle AND the sweep kernel on adversarial rows and on the whole 4096x3000 frame);
+//   5. Utilities::undistortPoints comes from per-pixel tables, Q*p and the three divisions stay f64.
+// Phase split at 4096x3000 (profiles/k4_stages.sh): loads 21 us, sort 66, heads 13, bins 10, queries 43, f64 + stores 55.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned sortable_key(float f)
 {
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
     __shared__ union {
         typename Sort::TempStorage sort;
-        struct { float phi[N]; unsigned short k[N]; } d;
+        struct { float2 pk[N]; } d;                      // distinct values: (phi, min column as bits)
     } sh;
     __shared__ float phR[N];                             // right-row phases, gathered by column after the sort
     __shared__ typename Scan::TempStorage scan_tmp;
@@ -211,7 +226,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     const int row = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)row * W;
     const int k0 = tid * IPT;
-    const bool vec = vec_ok != 0;
+    const bool vec = (vec_ok & 1) != 0;
+    const int stop = vec_ok >> 8;                        // debug: leave after phase N (SLR_DEBUG_K4_STOP), 0 = run all
 
     // all row loads of this thread are issued here, before the sort, and are independent of each other
     float pr[IPT], pl[IPT];
@@ -234,8 +250,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         keys[i] = ok ? ((((unsigned)phase_bin(pr[i]) << 4) | h4) << 16) | (unsigned)(k0 + i) : 0xFFFFFFFFu;
         phR[k0 + i] = pr[i];
     }
+    if (stop == 1) return;
     Sort(sh.sort).Sort(keys, 16, 32);
     __syncthreads();                                     // phR visible; everybody is done with sh.sort
+    if (stop == 2) return;
     unsigned phb[IPT];                                   // phase bits of the sorted items (0xFFFFFFFF = none)
 #pragma unroll
     for (int i = 0; i < IPT; i++) phb[i] = keys[i] != 0xFFFFFFFFu ? __float_as_uint(phR[keys[i] & 0xFFFFu]) : 0xFFFFFFFFu;
@@ -255,18 +273,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     Scan(scan_tmp).ExclusiveSum(heads, pos, total);
 #pragma unroll
     for (int i = 0; i < IPT; i++)
-        if (headmask & (1u << i)) { sh.d.phi[pos] = __uint_as_float(phb[i]); sh.d.k[pos] = (unsigned short)(keys[i] & 0xFFFFu); pos++; }
+        if (headmask & (1u << i)) { sh.d.pk[pos] = make_float2(__uint_as_float(phb[i]), __uint_as_float(keys[i] & 0xFFFFu)); pos++; }
     if (tid == 0) n_distinct = total;
     for (int b = tid; b <= kBins; b += BLOCK) binfirst[b] = 0xFFFFu;
     __syncthreads();
     const int nd = n_distinct;
+    if (stop == 3) return;
 
     // Bin index over the distinct values: bin(phi) = clamp(floor((phi + 512) * 4)) is monotone and two values
     // closer than 0.1001 land at most one bin apart, so bins [b-1, b+1] of phiL hold a superset of its
     // candidates.  binfirst[b] = first distinct index whose bin is >= b (suffix-min fill), binfirst[kBins] = nd.
     for (int i = tid; i < nd; i += BLOCK) {
-        const int b = phase_bin(sh.d.phi[i]);
-        if (i == 0 || phase_bin(sh.d.phi[i - 1]) != b) binfirst[b] = (unsigned short)i;
+        const int b = phase_bin(sh.d.pk[i].x);
+        if (i == 0 || phase_bin(sh.d.pk[i - 1].x) != b) binfirst[b] = (unsigned short)i;
     }
     __syncthreads();
     {
@@ -294,20 +313,35 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     }
     __syncthreads();
 
+    if (stop == 4) return;
     // queries: exact reference predicate over the <= 3-bin candidate window, smallest column wins
     int best[IPT];
+    int qi0[IPT], qi1[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {                      // all window bounds first: independent LDS reads
+        const bool act = k0 + i < W && vl[i] && pl[i] == pl[i];
+        const int b = act ? phase_bin(pl[i]) : 0;
+        qi0[i] = binfirst[b > 0 ? b - 1 : 0];
+        qi1[i] = act ? (int)binfirst[b + 2 < kBins ? b + 2 : kBins] : 0;
+    }
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         unsigned bk = 0xFFFFFFFFu;
-        if (k0 + i < W && vl[i] && pl[i] == pl[i]) {
-            const int b = phase_bin(pl[i]);
-            const int i0 = binfirst[b > 0 ? b - 1 : 0], i1 = binfirst[b + 2 < kBins ? b + 2 : kBins];
-            for (int idx = i0; idx < i1; idx++)
-                if (fabsf(pl[i] - sh.d.phi[idx]) < 0.1f) { const unsigned kk = sh.d.k[idx]; bk = kk < bk ? kk : bk; }
+        for (int idx = qi0[i]; idx < qi1[i]; idx += 4) {     // 4 candidates per round trip (8-byte (phi, k) pairs)
+            float2 c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = sh.d.pk[idx + q < N ? idx + q : N - 1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
+                bk = kk < bk ? kk : bk;
+            }
         }
         best[i] = bk == 0xFFFFFFFFu ? -1 : (int)bk;
     }
 
+    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
     // triangulate: gather the table values for all IPT pixels first (independent loads), then the f64 math
     float ulx[IPT], uly[IPT], urx[IPT];
     if (undL) {
@@ -342,7 +376,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
             const int i = i0 + q;
             float X[3] = {0.0f, 0.0f, 0.0f};
             if (best[i] >= 0) {
-                reproject(cal.Q, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
+                reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
                 if (cal.has_T) apply_T(cal.T, X);
             }
             out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
@@ -402,9 +436,10 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 {
     const float2 *undL = (const float2 *)undL_xy;
     if (algo != 1 && W <= 256 * 32) {
-        const int vec_ok = (W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
+        const char *dbg = getenv("SLR_DEBUG_K4_STOP");
+        const int vec_ok = ((dbg ? atoi(dbg) : 0) << 8) | (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
-                           ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0);
+                           ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
 #define SLR_SORTED(BLOCK, IPT)                                                                                     \
     hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
                        W, H, cal, vec_ok, undL, undRx, xyz, has, match_k)
@@ -526,7 +561,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
         float X[3] = {0.0f, 0.0f, 0.0f};
         int col = 0;
         if (m >= 0) {
-            reproject(cal.Q, (double)j, (double)row, (double)(j - m), X);   // reconstruct.cpp:570-582
+            reproject(cal.Q, cal.q_simple, (double)j, (double)row, (double)(j - m), X);   // reconstruct.cpp:570-582
             if (cal.has_T) apply_T(cal.T, X);
             if (color) col = ((int)whiteL[base + j] + (int)whiteR[base + m]) / 2;   // :598
         }

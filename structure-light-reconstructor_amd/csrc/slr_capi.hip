@@ -431,6 +431,11 @@ int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
     memcpy(c->cal.Q, cal->Q, sizeof(c->cal.Q));
     memcpy(c->cal.T, cal->T, sizeof(c->cal.T));
     c->cal.has_T = cal->has_T ? 1 : 0;
+    {
+        const double *Q = cal->Q;
+        c->cal.q_simple = (Q[0] == 1.0 && Q[1] == 0.0 && Q[2] == 0.0 && Q[4] == 0.0 && Q[5] == 1.0 && Q[6] == 0.0 &&
+                           Q[8] == 0.0 && Q[9] == 0.0 && Q[10] == 0.0 && Q[12] == 0.0 && Q[13] == 0.0) ? 1 : 0;
+    }
     c->has_calib = true;
     c->und_valid = false;
     return SLR_OK;

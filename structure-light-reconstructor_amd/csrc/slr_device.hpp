@@ -30,6 +30,7 @@ struct DevCalib {
     double Q[16];
     float T[12];
     int has_T;
+    int q_simple;                      // Q has cv::stereoRectify's zero/one pattern (kernels_match.hip reproject)
 };
 
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
