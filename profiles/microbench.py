@@ -69,4 +69,15 @@ if "--gray" in sys.argv:
     run("gray_rectify_decode", lambda: ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0, rectify_cam=0), 2 + 2 * ncol + 6 + 5.0)
     dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0) for cam in range(2)]
     run("ge_match", lambda: ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False), 23.0)
+if "--ray" in sys.argv:
+    # GRAY_ONLY: column + row bits, bucket sort, ray-ray triangulation (scan area = camera area)
+    sw, sh = W, H
+    calib2, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib2)
+    g2 = synth.render_gray_stack(W, H, sw, sh, seed=1234, device=dev, rows=True)
+    nc, nr = synth.gray_num_bits(sw), synth.gray_num_bits(sh)
+    torch.cuda.synchronize()
+    d2 = [ctx.gray_decode(g2[cam], nc, nr, 40, 0, sw, sh) for cam in range(2)]
+    run("gray_decode col+row", lambda: ctx.gray_decode(g2[0], nc, nr, 40, 0, sw, sh), 2 + 2 * (nc + nr) + 9.0)
+    run("ray (keys+sort+triangulate)", lambda: ctx.ray_triangulate(d2[0][0], d2[0][1], d2[0][2], d2[1][0], d2[1][1], d2[1][2], sw, sh), 31.0)
 ctx.close()

@@ -1,5 +1,5 @@
-// kernels_ray.hip -- GRAY_ONLY mode: K3' bucket scatter (as a stable key sort) and K6 ray-ray midpoint
-// triangulation with PointCloudImage sum/count accumulation; plus the PointCloudImage adaptors.
+// kernels_ray.hip -- GRAY_ONLY mode: K3' bucket scatter (counting sort by projector pixel) and K6 ray-ray
+// midpoint triangulation with PointCloudImage sum/count accumulation; plus the PointCloudImage adaptors.
 // gfx950 (MI355X) only.
 //
 // Reference behaviour restated (never copied):
@@ -12,7 +12,11 @@
 //
 // The reference pushes camera pixels into per-projector-pixel vectors while walking the camera image
 // column-major; a bucket's traversal order (c1 outer, c2 inner) fixes the f32 accumulation order.  Here the
-// same order is obtained by enumerating pixels in column-major order and STABLE radix-sorting by bucket key.
+// buckets are built as a counting sort -- histogram with returning atomics (rank inside the bucket, arbitrary
+// order), one exclusive scan over both cameras' histograms, scatter to offs[bucket]+rank -- and the push order is
+// restored inside each bucket by sorting its (few) pixels on (col,row), which IS the column-major walk order.
+// Buckets are numbered by their PointCloudImage cell  j*scan_w + i  (bucket ac = i*scan_h + j  <->  cell (j,i)),
+// so the triangulation kernel reads its ranges and writes its sums fully coalesced.
 #include "slr_device.hpp"
 
 #include <hipcub/hipcub.hpp>
@@ -20,48 +24,68 @@
 
 namespace slr {
 
-__global__ __launch_bounds__(256) void ray_keys_kernel(const int32_t *__restrict__ code_x, const int32_t *__restrict__ code_y,
-                                                       const uint8_t *__restrict__ valid, int W, int H, int scan_w,
-                                                       int scan_h, uint32_t *__restrict__ keys, uint32_t *__restrict__ items)
+constexpr uint32_t kNoBucket = 0xFFFFFFFFu;
+
+// pass 1: per pixel -> cell id (or kNoBucket) and its arrival rank inside that cell
+__global__ __launch_bounds__(256) void ray_count_kernel(const int32_t *__restrict__ code_x, const int32_t *__restrict__ code_y,
+                                                        const uint8_t *__restrict__ valid, unsigned npix, int scan_w,
+                                                        int scan_h, uint32_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ cell_of, uint32_t *__restrict__ rank_of)
 {
-    const unsigned total = (unsigned)W * (unsigned)H;
     const unsigned nb = (unsigned)scan_w * (unsigned)scan_h;
-    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
-        const unsigned col = t / H, row = t - col * H;         // column-major traversal (reconstruct.cpp:61-62)
-        const size_t o = (size_t)row * W + col;
-        unsigned key = nb;                                     // sentinel: sorts after every real bucket
-        if (valid[o]) {
-            const unsigned long long k = (unsigned long long)code_x[o] * (unsigned)scan_h + (unsigned)code_y[o];
-            if (k < nb) key = (unsigned)k;                     // Q9: key >= scan_w*scan_h is an OOB write -> dropped
+    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+        unsigned cell = kNoBucket, rank = 0;
+        if (valid[p]) {
+            const unsigned long long k = (unsigned long long)code_x[p] * (unsigned)scan_h + (unsigned)code_y[p];
+            if (k < nb) {                                      // Q9: ac >= scan_w*scan_h is an OOB write -> dropped
+                const unsigned i = (unsigned)k / (unsigned)scan_h, j = (unsigned)k - i * (unsigned)scan_h;
+                cell = j * (unsigned)scan_w + i;               // (a code_y >= scan_h aliases into column i+1.., as ac does)
+                rank = atomicAdd(&cnt[cell], 1u);
+            }
         }
-        keys[t] = key;
-        items[t] = col | (row << 16);
+        cell_of[p] = cell;
+        rank_of[p] = rank;
     }
 }
 
-hipError_t launch_ray_keys(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
-                           int scan_w, int scan_h, uint32_t *keys, uint32_t *items, hipStream_t s)
+// pass 2 (after the scan): item (col<<16 | row) -> items[offs[cell] + rank]
+__global__ __launch_bounds__(256) void ray_scatter_kernel(const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank_of,
+                                                          int W, const uint32_t *__restrict__ offs, uint32_t *__restrict__ items)
+{
+    const unsigned col = blockIdx.x * 256u + threadIdx.x, row = blockIdx.y;
+    if (col >= (unsigned)W) return;
+    const unsigned p = row * (unsigned)W + col;
+    const unsigned cell = cell_of[p];
+    if (cell != kNoBucket) items[offs[cell] + rank_of[p]] = (col << 16) | row;
+}
+
+hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
+                            int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of, hipStream_t s)
 {
     const size_t n = (size_t)W * H;
-    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(ray_keys_kernel, dim3(blocks), dim3(256), 0, s, code_x, code_y, valid, W, H, scan_w, scan_h,
-                       keys, items);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(ray_count_kernel, dim3(blocks), dim3(256), 0, s, code_x, code_y, valid, (unsigned)n, scan_w,
+                       scan_h, cnt, cell_of, rank_of);
     return hipGetLastError();
 }
 
-size_t ray_sort_temp_bytes(size_t n)
+hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, int W, int H, const uint32_t *offs,
+                              uint32_t *items, hipStream_t s)
+{
+    hipLaunchKernelGGL(ray_scatter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cell_of, rank_of, W, offs, items);
+    return hipGetLastError();
+}
+
+size_t ray_scan_temp_bytes(size_t n)
 {
     size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                       (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, 0, 32, 0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
     return bytes;
 }
 
-hipError_t launch_ray_sort(uint32_t *keys_in, uint32_t *keys_out, uint32_t *items_in, uint32_t *items_out, size_t n,
-                           int key_bits, void *temp, size_t temp_bytes, hipStream_t s)
+hipError_t launch_ray_scan(const uint32_t *cnt, uint32_t *offs, size_t n, void *temp, size_t temp_bytes, hipStream_t s)
 {
-    return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, items_in, items_out, (int)n, 0,
-                                              key_bits, s);
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cnt, offs, (int)n, s);
 }
 
 // ---- per camera-pixel unit ray (reconstruct.cpp:440-445) ----------------------------------------------
@@ -103,7 +127,7 @@ __device__ __forceinline__ void cam2world(const DevCamera &c, float p[3])
 __device__ __forceinline__ void pixel_ray(uint32_t item, const DevCamera &c, const float pos[3], float ray[3])
 {
     float ux, uy, pt[3];
-    undistort_point_ray((float)(item & 0xFFFFu), (float)(item >> 16), c, ux, uy);
+    undistort_point_ray((float)(item >> 16), (float)(item & 0xFFFFu), c, ux, uy);   // item = col<<16 | row
     pt[0] = (ux - c.ccx) / c.fcx;                  // utilities.cpp:51-53
     pt[1] = (uy - c.ccy) / c.fcy;
     pt[2] = 1.0f;
@@ -113,6 +137,30 @@ __device__ __forceinline__ void pixel_ray(uint32_t item, const DevCamera &c, con
     const double mag = (double)sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
     const float dv = (float)(0.000001 > mag ? 0.000001 : mag);
     ray[0] /= dv; ray[1] /= dv; ray[2] /= dv;
+}
+
+// per-(calibration, W, H) unit-ray tables: pixel_ray depends on the camera pixel only, so it is evaluated once
+// per calibration and cached by the context (like K4's undistortion tables), not once per pair per frame
+__global__ __launch_bounds__(256) void ray_table_kernel(DevCalib cal, int W, int H, float *__restrict__ raysL,
+                                                        float *__restrict__ raysR)
+{
+    float posL[3] = {0, 0, 0}, posR[3] = {0, 0, 0};
+    cam2world(cal.cam[0], posL);
+    cam2world(cal.cam[1], posR);
+    const unsigned col = blockIdx.x * 256u + threadIdx.x, row = blockIdx.y;
+    if (col >= (unsigned)W) return;
+    const size_t o = ((size_t)row * W + col) * 3;
+    float r[3];
+    pixel_ray((col << 16) | row, cal.cam[0], posL, r);
+    raysL[o] = r[0]; raysL[o + 1] = r[1]; raysL[o + 2] = r[2];
+    pixel_ray((col << 16) | row, cal.cam[1], posR, r);
+    raysR[o] = r[0]; raysR[o + 1] = r[1]; raysR[o + 2] = r[2];
+}
+
+hipError_t launch_ray_tables(const DevCalib &cal, int W, int H, float *raysL, float *raysR, hipStream_t s)
+{
+    hipLaunchKernelGGL(ray_table_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cal, W, H, raysL, raysR);
+    return hipGetLastError();
 }
 
 __device__ __forceinline__ float dot3(const float a[3], const float b[3])
@@ -144,40 +192,46 @@ __device__ __forceinline__ bool line_line(const float p1[3], const float v1[3], 
     return true;
 }
 
-__device__ __forceinline__ unsigned lower_bound_u32(const uint32_t *__restrict__ a, unsigned n, unsigned key)
+// restore the reference's push order inside one bucket: ascending (col,row) == ascending packed item
+__device__ __forceinline__ void sort_bucket(uint32_t *__restrict__ a, unsigned lo, unsigned hi)
 {
-    unsigned lo = 0, hi = n;
-    while (lo < hi) {
-        const unsigned mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    for (unsigned i = lo + 1; i < hi; i++) {
+        const uint32_t v = a[i];
+        unsigned j = i;
+        while (j > lo && a[j - 1] > v) { a[j] = a[j - 1]; j--; }
+        a[j] = v;
     }
-    return lo;
 }
 
-// one thread per projector pixel (bucket)
-__global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__restrict__ keysL, const uint32_t *__restrict__ itemsL,
-                                                              const uint32_t *__restrict__ keysR, const uint32_t *__restrict__ itemsR,
-                                                              unsigned n, DevCalib cal, int scan_w, int scan_h,
+__device__ __forceinline__ void load_ray(const float *__restrict__ rays, uint32_t item, int W, float ray[3])
+{
+    const size_t o = ((size_t)(item & 0xFFFFu) * W + (item >> 16)) * 3;     // item = col<<16 | row
+    ray[0] = rays[o]; ray[1] = rays[o + 1]; ray[2] = rays[o + 2];
+}
+
+// one thread per projector pixel (bucket == PointCloudImage cell j*scan_w + i)
+__global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__restrict__ offs, uint32_t *__restrict__ items,
+                                                              DevCalib cal, unsigned nb, int W,
+                                                              const float *__restrict__ raysL, const float *__restrict__ raysR,
                                                               float *__restrict__ xyz_sum, uint8_t *__restrict__ count)
 {
-    const unsigned nb = (unsigned)scan_w * (unsigned)scan_h;
     float posL[3] = {0, 0, 0}, posR[3] = {0, 0, 0};
     cam2world(cal.cam[0], posL);                   // reconstruct.cpp:239-240
     cam2world(cal.cam[1], posR);
     for (unsigned b = blockIdx.x * 256u + threadIdx.x; b < nb; b += gridDim.x * 256u) {
-        const unsigned i = b / scan_h, j = b - i * scan_h;   // bucket ac(i,j): projector column i, row j
-        const size_t o = (size_t)j * scan_w + i;             // addPoint(i_w=i, j_h=j) -> points[j][i]
         float sum[3] = {0.0f, 0.0f, 0.0f};
         unsigned num = 0;
-        const unsigned l0 = lower_bound_u32(keysL, n, b);
-        const unsigned r0 = lower_bound_u32(keysR, n, b);
-        if (l0 < n && keysL[l0] == b && r0 < n && keysR[r0] == b) {
-            for (unsigned c1 = l0; c1 < n && keysL[c1] == b; c1++) {
+        const unsigned l0 = offs[b], l1 = offs[b + 1];
+        const unsigned r0 = offs[nb + b], r1 = offs[nb + b + 1];
+        if (l1 > l0 && r1 > r0) {
+            if (l1 - l0 > 1) sort_bucket(items, l0, l1);
+            if (r1 - r0 > 1) sort_bucket(items, r0, r1);
+            for (unsigned c1 = l0; c1 < l1; c1++) {
                 float ray1[3];
-                pixel_ray(itemsL[c1], cal.cam[0], posL, ray1);
-                for (unsigned c2 = r0; c2 < n && keysR[c2] == b; c2++) {
+                load_ray(raysL, items[c1], W, ray1);
+                for (unsigned c2 = r0; c2 < r1; c2++) {
                     float ray2[3], X[3];
-                    pixel_ray(itemsR[c2], cal.cam[1], posR, ray2);
+                    load_ray(raysR, items[c2], W, ray2);
                     if (!line_line(posL, ray1, posR, ray2, X)) continue;
                     if (cal.has_T) {
                         float Y[3];
@@ -200,19 +254,19 @@ __global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__
                 }
             }
         }
-        xyz_sum[3 * o] = sum[0]; xyz_sum[3 * o + 1] = sum[1]; xyz_sum[3 * o + 2] = sum[2];
-        count[o] = (uint8_t)num;
+        xyz_sum[3 * (size_t)b] = sum[0]; xyz_sum[3 * (size_t)b + 1] = sum[1]; xyz_sum[3 * (size_t)b + 2] = sum[2];
+        count[b] = (uint8_t)num;
     }
 }
 
-hipError_t launch_ray_triangulate(const uint32_t *keysL, const uint32_t *itemsL, const uint32_t *keysR,
-                                  const uint32_t *itemsR, size_t n, const DevCalib &cal, int scan_w, int scan_h,
-                                  float *xyz_sum, uint8_t *count, hipStream_t s)
+hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const DevCalib &cal, int scan_w, int scan_h,
+                                  int W, const float *raysL, const float *raysR, float *xyz_sum, uint8_t *count,
+                                  hipStream_t s)
 {
     const size_t nb = (size_t)scan_w * scan_h;
-    const unsigned blocks = (unsigned)((nb + 255) / 256 < 8192 ? (nb + 255) / 256 : 8192);
-    hipLaunchKernelGGL(ray_triangulate_kernel, dim3(blocks), dim3(256), 0, s, keysL, itemsL, keysR, itemsR,
-                       (unsigned)n, cal, scan_w, scan_h, xyz_sum, count);
+    const unsigned blocks = (unsigned)((nb + 255) / 256 < 16384 ? (nb + 255) / 256 : 16384);
+    hipLaunchKernelGGL(ray_triangulate_kernel, dim3(blocks), dim3(256), 0, s, offs, items, cal, (unsigned)nb, W, raysL,
+                       raysR, xyz_sum, count);
     return hipGetLastError();
 }
 

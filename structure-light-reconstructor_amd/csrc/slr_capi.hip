@@ -20,16 +20,17 @@ namespace {
 
 const char *kKernelNames[K_COUNT] = {
     "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
-    "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_keys", "slr_ray_sort", "slr_ray_triangulate",
-    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table"};
+    "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
+    "slr_ray_triangulate",
+    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
     S_STAGE0 = 0,            // host-mode staging: 16 generic slots
     S_PHASE_L = 16, S_VALID_L, S_PHASE_R, S_VALID_R,
     S_CODEX_L, S_CODEY_L, S_CODEX_R, S_CODEY_R,
-    S_KEYS_A, S_KEYS_B, S_ITEMS_A, S_ITEMS_B, S_KEYS_L, S_ITEMS_L, S_SORT_TMP,
-    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R,
+    S_RAY_CELL, S_RAY_CELL2, S_RAY_RANK, S_RAY_CNT, S_RAY_OFFS, S_RAY_ITEMS, S_SCAN_TMP,
+    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R, S_RAYS_L, S_RAYS_R,
     S_COUNT
 };
 
@@ -54,6 +55,8 @@ struct slr_ctx {
     int opt_rect_algo = 0;         // SLR_OPT_RECT_DECODE_ALGO
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
+    bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
+    int rays_w = 0, rays_h = 0;
     void *scratch[S_COUNT] = {};
     size_t scratch_cap[S_COUNT] = {};
     // profiler
@@ -285,31 +288,41 @@ int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *
 {
     const size_t n = (size_t)W * H;
     const unsigned long long nb = (unsigned long long)scan_w * scan_h;
-    if (nb >= 0xFFFFFFFFull) return fail(c, SLR_ERR_UNSUPPORTED, "scan_w*scan_h too large");
-    int key_bits = 1;
-    while ((1ull << key_bits) <= nb) key_bits++;
-    void *ka, *kb, *ia, *ib, *kl, *il, *tmp;
-    const size_t tb = ray_sort_temp_bytes(n);
-    SLR_TRY(get_scratch(c, S_KEYS_A, n * 4, &ka));
-    SLR_TRY(get_scratch(c, S_KEYS_B, n * 4, &kb));
-    SLR_TRY(get_scratch(c, S_ITEMS_A, n * 4, &ia));
-    SLR_TRY(get_scratch(c, S_ITEMS_B, n * 4, &ib));
-    SLR_TRY(get_scratch(c, S_KEYS_L, n * 4, &kl));
-    SLR_TRY(get_scratch(c, S_ITEMS_L, n * 4, &il));
-    SLR_TRY(get_scratch(c, S_SORT_TMP, tb, &tmp));
-    // left camera -> (kl, il)
-    { ProfScope ps(c, K_RAY_KEYS);
-      SLR_HIP(c, launch_ray_keys(cxL, cyL, vL, W, H, scan_w, scan_h, (uint32_t *)ka, (uint32_t *)ia, c->stream)); }
-    { ProfScope ps(c, K_RAY_SORT);
-      SLR_HIP(c, launch_ray_sort((uint32_t *)ka, (uint32_t *)kl, (uint32_t *)ia, (uint32_t *)il, n, key_bits, tmp, tb, c->stream)); }
-    // right camera -> (kb, ib)
-    { ProfScope ps(c, K_RAY_KEYS);
-      SLR_HIP(c, launch_ray_keys(cxR, cyR, vR, W, H, scan_w, scan_h, (uint32_t *)ka, (uint32_t *)ia, c->stream)); }
-    { ProfScope ps(c, K_RAY_SORT);
-      SLR_HIP(c, launch_ray_sort((uint32_t *)ka, (uint32_t *)kb, (uint32_t *)ia, (uint32_t *)ib, n, key_bits, tmp, tb, c->stream)); }
+    if (nb >= (1ull << 30)) return fail(c, SLR_ERR_UNSUPPORTED, "scan_w*scan_h too large");
+    const size_t ncell = 2 * (size_t)nb + 1;                 // left cells, right cells, end sentinel
+    void *cell, *rank, *cnt, *offs, *items, *tmp;
+    const size_t tb = ray_scan_temp_bytes(ncell);
+    SLR_TRY(get_scratch(c, S_RAY_CELL, n * 4, &cell));
+    SLR_TRY(get_scratch(c, S_RAY_RANK, n * 8, &rank));       // [2][n]
+    SLR_TRY(get_scratch(c, S_RAY_CNT, ncell * 4, &cnt));
+    SLR_TRY(get_scratch(c, S_RAY_OFFS, ncell * 4, &offs));
+    SLR_TRY(get_scratch(c, S_RAY_ITEMS, 2 * n * 4, &items));
+    SLR_TRY(get_scratch(c, S_SCAN_TMP, tb, &tmp));
+    void *raysL, *raysR;
+    if (c->scratch_cap[S_RAYS_L] < n * 12 || c->scratch_cap[S_RAYS_R] < n * 12) c->rays_valid = false;   // will realloc
+    SLR_TRY(get_scratch(c, S_RAYS_L, n * 12, &raysL));
+    SLR_TRY(get_scratch(c, S_RAYS_R, n * 12, &raysR));
+    if (!c->rays_valid || c->rays_w != W || c->rays_h != H) {
+        ProfScope ps(c, K_RAY_TABLE);
+        SLR_HIP(c, launch_ray_tables(c->cal, W, H, (float *)raysL, (float *)raysR, c->stream));
+        c->rays_valid = true; c->rays_w = W; c->rays_h = H;
+    }
+    uint32_t *cellL = (uint32_t *)cell, *rankL = (uint32_t *)rank, *rankR = rankL + n;
+    SLR_HIP(c, hipMemsetAsync(cnt, 0, ncell * 4, c->stream));
+    void *cell2;
+    SLR_TRY(get_scratch(c, S_RAY_CELL2, n * 4, &cell2));
+    uint32_t *cellR = (uint32_t *)cell2;
+    { ProfScope ps(c, K_RAY_COUNT);
+      SLR_HIP(c, launch_ray_count(cxL, cyL, vL, W, H, scan_w, scan_h, (uint32_t *)cnt, cellL, rankL, c->stream));
+      SLR_HIP(c, launch_ray_count(cxR, cyR, vR, W, H, scan_w, scan_h, (uint32_t *)cnt + nb, cellR, rankR, c->stream)); }
+    { ProfScope ps(c, K_RAY_SCAN);
+      SLR_HIP(c, launch_ray_scan((const uint32_t *)cnt, (uint32_t *)offs, ncell, tmp, tb, c->stream)); }
+    { ProfScope ps(c, K_RAY_SCATTER);
+      SLR_HIP(c, launch_ray_scatter(cellL, rankL, W, H, (const uint32_t *)offs, (uint32_t *)items, c->stream));
+      SLR_HIP(c, launch_ray_scatter(cellR, rankR, W, H, (const uint32_t *)offs + nb, (uint32_t *)items, c->stream)); }
     { ProfScope ps(c, K_RAY_TRI);
-      SLR_HIP(c, launch_ray_triangulate((uint32_t *)kl, (uint32_t *)il, (uint32_t *)kb, (uint32_t *)ib, n, c->cal,
-                                        scan_w, scan_h, xyz_sum, count, c->stream)); }
+      SLR_HIP(c, launch_ray_triangulate((const uint32_t *)offs, (uint32_t *)items, c->cal, scan_w, scan_h, W,
+                                        (const float *)raysL, (const float *)raysR, xyz_sum, count, c->stream)); }
     return SLR_OK;
 }
 
@@ -438,6 +451,7 @@ int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
     }
     c->has_calib = true;
     c->und_valid = false;
+    c->rays_valid = false;
     return SLR_OK;
 }
 

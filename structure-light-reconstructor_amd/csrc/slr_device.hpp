@@ -36,7 +36,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_KEYS, K_RAY_SORT, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_COUNT
 };
 
 // ---- launchers (defined in the .hip files; all asynchronous on `s`) -----------------------------------
@@ -73,15 +73,19 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
                            const uint8_t *whiteL, const uint8_t *whiteR,
                            float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s);
 
-// GRAY_ONLY: keys/items in the reference's column-major traversal order, stable sort, per-bucket pairs
-size_t     ray_sort_temp_bytes(size_t n);
-hipError_t launch_ray_keys(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
-                           int scan_w, int scan_h, uint32_t *keys, uint32_t *items, hipStream_t s);
-hipError_t launch_ray_sort(uint32_t *keys_in, uint32_t *keys_out, uint32_t *items_in, uint32_t *items_out,
-                           size_t n, int key_bits, void *temp, size_t temp_bytes, hipStream_t s);
-hipError_t launch_ray_triangulate(const uint32_t *keysL, const uint32_t *itemsL, const uint32_t *keysR,
-                                  const uint32_t *itemsR, size_t n, const DevCalib &cal, int scan_w,
-                                  int scan_h, float *xyz_sum, uint8_t *count, hipStream_t s);
+// GRAY_ONLY: counting sort of camera pixels by projector cell (both cameras share one histogram / offsets
+// array: left cells [0,nb), right cells [nb,2nb), +1 pad), then one thread per cell
+size_t     ray_scan_temp_bytes(size_t n);
+hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
+                            int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of, hipStream_t s);
+hipError_t launch_ray_scan(const uint32_t *cnt, uint32_t *offs, size_t n, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, int W, int H, const uint32_t *offs,
+                              uint32_t *items, hipStream_t s);
+// unit view rays of every camera pixel, [H][W][3] per camera (calibration constants, cached by the context)
+hipError_t launch_ray_tables(const DevCalib &cal, int W, int H, float *raysL, float *raysR, hipStream_t s);
+hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const DevCalib &cal, int scan_w, int scan_h,
+                                  int W, const float *raysL, const float *raysR, float *xyz_sum, uint8_t *count,
+                                  hipStream_t s);
 
 hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8_t *color, int W, int H,
                                int scan_w, int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color,
