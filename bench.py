@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--profile", type=int, default=1, help="bracket every kernel with HIP events (roofline)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU triangulation sample (0 = auto)")
+    ap.add_argument("--host-io", type=int, default=1,
+                    help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
     return ap.parse_args()
 
 
@@ -86,6 +88,39 @@ def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
                   "rows (%.1f s), scaled to the frame; single thread, gcc -O2" % (W, H, t_dec, rows, H, t_tri),
         "host_cpus": os.cpu_count(),
     }
+
+
+def copy_ceiling(torch, dev, stream):
+    """On-box streaming ceiling: a 1 GiB device-to-device copy on the bench stream, read+write bytes / time."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        b.copy_(a)
+        e0.record(stream)
+        for _ in range(5):
+            b.copy_(a)
+        e1.record(stream)
+    e1.synchronize()
+    return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def host_io_rate(np, torch, ctx, stack, W, H, rectify):
+    """The drop-in boundary with host buffers (what a cv::Mat caller hands over): H2D of 2x14 planes, the path, D2H of
+    XYZ + mask, synchronous.  Pinned host memory, 3 frames after one warm-up."""
+    host = stack[0].cpu().pin_memory()
+    L, R = host[0].numpy(), host[1].numpy()
+    xyz = torch.empty((H, W, 3), dtype=torch.float32).pin_memory().numpy()
+    has = torch.empty((H, W), dtype=torch.uint8).pin_memory().numpy()
+    ctx.reconstruct_mf(L, R, BLACK_THR, rectify, xyz=xyz, has=has)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.reconstruct_mf(L, R, BLACK_THR, rectify, xyz=xyz, has=has)
+    dt = (time.perf_counter() - t0) / 3
+    return {"value": round(W * H / dt / 1e6, 1), "unit": "Mpix/s", "ms_per_frame": round(dt * 1e3, 3),
+            "bytes_in": int(host.numel()), "bytes_out": int(xyz.nbytes + has.nbytes),
+            "note": "slr_reconstruct_mf with SLR_MEM_HOST pinned buffers: H2D + kernels + D2H, synchronous, no overlap"}
 
 
 def main():
@@ -239,6 +274,15 @@ def main():
                            "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         ctx.profile_enable(False)
 
+    ceiling = hostio = None
+    if rank == 0:
+        ceiling = copy_ceiling(torch, dev, compute)
+        if roofline and roofline.get("achieved"):
+            roofline["copy_ceiling"] = round(ceiling, 1)
+            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / ceiling, 4)
+        if world == 1 and args.host_io:
+            hostio = host_io_rate(np, torch, ctx, stack, W, H, bool(args.rectify))
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline:
         rows = args.cpu_rows or H          # whole frame: ~8 s of single-thread CPU work at 4096x3000
@@ -259,6 +303,7 @@ def main():
                            (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else ""))},
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4),
             "roofline": roofline, "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
+            "host_buffers_pcie_inclusive": hostio,
         }
         print(json.dumps(out))
     if world > 1:

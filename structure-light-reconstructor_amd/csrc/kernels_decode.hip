@@ -63,7 +63,13 @@ __device__ __forceinline__ float heterodyne(float P0f, float P1f, float P2f)
     const float P12 = (float)((P0 > P1) ? (P0 - P1) : (P0 - P1 + two_pi));
     const float P23 = (float)((P1 > P2) ? (P1 - P2) : (P1 - P2 + two_pi));
     const float P123 = (P12 > P23) ? (P12 - P23) : (P12 - P23 + kTwoPI);
-    return P123 / kTwoPI * 255;
+    // P123 / (2*PI) * 255 (:268).  The correctly rounded quotient by a constant without the 10-instruction IEEE division
+    // sequence (Markstein): q = x*rc, r = fma(-q, c, x) (exact), q' = fma(r, rc, q) == RN(x / c) when rc = RN(1/c) --
+    // checked against x / c for every finite f32 x with 1e-30 <= |x| <= 1e30 (P123 is in (0, 4*PI]).
+    constexpr float rc = 1.0f / kTwoPI;
+    const float q = P123 * rc;
+    const float r = __builtin_fmaf(-q, kTwoPI, P123);
+    return __builtin_fmaf(r, rc, q) * 255;
 }
 
 // one pixel of K2: g[0]=white g[1]=black g[2..13] fringes
@@ -504,6 +510,29 @@ __device__ __forceinline__ TileTaps<NP> tile_taps(const Tap &t, int x0, int y0, 
     return k;
 }
 
+// the same state straight from one map entry (xy = x | y << 16, frac = fy << 5 | fx), without the generic Tap:
+// ~20 VALU instructions.  Lanes outside the image (inb == false) and footprints completely outside the source get
+// zero weights and address 0, i.e. sample 0 (BORDER_CONSTANT).
+template <int NP>
+__device__ __forceinline__ TileTaps<NP> tile_taps_map(unsigned xy, unsigned frac, bool inb, int W, int H, int x0, int y0,
+                                                      int BW4)
+{
+    TileTaps<NP> k;
+    const int sx = (int)(short)(xy & 0xFFFFu), sy = (int)xy >> 16;
+    // sx >= W || sx + 1 < 0  <=>  (unsigned)(sx + 1) > (unsigned)W   (same for y)
+    const bool out = !inb || (unsigned)(sx + 1) > (unsigned)W || (unsigned)(sy + 1) > (unsigned)H;
+    const unsigned fx = frac & 31u, fy = (frac >> 5) & 31u;
+    const unsigned wxp = out ? 0u : __umul24(fx, 0xFFFFu) + 32u;          // (32 - fx) | fx << 16
+    const unsigned w0 = __umul24(wxp, 32u - fy), w1 = __umul24(wxp, fy);  // both halves <= 1024: no carry across
+    const int bx = out ? 0 : sx - x0, r0 = out ? 0 : sy - y0;
+    k.a0 = __mul24(__mul24(r0, BW4) + (bx >> 2), NP * 4);
+    k.a1 = k.a0 + __mul24(BW4, NP * 4);
+    k.sel = __umul24((unsigned)bx & 3u, 0x10001u) + 0x0C010C00u;          // bytes (sh, 0, sh+1, 0)
+    k.w0 = __builtin_bit_cast(u16x2, w0);
+    k.w1 = __builtin_bit_cast(u16x2, w1);
+    return k;
+}
+
 // blended sample of plane p: LDS reads are (base + immediate), 2 perms, 2 dot2, 1 shift
 template <int NP>
 __device__ __forceinline__ int tile_sample(const uint8_t *tile, const TileTaps<NP> &k, int p)
@@ -566,35 +595,39 @@ __global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(MfPlanes pl, in
         __syncthreads();
     }
     // ---- per pass: 14 blended samples (from LDS, or by direct gather when the box did not fit), decode, store ----
+    const unsigned lane31 = (unsigned)lane & 31u;
 #pragma unroll 1
     for (int q = 0; q < 4; q++) {
         const int row = ty * kTileH + 4 * q + wv;
-        Tap t = make_tap(0, 0, 0, pitch, W, H);
-        t.kind = 1;
         const bool inb = row < H && col < W;
         const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+        // 32-bit byte offsets on scalar bases (the launcher guarantees W*H < 2^30)
+        unsigned xy = 0, fr = 0;
         if (inb) {
-            const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * (size_t)m);
-            t = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
+            xy = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+            fr = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
         }
         int gpx[NP];
         if (fits) {
-            const TileTaps<NP> k = tile_taps<NP>(t, x0, y0, BW4);
+            const TileTaps<NP> k = tile_taps_map<NP>(xy, fr, inb, W, H, x0, y0, BW4);
 #pragma unroll
             for (int p = 0; p < NP; p++) gpx[p] = tile_sample<NP>(tile, k, p);
         } else {
+            Tap t = make_tap((int)(short)(xy & 0xFFFFu), (int)xy >> 16, fr, pitch, W, H);
+            if (!inb) t.kind = 1;
 #pragma unroll 1
             for (int p = 0; p < NP; p++) gpx[p] = any ? sample(pl.p[p], pitch, W, H, t) : 0;
         }
         int v;
         const float ph = mf_pixel(gpx, black_thr, lut, v);
-        // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane
-        unsigned vw = (unsigned)v;
-        vw |= (unsigned)__shfl_down(v, 1) << 8;
-        vw |= (unsigned)__shfl_down(v, 2) << 16;
-        vw |= (unsigned)__shfl_down(v, 3) << 24;
+        // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane: the wave's ballot, this lane's
+        // nibble of it, and a multiply that spreads 4 bits into 4 bytes (bit i -> bit 8i; the partial products of
+        // 1 + 2^7 + 2^14 + 2^21 do not overlap)
+        const unsigned long long bal = __ballot(v != 0);
+        const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+        const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
         if (inb) {
-            __builtin_nontemporal_store(ph, phase + m);
+            __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
             if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
         }
     }
@@ -613,7 +646,8 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
-    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0)) {
+    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
+        (long long)W * H < (1ll << 30)) {
         bool aligned = pitch % 4 == 0;
         for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
