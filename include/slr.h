@@ -82,7 +82,8 @@ int          slr_set_stream(slr_ctx *ctx, void *hip_stream);     /* borrow a cal
 int          slr_synchronize(slr_ctx *ctx);
 const char  *slr_last_error(const slr_ctx *ctx);
 /* tuning / test knobs.  SLR_OPT_MF_MATCH_ALGO: 0 = auto, 1 = linear LDS sweep (the literal form of
- * mfreconstruct.cpp:289-331), 2 = indexed exact form (sorted distinct phases).  Both give identical results. */
+ * mfreconstruct.cpp:289-331), 2 = indexed exact form built by an LDS radix sort (distinct phases), 3 = indexed exact form
+ * built by an LDS counting sort (the default).  All give identical results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2

@@ -56,7 +56,10 @@ ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 0)
 ctx.mf_decode(st[1], 40, rectify_cam=1, phase=ph[1], valid=vd[1])
 tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
 run("remap", lambda: ctx.remap_u8(0, st[0, 3], out=tmp), 8.0)
-run("mf_match indexed", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0)
+run("mf_match binned", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0)
+ctx.set_option(cap.OPT_MF_MATCH_ALGO, 2)
+run("mf_match sorted", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0)
+ctx.set_option(cap.OPT_MF_MATCH_ALGO, 0)
 if "--sweep" in sys.argv:
     ctx.set_option(cap.OPT_MF_MATCH_ALGO, 1)
     run("mf_match sweep", lambda: ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False), 23.0, warm=0)

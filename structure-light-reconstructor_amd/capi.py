@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libslr_hip.so")
 MF_PLANES = 14
 MAX_GRAY_BITS = 16
 MEM_HOST, MEM_DEVICE = 0, 1
-OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (sorted distinct phases)
+OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort)
 OPT_RECT_DECODE_ALGO = 3       # 0 LDS-tiled fused rectify+decode, 1 direct gather
 OPT_MF_DECODE_VEC = 2          # 0 auto, 4 / 8 / 16 pixels per thread in the unfused K2 kernel
 

@@ -199,6 +199,214 @@ __device__ __forceinline__ void load_u8_blocked(const uint8_t *__restrict__ p, i
     }
 }
 
+// the common tail of the indexed forms: table gathers for all IPT pixels first (independent loads), then the f64
+// reprojection and wide stores (mfreconstruct.cpp:297-326)
+template <int IPT>
+__device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0, int row, int W, bool vec,
+                                        const DevCalib &cal, const float2 *__restrict__ undL,
+                                        const float *__restrict__ undRx, float *__restrict__ xyz,
+                                        uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    // triangulate: gather the table values for all IPT pixels first (independent loads), then the f64 math
+    float ulx[IPT], uly[IPT], urx[IPT];
+    if (undL) {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            ulx[i] = uly[i] = urx[i] = 0.0f;
+            if (best[i] >= 0) {
+                const float2 u = undL[base + k0 + i];
+                ulx[i] = u.x; uly[i] = u.y;
+                urx[i] = undRx[base + best[i]];
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < IPT; i++) {
+            ulx[i] = uly[i] = urx[i] = 0.0f;
+            if (best[i] >= 0) {
+                float ury;
+                undistort_point((float)(k0 + i), (float)row, cal.cam[0], ulx[i], uly[i]);
+                undistort_point((float)best[i], (float)row, cal.cam[1], urx[i], ury);
+            }
+        }
+    }
+    const bool full = vec && IPT >= 4 && k0 + IPT <= W;
+#pragma unroll
+    for (int i0 = 0; i0 < IPT; i0 += 4) {
+        float out[12];
+        unsigned hw = 0;
+        int mk[4];
+#pragma unroll
+        for (int q = 0; q < 4 && i0 + q < IPT; q++) {
+            const int i = i0 + q;
+            float X[3] = {0.0f, 0.0f, 0.0f};
+            if (best[i] >= 0) {
+                reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
+                if (cal.has_T) apply_T(cal.T, X);
+            }
+            out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
+            hw |= (best[i] >= 0 ? 1u : 0u) << (8 * q);
+            mk[q] = best[i];
+        }
+        const size_t o = base + k0 + i0;
+        if (full) {
+            float4 *dst = reinterpret_cast<float4 *>(xyz + 3 * o);
+            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
+            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
+            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
+            *reinterpret_cast<unsigned *>(has + o) = hw;
+            if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(mk[0], mk[1], mk[2], mk[3]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4 && i0 + q < IPT; q++) {
+                if (k0 + i0 + q >= W) break;
+                xyz[3 * (o + q)] = out[3 * q]; xyz[3 * (o + q) + 1] = out[3 * q + 1]; xyz[3 * (o + q) + 2] = out[3 * q + 2];
+                has[o + q] = (uint8_t)((hw >> (8 * q)) & 1u);
+                if (match_k) match_k[o + q] = mk[q];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4 (exact indexed form, hash + counting-sort build).  Same candidate-window query as the sorted form below, but
+// the per-bin lists of DISTINCT right phases are built without a sort:
+//   A. the reference's phases are heavily quantised (atan of an INTEGER quotient, Q1): a 4096-pixel row holds only a
+//      few hundred distinct values.  An LDS open-addressing hash table keyed by the phase bits keeps, per distinct
+//      value, its smallest column (atomicCAS claims the slot, atomicMin on the column) -- "first k ascending" can only
+//      ever pick that one;
+//   B. the pixels that ARE their value's smallest column are the representatives; they are counting-sorted by
+//      0.25-wide phase bin: LDS histogram with returning atomics (bin, rank), one block scan over the 4096 bins,
+//      scatter of (phi, k) to start[bin] + rank.  The order inside a bin is arbitrary, which is fine because the
+//      query takes the MIN column over all pairs that satisfy the predicate.
+// The table's LDS is dead once the representatives are known and is reused for the bin index and the pairs.
+// ------------------------------------------------------------------------------------------------------
+template <int BLOCK, int IPT>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binned_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                                const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                                int W, int H, DevCalib cal, int vec_ok,
+                                                                const float2 *__restrict__ undL, const float *__restrict__ undRx,
+                                                                float *__restrict__ xyz,
+                                                                uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int N = BLOCK * IPT;
+    constexpr int TS = 2 * N;                            // hash slots (power of two, load factor <= 0.5)
+    constexpr int kPer = kBins / BLOCK;                  // bins per thread (kBins is a multiple of BLOCK)
+    constexpr unsigned kEmpty = 0xFFFFFFFFu;             // a NaN pattern: never a candidate's phase bits
+    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
+    __shared__ union {
+        struct { unsigned key[TS]; unsigned mink[TS]; } t;               // phase bits -> smallest column
+        struct { float2 pk[N]; unsigned binstart[kBins + 1]; } b;        // (phi, column as bits) grouped by bin; bin index
+    } sh;
+    __shared__ typename ScanU::TempStorage scan_tmp;
+
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)row * W;
+    const int k0 = tid * IPT;
+    const bool vec = (vec_ok & 1) != 0;
+    const int stop = vec_ok >> 8;                        // debug: leave after phase N (SLR_DEBUG_K4_STOP), 0 = run all
+
+    float pr[IPT], pl[IPT];
+    unsigned vr[IPT], vl[IPT];
+    load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
+    load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+    load_f32_blocked<IPT>(phaseL + base, k0, W, vec, pl);
+    load_u8_blocked<IPT>(validL + base, k0, W, vec, vl);
+#pragma unroll
+    for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
+    __syncthreads();
+    if (stop == 1) return;
+
+    // A. distinct values and their smallest column
+    unsigned slot[IPT];                                  // hash slot of this pixel's value; kEmpty = not a candidate
+    bool prev_ok = false;
+    unsigned prev_bits = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const bool ok = (k0 + i < W) && vr[i] && (pr[i] == pr[i]);   // NaN can never satisfy the predicate
+        const unsigned bits = __float_as_uint(pr[i]);
+        const bool dup = prev_ok && ok && bits == prev_bits;         // same value one column to the left (flat regions)
+        slot[i] = kEmpty;
+        if (ok && !dup) {
+            unsigned h = (bits * 2654435761u) >> (32 - __builtin_ctz(TS));
+            for (;;) {
+                const unsigned old = atomicCAS(&sh.t.key[h], kEmpty, bits);
+                if (old == kEmpty || old == bits) break;
+                h = (h + 1) & (TS - 1);
+            }
+            atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
+            slot[i] = h;
+        }
+        prev_ok = ok; prev_bits = bits;
+    }
+    __syncthreads();
+    unsigned repmask = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (slot[i] != kEmpty && sh.t.mink[slot[i]] == (unsigned)(k0 + i)) repmask |= 1u << i;
+    __syncthreads();                                     // the table is dead from here on
+    if (stop == 2) return;
+
+    // B. counting sort of the representatives by phase bin
+#pragma unroll
+    for (int q = 0; q < kPer; q++) sh.b.binstart[tid + q * BLOCK] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if (repmask & (1u << i)) {
+            const unsigned b = (unsigned)phase_bin(pr[i]);
+            slot[i] = (b << 16) | atomicAdd(&sh.b.binstart[b], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        unsigned c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = sh.b.binstart[tid * kPer + q]; sum += c[q]; }
+        unsigned excl, total;
+        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { sh.b.binstart[tid * kPer + q] = excl; excl += c[q]; }   // own bins only: no hazard
+        if (tid == 0) sh.b.binstart[kBins] = total;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (repmask & (1u << i))
+            sh.b.pk[sh.b.binstart[slot[i] >> 16] + (slot[i] & 0xFFFFu)] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+    __syncthreads();
+    if (stop == 4) return;
+
+    // queries: exact reference predicate over the <= 3-bin candidate window, smallest column wins
+    int best[IPT];
+    int qi0[IPT], qi1[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {                      // all window bounds first: independent LDS reads
+        const bool act = k0 + i < W && vl[i] && pl[i] == pl[i];
+        const int b = act ? phase_bin(pl[i]) : 0;
+        qi0[i] = (int)sh.b.binstart[b > 0 ? b - 1 : 0];
+        qi1[i] = act ? (int)sh.b.binstart[b + 2 < kBins ? b + 2 : kBins] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        unsigned bk = 0xFFFFFFFFu;
+        for (int idx = qi0[i]; idx < qi1[i]; idx += 4) {     // 4 candidates per round trip (8-byte (phi, k) pairs)
+            float2 c[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = sh.b.pk[idx + q < N ? idx + q : N - 1];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
+                bk = kk < bk ? kk : bk;
+            }
+        }
+        best[i] = bk == 0xFFFFFFFFu ? -1 : (int)bk;
+    }
+    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
+    k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
+}
+
 template <int BLOCK, int IPT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
@@ -342,65 +550,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     }
 
     if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
-    // triangulate: gather the table values for all IPT pixels first (independent loads), then the f64 math
-    float ulx[IPT], uly[IPT], urx[IPT];
-    if (undL) {
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {
-            ulx[i] = uly[i] = urx[i] = 0.0f;
-            if (best[i] >= 0) {
-                const float2 u = undL[base + k0 + i];
-                ulx[i] = u.x; uly[i] = u.y;
-                urx[i] = undRx[base + best[i]];
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < IPT; i++) {
-            ulx[i] = uly[i] = urx[i] = 0.0f;
-            if (best[i] >= 0) {
-                float ury;
-                undistort_point((float)(k0 + i), (float)row, cal.cam[0], ulx[i], uly[i]);
-                undistort_point((float)best[i], (float)row, cal.cam[1], urx[i], ury);
-            }
-        }
-    }
-    const bool full = vec && IPT >= 4 && k0 + IPT <= W;
-#pragma unroll
-    for (int i0 = 0; i0 < IPT; i0 += 4) {
-        float out[12];
-        unsigned hw = 0;
-        int mk[4];
-#pragma unroll
-        for (int q = 0; q < 4 && i0 + q < IPT; q++) {
-            const int i = i0 + q;
-            float X[3] = {0.0f, 0.0f, 0.0f};
-            if (best[i] >= 0) {
-                reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
-                if (cal.has_T) apply_T(cal.T, X);
-            }
-            out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
-            hw |= (best[i] >= 0 ? 1u : 0u) << (8 * q);
-            mk[q] = best[i];
-        }
-        const size_t o = base + k0 + i0;
-        if (full) {
-            float4 *dst = reinterpret_cast<float4 *>(xyz + 3 * o);
-            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
-            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
-            *reinterpret_cast<unsigned *>(has + o) = hw;
-            if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(mk[0], mk[1], mk[2], mk[3]);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4 && i0 + q < IPT; q++) {
-                if (k0 + i0 + q >= W) break;
-                xyz[3 * (o + q)] = out[3 * q]; xyz[3 * (o + q) + 1] = out[3 * q + 1]; xyz[3 * (o + q) + 2] = out[3 * q + 2];
-                has[o + q] = (uint8_t)((hw >> (8 * q)) & 1u);
-                if (match_k) match_k[o + q] = mk[q];
-            }
-        }
-    }
+    k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
 }
 
 
@@ -429,7 +579,8 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
     return hipGetLastError();
 }
 
-// algo: 0 = auto (indexed form when the row fits 256 x 32 items, else the sweep), 1 = sweep, 2 = indexed
+// algo: 0 = auto (binned indexed form when the row fits 8192 items, else the sweep), 1 = sweep, 2 = sorted indexed form,
+// 3 = binned indexed form
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
                            int algo, const float *undL_xy, const float *undRx, hipStream_t s)
@@ -441,8 +592,14 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
                            ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
 #define SLR_SORTED(BLOCK, IPT)                                                                                     \
-    hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
-                       W, H, cal, vec_ok, undL, undRx, xyz, has, match_k)
+    do {                                                                                                           \
+        if (algo == 2)                                                                                             \
+            hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
+                               phaseR, validR, W, H, cal, vec_ok, undL, undRx, xyz, has, match_k);                 \
+        else                                                                                                       \
+            hipLaunchKernelGGL((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
+                               phaseR, validR, W, H, cal, vec_ok, undL, undRx, xyz, has, match_k);                 \
+    } while (0)
         // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
         if (W <= 256) SLR_SORTED(256, 1);
         else if (W <= 512) SLR_SORTED(256, 2);

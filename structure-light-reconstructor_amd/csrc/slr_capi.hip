@@ -810,7 +810,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
     if (!c) return SLR_ERR_INVALID_ARG;
     switch (option) {
         case SLR_OPT_MF_MATCH_ALGO:
-            if (value < 0 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0, 1 or 2");
+            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..3");
             c->opt_mf_match_algo = value;
             return SLR_OK;
         case SLR_OPT_MF_DECODE_VEC:

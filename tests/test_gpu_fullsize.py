@@ -49,13 +49,14 @@ def test_fullsize_mf_match_forms_agree_and_oracle_rows(ctx, oracle, scene, slr):
         ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
     dec = [ctx.mf_decode(st[cam], BLACK, rectify_cam=cam) for cam in range(2)]
     out = {}
-    for algo in (2, 1):
+    for algo in (3, 2, 1):
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         out[algo] = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
     ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
     ctx.synchronize()
-    for a, b in zip(out[1], out[2]):
-        assert torch.equal(a, b)                       # whole frame: indexed == literal sweep, bit for bit
+    for algo in (2, 3):
+        for a, b in zip(out[1], out[algo]):
+            assert torch.equal(a, b)                   # whole frame: indexed forms == literal sweep, bit for bit
     xyz, has, mk = [np_of(t) for t in out[2]]
     assert 0.05 < has.mean() < 1.0
     camL, camR, Q, T = calib_parts(oracle, calib)

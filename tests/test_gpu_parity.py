@@ -323,11 +323,11 @@ def test_mf_match_sweep_and_indexed_forms_agree(ctx, oracle, synth, slr, W):
     vL[11] = 0
     exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
     out = {}
-    for algo in (1, 2, 0):
+    for algo in (1, 2, 3, 0):
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         out[algo] = ctx.mf_triangulate(phL, vL, phR, vR)
     ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
-    for algo in (1, 2, 0):
+    for algo in (1, 2, 3, 0):
         xyz, has, mk = out[algo]
         assert bits_equal(mk, emk), "algo %d" % algo
         assert bits_equal(has, ehas) and bits_equal(xyz, exyz), "algo %d" % algo
