@@ -87,7 +87,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2
-/* SLR_OPT_RECT_DECODE_ALGO: fused rectify+decode form: 0 = LDS-tiled (default), 1 = direct gather (identical results) */
+/* SLR_OPT_RECT_DECODE_ALGO: fused rectify+decode form: 0 = LDS-tiled, 64x8 tiles per persistent workgroup with a
+ * register prefetch pipeline (default), 1 = direct gather, 2 = as 0 with 64x16 tiles (identical results) */
 #define SLR_OPT_RECT_DECODE_ALGO 3
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 

@@ -53,6 +53,16 @@ if "gray" in WHAT:
         dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0, rectify_cam=cam) for cam in range(2)]   # fused K1+K3
     for _ in range(REPS):
         ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False)   # K5
+if "ray" in WHAT:
+    # GRAY_ONLY: column + row bits, counting sort by projector cell, ray-ray triangulation (scan area = camera area)
+    calib2, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib2)
+    g2 = synth.render_gray_stack(W, H, W, H, seed=1234, device=dev, rows=True)
+    nc, nr = synth.gray_num_bits(W), synth.gray_num_bits(H)
+    torch.cuda.synchronize()
+    d2 = [ctx.gray_decode(g2[cam], nc, nr, 40, 0, W, H) for cam in range(2)]
+    for _ in range(REPS):
+        ctx.ray_triangulate(d2[0][0], d2[0][1], d2[0][2], d2[1][0], d2[1][1], d2[1][2], W, H)
 ctx.synchronize()
 ctx.close()
 print("prof_driver done")

@@ -37,3 +37,6 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
 done
 python "$REPO/profiles/summarize_pmc.py" "$OUT" "$SUM/${TAG}_pmc_summary.csv" > "$SUM/${TAG}_pmc_summary.txt" 2>&1
 ls -la "$SUM"
+# the raw rocprofv3 output is tens of MB per pass and gpurun_out/ is capped at 64 MiB: keep logs + summaries only
+mkdir -p "$SUM/logs"; cp "$OUT"/*_stdout.log "$SUM/logs/" 2>/dev/null
+rm -rf "$OUT"

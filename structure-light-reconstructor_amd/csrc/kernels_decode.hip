@@ -72,9 +72,15 @@ __device__ __forceinline__ float heterodyne(float P0f, float P1f, float P2f)
     return __builtin_fmaf(r, rc, q) * 255;
 }
 
-// one pixel of K2: g[0]=white g[1]=black g[2..13] fringes
-__device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const float *lut, int &valid)
+// one pixel of K2: g[0]=white g[1]=black g[2..13] fringes.  SH: the samples sit in bits [SH, SH+8) of g[] with zeros
+// above (the fused LDS kernel hands over its dot-product accumulators, SH = 16, so that the extraction folds into the
+// subtractions as an SDWA operand select instead of 14 shifts).
+template <int SH>
+__device__ __forceinline__ float mf_pixel_sh(const int *gs, int black_thr, const float *lut, int &valid)
 {
+    int g[SLR_MF_PLANES];
+#pragma unroll
+    for (int p = 0; p < SLR_MF_PLANES; p++) g[p] = (int)((unsigned)gs[p] >> SH);
     // computeShadows :198-204: (float)white - (float)black > blackThreshold (exact in integers)
     const bool mask = g[0] - g[1] > black_thr;
     int nz0, nz1, nz2;
@@ -84,6 +90,10 @@ __device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const flo
     const float ph = heterodyne(P0, P1, P2);
     valid = (mask && nz0 != 0 && nz1 != 0 && nz2 != 0) ? 1 : 0;   // Q5 rule: an undefined P makes the pixel invalid
     return mask ? ph : 0.0f;
+}
+__device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const float *lut, int &valid)
+{
+    return mf_pixel_sh<0>(g, black_thr, lut, valid);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(256) void tile_boxes_kernel(const int16_t *__restri
 }
 
 // two tables in one buffer: 64x16 tiles (multi-frequency kernel: 14 planes) then 64x4 tiles (Gray kernel: 22..66 planes)
-constexpr int kGrayTileH = 4;
+constexpr int kGrayTileH = 4, kMidTileH = 8;
 static size_t tile_count(int W, int H, int tile_h)
 {
     return (size_t)((W + kTileW - 1) / kTileW) * ((H + tile_h - 1) / tile_h);
@@ -466,11 +476,13 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, h
                        kTileH, boxes);
     hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kGrayTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kGrayTileH, boxes + tile_count(W, H, kTileH));
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+                       kMidTileH, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH));
     return hipGetLastError();
 }
 size_t tile_boxes_bytes(int W, int H)
 {
-    return (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH)) * sizeof(int4);
+    return (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) + tile_count(W, H, kMidTileH)) * sizeof(int4);
 }
 
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
@@ -494,23 +506,7 @@ struct TileTaps {                        // per-pixel tap state shared by all pl
     u16x2 w0, w1;                        // wx0*wy0, wx1*wy0 | wx0*wy1, wx1*wy1 (<= 1024 each)
 };
 
-template <int NP>
-__device__ __forceinline__ TileTaps<NP> tile_taps(const Tap &t, int x0, int y0, int BW4)
-{
-    TileTaps<NP> k;
-    const bool out = t.kind == 1;        // completely outside: zero weights, any valid address
-    const int bx = out ? 0 : t.sx - x0, r0 = out ? 0 : t.sy - y0;
-    const unsigned sh = (unsigned)bx & 3u;
-    k.a0 = __mul24(__mul24(r0, BW4) + (bx >> 2), NP * 4);
-    k.a1 = k.a0 + __mul24(BW4, NP * 4);
-    k.sel = sh | 0x0C000C00u | ((sh + 1u) << 16);
-    const unsigned wx0 = out ? 0u : (unsigned)t.wx0, wx1 = out ? 0u : (unsigned)t.wx1;
-    k.w0.x = (unsigned short)__umul24(wx0, (unsigned)t.wy0); k.w0.y = (unsigned short)__umul24(wx1, (unsigned)t.wy0);
-    k.w1.x = (unsigned short)__umul24(wx0, (unsigned)t.wy1); k.w1.y = (unsigned short)__umul24(wx1, (unsigned)t.wy1);
-    return k;
-}
-
-// the same state straight from one map entry (xy = x | y << 16, frac = fy << 5 | fx), without the generic Tap:
+// tap state straight from one map entry (xy = x | y << 16, frac = fy << 5 | fx), without the generic Tap:
 // ~20 VALU instructions.  Lanes outside the image (inb == false) and footprints completely outside the source get
 // zero weights and address 0, i.e. sample 0 (BORDER_CONSTANT).
 template <int NP>
@@ -523,7 +519,12 @@ __device__ __forceinline__ TileTaps<NP> tile_taps_map(unsigned xy, unsigned frac
     const bool out = !inb || (unsigned)(sx + 1) > (unsigned)W || (unsigned)(sy + 1) > (unsigned)H;
     const unsigned fx = frac & 31u, fy = (frac >> 5) & 31u;
     const unsigned wxp = out ? 0u : __umul24(fx, 0xFFFFu) + 32u;          // (32 - fx) | fx << 16
-    const unsigned w0 = __umul24(wxp, 32u - fy), w1 = __umul24(wxp, fy);  // both halves <= 1024: no carry across
+    // weights x 64 so that the blended sample is the HIGH HALF of the accumulator (tile_sample): every product is
+    // < 65536 except wx0*wy0*64 at fx = fy = 0, which is 65536 and would carry into the other half; there the other
+    // three weights are 0 and 65535 gives the same sample: (S*65535 + 32768) >> 16 == S for S <= 255.
+    unsigned w0 = __umul24(wxp, (32u - fy) << 6);
+    const unsigned w1 = __umul24(wxp, fy << 6);
+    w0 = w0 == 0x10000u ? 0xFFFFu : w0;
     const int bx = out ? 0 : sx - x0, r0 = out ? 0 : sy - y0;
     k.a0 = __mul24(__mul24(r0, BW4) + (bx >> 2), NP * 4);
     k.a1 = k.a0 + __mul24(BW4, NP * 4);
@@ -534,102 +535,162 @@ __device__ __forceinline__ TileTaps<NP> tile_taps_map(unsigned xy, unsigned frac
 }
 
 // blended sample of plane p: LDS reads are (base + immediate), 2 perms, 2 dot2, 1 shift
-template <int NP>
+template <int NP, int WSHIFT>
 __device__ __forceinline__ int tile_sample(const uint8_t *tile, const TileTaps<NP> &k, int p)
 {
     const unsigned *q0 = reinterpret_cast<const unsigned *>(tile + k.a0);
     const unsigned *q1 = reinterpret_cast<const unsigned *>(tile + k.a1);
     const unsigned p0 = __builtin_amdgcn_perm(q0[p + NP], q0[p], k.sel);
     const unsigned p1 = __builtin_amdgcn_perm(q1[p + NP], q1[p], k.sel);
-    unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), k.w0, 512u, false);
+    unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), k.w0, 512u << WSHIFT, false);
     acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), k.w1, acc, false);
-    return (int)(acc >> 10);
+    return (int)acc;                     // the sample is acc >> (10 + WSHIFT); WSHIFT == 6: the high half-word
 }
 
+// Software pipeline (round 1 finding: with the frame NOT resident in the 256 MB Infinity Cache -- the real pipeline
+// alternates two 172 MB camera stacks -- the non-pipelined form was bound by HBM latency x the few workgroups that
+// happen to be in their fill phase: 129 us vs 100 us warm).  The workgroups are persistent; while a tile is being
+// decoded out of LDS, the global loads of the NEXT tile's box are already in flight into registers (2 rounds x 14
+// planes per thread) and are committed to LDS after the barrier that ends the current tile.  gfx9 has ONE in-order
+// counter for vector memory (vmcnt), so the loads a tile's decode itself needs (its 4x2 map entries) are issued
+// BEFORE the prefetch, and the prefetch is branch-free (out-of-box elements read a dummy address) so that the
+// compiler's s_waitcnt for the map entries is vmcnt(28) on every path and never drains the prefetch.
+struct BoxGeom { int x0, y0, BW4, BH; bool any, fits; };
+
+template <int NP, int ROUNDS>
+__device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int tile, int budget)
+{
+    const int4 box = boxes[tile];
+    BoxGeom g;
+    g.x0 = box.x; g.y0 = box.y; g.BW4 = box.z; g.BH = box.w;
+    g.any = g.BW4 > 0;
+    // the LDS budget, and the prefetch registers: at most ROUNDS x 256 dwords per plane
+    g.fits = g.any && g.BW4 * g.BH <= 256 * ROUNDS && g.BW4 * g.BH * (NP * 4) <= budget;
+    return g;
+}
+
+template <int TH, int ROUNDS>
 __global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                                  const float *__restrict__ lut_g,
                                                                  const int16_t *__restrict__ map_xy,
                                                                  const uint16_t *__restrict__ map_frac,
                                                                  const int4 *__restrict__ boxes,
                                                                  float *__restrict__ phase, uint8_t *__restrict__ valid,
-                                                                 int tiles_x, int tiles_y, int budget, int aligned)
+                                                                 int tiles_x, int tiles_y, int budget)
 {
     constexpr int NP = SLR_MF_PLANES;
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
-    // XCD band order (see mf_rect_decode_kernel): consecutive virtual ids walk tiles row-major inside a band
-    const unsigned nb = gridDim.x, per = nb / 8;
-    const unsigned vb = (nb % 8 == 0) ? (blockIdx.x % 8) * per + blockIdx.x / 8 : blockIdx.x;
-    const int ty = (int)(vb / (unsigned)tiles_x), tx = (int)(vb - (unsigned)ty * tiles_x);
-    if (ty >= tiles_y) return;                              // padding blocks (whole workgroup leaves together)
-    const int4 box = boxes[ty * tiles_x + tx];
-    const int x0 = box.x, y0 = box.y, BW4 = box.z, BH = box.w;
-    const bool any = BW4 > 0;
-    const bool fits = any && (long long)BW4 * BH * (NP * 4) <= budget;
+    // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
+    // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
+    // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
+    const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7u), lb = (int)(blockIdx.x >> 3), nbx = (int)(gridDim.x >> 3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = tx * kTileW + lane;
-
-    if (fits) {
-        // ---- HBM -> LDS: each dword of the box once per plane -------------------------------------------
-        const int E = BH * BW4;
-        const float inv = 1.0f / (float)BW4;
-        for (int e = threadIdx.x; e < E; e += 256) {
-            const int rr = (int)(((float)e + 0.5f) * inv);  // e / BW4 (exact: e < 2^20, remainder margin 0.5/BW4)
-            const int cc = e - rr * BW4;
-            const int gx = x0 + 4 * cc, gy = y0 + rr;
-            unsigned v[NP];
-            // the in/out-of-image decision is the same for all planes: decide once, then 14 independent loads
-            if (aligned && (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W) {
-                const unsigned off = (unsigned)gy * (unsigned)pitch + (unsigned)gx;
-#pragma unroll
-                for (int p = 0; p < NP; p++) v[p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
-            } else {
-#pragma unroll 1
-                for (int p = 0; p < NP; p++) v[p] = load_src_dword(pl.p[p], pitch, W, H, gx, gy);
-            }
-            u32x2 *dst = reinterpret_cast<u32x2 *>(tile + (size_t)e * (NP * 4));
-#pragma unroll
-            for (int p = 0; p < NP; p += 2) { u32x2 w2; w2.x = v[p]; w2.y = v[p + 1]; dst[p >> 1] = w2; }
-        }
-        __syncthreads();
-    }
-    // ---- per pass: 14 blended samples (from LDS, or by direct gather when the box did not fit), decode, store ----
     const unsigned lane31 = (unsigned)lane & 31u;
-#pragma unroll 1
-    for (int q = 0; q < 4; q++) {
-        const int row = ty * kTileH + 4 * q + wv;
-        const bool inb = row < H && col < W;
-        const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
-        // 32-bit byte offsets on scalar bases (the launcher guarantees W*H < 2^30)
-        unsigned xy = 0, fr = 0;
-        if (inb) {
-            xy = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
-            fr = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
-        }
-        int gpx[NP];
-        if (fits) {
-            const TileTaps<NP> k = tile_taps_map<NP>(xy, fr, inb, W, H, x0, y0, BW4);
+
+    // element e of a box (row-major dwords) that thread `tid` owns in round r: e = tid + 256 r
+    unsigned pre[ROUNDS][NP];
+    auto issue = [&](const BoxGeom &g, bool live) {
+        const int E = live && g.fits ? g.BH * g.BW4 : 0;
+        const float inv = 1.0f / (float)(g.BW4 > 0 ? g.BW4 : 1);
 #pragma unroll
-            for (int p = 0; p < NP; p++) gpx[p] = tile_sample<NP>(tile, k, p);
-        } else {
-            Tap t = make_tap((int)(short)(xy & 0xFFFFu), (int)xy >> 16, fr, pitch, W, H);
-            if (!inb) t.kind = 1;
+        for (int r = 0; r < ROUNDS; r++) {
+            const int e = (int)threadIdx.x + 256 * r;
+            const int rr = (int)(((float)e + 0.5f) * inv);  // e / BW4 (exact: e < 2^20, remainder margin 0.5/BW4)
+            const int cc = e - rr * g.BW4;
+            const int gx = g.x0 + 4 * cc, gy = g.y0 + rr;
+            // W % 4 == 0 and gx % 4 == 0: a dword is completely inside or completely outside the image
+            const bool in = e < E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
+#pragma unroll
+            for (int p = 0; p < NP; p++) pre[r][p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
+        }
+    };
+    auto commit = [&](const BoxGeom &g) {                   // same predicate as issue(); outside the image -> 0
+        const int E = g.BH * g.BW4;
+        const float inv = 1.0f / (float)g.BW4;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            const int e = (int)threadIdx.x + 256 * r;
+            if (e < E) {
+                const int rr = (int)(((float)e + 0.5f) * inv);
+                const int cc = e - rr * g.BW4;
+                const int gx = g.x0 + 4 * cc, gy = g.y0 + rr;
+                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                u32x2 *dst = reinterpret_cast<u32x2 *>(tile + (size_t)e * (NP * 4));
+#pragma unroll
+                for (int p = 0; p < NP; p += 2) {
+                    u32x2 w2;
+                    w2.x = in ? pre[r][p] : 0u; w2.y = in ? pre[r][p + 1] : 0u;
+                    dst[p >> 1] = w2;
+                }
+            }
+        }
+    };
+
+    if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
+    int cur = xcd * per + lb;
+    BoxGeom gc = box_geom<NP, ROUNDS>(boxes, cur, budget);
+    issue(gc, true);
+    for (int it = 1;; it++) {
+        if (gc.fits) commit(gc);
+        __syncthreads();
+        const int nl = lb + it * nbx;
+        const bool has_next = nl < per && xcd * per + nl < T;
+        const int nxt = has_next ? xcd * per + nl : cur;
+        const BoxGeom gn = box_geom<NP, ROUNDS>(boxes, nxt, budget);
+
+        const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
+        const int col = tx * kTileW + lane;
+        // map entries of the four passes first (see the header: they must be older than the prefetch)
+        unsigned xy[TH / 4], fr[TH / 4];
+#pragma unroll
+        for (int q = 0; q < TH / 4; q++) {
+            const int row = ty * TH + 4 * q + wv;
+            const bool inb = row < H && col < W;
+            const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
+            xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+            fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
+        }
+        issue(gn, has_next);
+#pragma unroll
+        for (int q = 0; q < TH / 4; q++) {
+            const int row = ty * TH + 4 * q + wv;
+            const bool inb = row < H && col < W;
+            const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+            int v;
+            float ph;
+            if (gc.fits) {
+                const TileTaps<NP> k = tile_taps_map<NP>(xy[q], fr[q], inb, W, H, gc.x0, gc.y0, gc.BW4);
+                int acc[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) acc[p] = tile_sample<NP, 6>(tile, k, p);
+                ph = mf_pixel_sh<16>(acc, black_thr, lut, v);
+            } else {                                        // wild map: direct gather for this tile
+                Tap t = make_tap((int)(short)(xy[q] & 0xFFFFu), (int)xy[q] >> 16, fr[q], pitch, W, H);
+                if (!inb) t.kind = 1;
+                int gpx[NP];
 #pragma unroll 1
-            for (int p = 0; p < NP; p++) gpx[p] = any ? sample(pl.p[p], pitch, W, H, t) : 0;
+                for (int p = 0; p < NP; p++) gpx[p] = gc.any ? sample(pl.p[p], pitch, W, H, t) : 0;
+                ph = mf_pixel(gpx, black_thr, lut, v);
+            }
+            // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane: the wave's ballot, this lane's
+            // nibble of it, and a multiply that spreads 4 bits into 4 bytes (bit i -> bit 8i; the partial products of
+            // 1 + 2^7 + 2^14 + 2^21 do not overlap)
+            const unsigned long long bal = __ballot(v != 0);
+            const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+            const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+            if (inb) {
+                __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
+                if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            }
         }
-        int v;
-        const float ph = mf_pixel(gpx, black_thr, lut, v);
-        // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane: the wave's ballot, this lane's
-        // nibble of it, and a multiply that spreads 4 bits into 4 bytes (bit i -> bit 8i; the partial products of
-        // 1 + 2^7 + 2^14 + 2^21 do not overlap)
-        const unsigned long long bal = __ballot(v != 0);
-        const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
-        const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
-        if (inb) {
-            __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
-            if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
-        }
+        if (!has_next) break;
+        __syncthreads();                                    // everybody is done reading this tile's LDS
+        cur = nxt;
+        gc = gn;
     }
 }
 
@@ -646,16 +707,37 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
-    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
-        (long long)W * H < (1ll << 30)) {
-        bool aligned = pitch % 4 == 0;
-        for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+    bool aligned = pitch % 4 == 0;
+    for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+    if (map_xy && tile_boxes && W % 4 == 0 && aligned && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) &&
+        ((uintptr_t)valid % 4 == 0) && (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32)) {
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-        const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
-        const int budget = 24 * 1024;                        // 14 planes x ~72 x 23 source bytes; 6 workgroups per CU
-        hipLaunchKernelGGL(mf_rect_decode_lds_kernel, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl, pitch, W, H,
-                           black_thr, atan_lut, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, tiles_x, tiles_y,
-                           budget, aligned ? 1 : 0);
+        // persistent workgroups: as many as are resident at once (a multiple of 8 for the XCD bands), never more
+        // than one per tile
+        const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
+        const int th = mid ? kMidTileH : kTileH;
+        const int tiles_yy = (H + th - 1) / th;
+        const int budget = mid ? 12 * 1024 : 24 * 1024;      // 14 planes x ~72 x (th + 7) source bytes
+        const int4 *bx = (const int4 *)tile_boxes + (mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0);
+        static int resident[2] = {0, 0};
+        if (!resident[mid]) {
+            int per_cu = 0, dev = 0, cus = 0;
+            const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1>, 256, (size_t)budget + 16)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2>, 256, (size_t)budget + 16);
+            if (e != hipSuccess || per_cu < 1) per_cu = 4;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            resident[mid] = per_cu * cus;
+        }
+        const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
+        int nbx = resident[mid] / 8 < per ? resident[mid] / 8 : per;
+        if (nbx < 1) nbx = 1;
+        if (mid)
+            hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), dim3(8u * (unsigned)nbx), dim3(256), (size_t)budget + 16, s,
+                               pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, bx, phase, valid, tiles_x, tiles_yy, budget);
+        else
+            hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), dim3(8u * (unsigned)nbx), dim3(256), (size_t)budget + 16, s,
+                               pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, bx, phase, valid, tiles_x, tiles_yy, budget);
         return hipGetLastError();
     }
     if (map_xy) {
