@@ -13,6 +13,8 @@
 //       GrayCodes::grayToDec                                                       Duke/graycodes.cpp:116-128
 #include "slr_device.hpp"
 
+#include <stdlib.h>
+
 namespace slr {
 
 // native clang vectors (HIP's uint4/float4 are structs and cannot be used with __builtin_nontemporal_*)
@@ -730,7 +732,9 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
             resident[mid] = per_cu * cus;
         }
         const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
-        int nbx = resident[mid] / 8 < per ? resident[mid] / 8 : per;
+        const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
+        const int res = dbg && atoi(dbg) > 0 ? atoi(dbg) : resident[mid];
+        int nbx = res / 8 < per ? res / 8 : per;
         if (nbx < 1) nbx = 1;
         if (mid)
             hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), dim3(8u * (unsigned)nbx), dim3(256), (size_t)budget + 16, s,

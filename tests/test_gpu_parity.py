@@ -122,7 +122,7 @@ def test_remap_border_constant(ctx, oracle, synth, dx, dy, fx, fy):
     assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph)
 
 
-@pytest.mark.parametrize("W,H", [(640, 480), (101, 67), (64, 48)])
+@pytest.mark.parametrize("W,H", [(640, 480), (101, 67), (64, 48), (200, 77)])
 def test_remap_and_fused_rectify_decode(ctx, oracle, synth, slr, W, H):
     st = synth.render_mf_stack(W, H, seed=99)
     maps = [synth.make_rectify_maps(W, H, cam, strength=3.0) for cam in range(2)]
@@ -170,6 +170,31 @@ def test_fused_rectify_decode_wild_maps(ctx, oracle, synth, slr):
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
         assert np.array_equal(ctx.remap_u8(0, raw[3]), rect[3])
+
+
+@pytest.mark.parametrize("W,H", [(200, 77), (448, 203)])
+def test_fused_rectify_decode_pipeline_many_tiles_per_workgroup(ctx, oracle, synth, slr, W, H, monkeypatch):
+    """the persistent, register-prefetching form with only 8 / 16 workgroups: every workgroup walks many tiles, among
+    them tiles whose box does not fit (random-scatter patch -> gather fallback), tiles completely outside the source,
+    ragged right/bottom tiles (W % 64 != 0, H % 8 != 0) -- the prefetch of tile t+1 must never leak into tile t"""
+    rng = np.random.default_rng(W)
+    st = synth.render_mf_stack(W, H, seed=11)
+    raw = st[0].numpy()
+    mxt, mft = synth.make_rectify_maps(W, H, 0, strength=3.0)
+    mx, mf = mxt.numpy().copy(), mft.numpy().copy()
+    mx[20:45, 70:150] = np.stack([rng.integers(-9, W + 9, size=(25, 80)), rng.integers(-9, H + 9, size=(25, 80))], -1)
+    mx[50:60, 0:64, 0] += 6000                                       # one tile row segment entirely outside
+    ctx.set_rectify_maps(0, np.ascontiguousarray(mx), np.ascontiguousarray(mf))
+    rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+    exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
+    for res in ("8", "16", "40"):
+        monkeypatch.setenv("SLR_DEBUG_RECT_RESIDENT", res)
+        for algo in (0, 2):
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+            ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
+            assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), (res, algo)
+    monkeypatch.delenv("SLR_DEBUG_RECT_RESIDENT")
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
 
 
 # ---------------------------------------------------------------------------------------------------------
