@@ -35,7 +35,7 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
     rocprofv3 --kernel-trace --pmc $PMC -f csv -d "$OUT/pmc$i" -o pmc$i -- python "$REPO/profiles/prof_driver.py" > "$OUT/pmc${i}_stdout.log" 2>&1
     cp "$OUT"/pmc$i/*counter_collection.csv "$OUT/pmc${i}_counters.csv" 2>/dev/null
 done
-python "$REPO/profiles/summarize_pmc.py" "$OUT" "$SUM/${TAG}_pmc_summary.csv" > "$SUM/${TAG}_pmc_summary.txt" 2>&1
+python "$REPO/profiles/summarize_pmc.py" "$OUT" "$SUM/${TAG}_pmc_summary.csv" "$SUM/pmc_traffic.json" > "$SUM/${TAG}_pmc_summary.txt" 2>&1
 ls -la "$SUM"
 # the raw rocprofv3 output is tens of MB per pass and gpurun_out/ is capped at 64 MiB: keep logs + summaries only
 mkdir -p "$SUM/logs"; cp "$OUT"/*_stdout.log "$SUM/logs/" 2>/dev/null

@@ -44,5 +44,32 @@ def main(out_dir, summary_csv):
             print("    %-32s %.6g" % ("hbm_write_bytes (WRITE_SIZE KiB)", wr))
 
 
+# rocprof kernel name prefix -> the library's profiler name (slr_profile_kernel_name), for bench.py's roofline.traffic
+PROFILER_NAME = [
+    ("mf_rect_decode_lds_kernel", "slr_mf_rectify_decode"), ("mf_decode_kernel", "slr_mf_decode"),
+    ("remap_kernel", "slr_remap_u8"), ("gray_rect_decode_lds_kernel", "slr_gray_rectify_decode"),
+    ("gray_decode_kernel<4, false>", "slr_gray_decode"), ("mf_match_binned_kernel", "slr_mf_match_triangulate"),
+    ("ge_match_kernel", "slr_ge_match_triangulate"), ("ray_count_kernel", "slr_ray_count"),
+    ("ray_scatter_kernel", "slr_ray_scatter"), ("ray_triangulate_kernel", "slr_ray_triangulate"),
+]
+
+
+def traffic_json(summary_csv, out_json):
+    import json
+    out = {}
+    for row in csv.DictReader(open(summary_csv)):
+        for prefix, name in PROFILER_NAME:
+            if row["kernel"].startswith(prefix) and name not in out:
+                rd, wr = float(row["hbm_read_bytes(2xFETCH)"]), float(row["hbm_write_bytes"])
+                if rd == rd and wr == wr:
+                    out[name] = {"hbm_bytes_per_launch": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+                                 "kernel": row["kernel"],
+                                 "source": "profiles/%s: 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM "
+                                           "section) + WRITE_SIZE KiB, mean per dispatch at 4096x3000" % os.path.basename(summary_csv)}
+    json.dump(out, open(out_json, "w"), indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) > 3:
+        traffic_json(sys.argv[2], sys.argv[3])
