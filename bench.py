@@ -34,6 +34,7 @@ BLACK_THR = 40                 # Duke/Set.ui:429-431 default
 # algorithmic bytes per camera-pixel (or stereo-pixel for the match kernel) -- SURVEY.md 8(d), DESIGN.md
 ALG_BYTES = {
     "slr_mf_rectify_decode": 25.0,     # 14 src + 6 map + 4 phase + 1 valid
+    "slr_mf_rectify_decode_pair": 50.0,  # the same kernel serving both cameras of the frame in one launch (per st-px)
     "slr_mf_decode": 19.0,             # 12 fringe + 2 white/black + 4 phase + 1 valid
     "slr_mf_match_triangulate": 23.0,  # 2x(4+1) read + 12 + 1 write
     "slr_remap_u8": 8.0,
@@ -245,7 +246,12 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(k0["name"], {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if k0["name"].endswith("_pair"):         # both cameras in one launch: 2 x the per-camera launch measured
+                    traffic = tj.get(k0["name"][:-5], {}).get("hbm_bytes_per_launch")
+                    traffic = 2 * traffic if traffic else None
+                else:
+                    traffic = tj.get(k0["name"], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0.get("achieved_GBs"), "peak": HBM_PEAK_GBS,

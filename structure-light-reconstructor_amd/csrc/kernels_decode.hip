@@ -571,24 +571,42 @@ __device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int 
     return g;
 }
 
+// One launch serves one camera (njobs == 1) or both cameras of a stereo frame (njobs == 2: the first half of the grid
+// decodes job 0, the second half job 1 -- one launch gap and one tail less per frame).
+struct RectJob {
+    MfPlanes pl;
+    const int16_t *map_xy;
+    const uint16_t *map_frac;
+    const int4 *boxes;
+    float *phase;
+    uint8_t *valid;
+};
+
 template <int TH, int ROUNDS>
-__global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
-                                                                 const float *__restrict__ lut_g,
-                                                                 const int16_t *__restrict__ map_xy,
-                                                                 const uint16_t *__restrict__ map_frac,
-                                                                 const int4 *__restrict__ boxes,
-                                                                 float *__restrict__ phase, uint8_t *__restrict__ valid,
+__global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(RectJob job0, RectJob job1, int njobs, int pitch, int W, int H,
+                                                                 int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
 {
     constexpr int NP = SLR_MF_PLANES;
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     __shared__ float lut[kLutWords + 1];
     load_lut(lut, lut_g);
+    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
+    const bool second = blockIdx.x >= nblk;
+    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
+    MfPlanes pl;
+#pragma unroll
+    for (int p = 0; p < NP; p++) pl.p[p] = second ? job1.pl.p[p] : job0.pl.p[p];
+    const int16_t *__restrict__ map_xy = second ? job1.map_xy : job0.map_xy;
+    const uint16_t *__restrict__ map_frac = second ? job1.map_frac : job0.map_frac;
+    const int4 *__restrict__ boxes = second ? job1.boxes : job0.boxes;
+    float *__restrict__ phase = second ? job1.phase : job0.phase;
+    uint8_t *__restrict__ valid = second ? job1.valid : job0.valid;
     // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
     // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
     // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
     const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
-    const int xcd = (int)(blockIdx.x & 7u), lb = (int)(blockIdx.x >> 3), nbx = (int)(gridDim.x >> 3);
+    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const unsigned lane31 = (unsigned)lane & 31u;
 
@@ -705,44 +723,77 @@ static unsigned pick_blocks(size_t groups)
     return (unsigned)(((b ? b : 1) + 7) & ~(size_t)7);
 }
 
+// the LDS-tiled fused kernel needs dword-aligned planes and outputs and 32-bit offsets
+static bool rect_lds_ok(const MfPlanes &pl, int pitch, int W, int H, const float *phase, const uint8_t *valid,
+                        const int16_t *map_xy, const void *tile_boxes, int rect_algo)
+{
+    bool aligned = pitch % 4 == 0;
+    for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+    return map_xy && tile_boxes && W % 4 == 0 && aligned && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) &&
+           ((uintptr_t)valid % 4 == 0) && (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32);
+}
+
+static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int W, int H, int black_thr,
+                                  const float *atan_lut, int rect_algo, hipStream_t s)
+{
+    const int tiles_x = (W + kTileW - 1) / kTileW;
+    // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
+    // than one per tile
+    const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
+    const int th = mid ? kMidTileH : kTileH;
+    const int tiles_yy = (H + th - 1) / th;
+    const int budget = mid ? 12 * 1024 : 24 * 1024;      // 14 planes x ~72 x (th + 7) source bytes
+    const size_t box_off = mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0;
+    RectJob j[2] = {jobs[0], jobs[njobs - 1]};
+    j[0].boxes += box_off; j[1].boxes += box_off;
+    static int resident[2] = {0, 0};
+    if (!resident[mid]) {
+        int per_cu = 0, dev = 0, cus = 0;
+        const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1>, 256, (size_t)budget + 16)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2>, 256, (size_t)budget + 16);
+        if (e != hipSuccess || per_cu < 1) per_cu = 4;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        resident[mid] = per_cu * cus;
+    }
+    const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
+    const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
+    const int res = (dbg && atoi(dbg) > 0 ? atoi(dbg) : resident[mid]) / njobs;
+    int nbx = res / 8 < per ? res / 8 : per;
+    if (nbx < 1) nbx = 1;
+    const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);
+    if (mid)
+        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), grid, dim3(256), (size_t)budget + 16, s, j[0], j[1], njobs,
+                           pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+    else
+        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), grid, dim3(256), (size_t)budget + 16, s, j[0], j[1], njobs,
+                           pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+    return hipGetLastError();
+}
+
+// both cameras of a stereo frame in one launch; *done = false when the LDS-tiled form does not apply (caller then
+// launches the cameras one by one through launch_mf_decode)
+hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, int H, int black_thr, const float *atan_lut,
+                                      float *const phase[2], uint8_t *const valid[2], const int16_t *const map_xy[2],
+                                      const uint16_t *const map_frac[2], const void *const tile_boxes[2], int rect_algo,
+                                      bool *done, hipStream_t s)
+{
+    *done = false;
+    for (int c = 0; c < 2; c++)
+        if (!rect_lds_ok(pl[c], pitch, W, H, phase[c], valid[c], map_xy[c], tile_boxes[c], rect_algo)) return hipSuccess;
+    RectJob jobs[2];
+    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c]};
+    *done = true;
+    return launch_rect_lds(jobs, 2, pitch, W, H, black_thr, atan_lut, rect_algo, s);
+}
+
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
-    bool aligned = pitch % 4 == 0;
-    for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
-    if (map_xy && tile_boxes && W % 4 == 0 && aligned && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) &&
-        ((uintptr_t)valid % 4 == 0) && (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32)) {
-        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kTileH - 1) / kTileH;
-        // persistent workgroups: as many as are resident at once (a multiple of 8 for the XCD bands), never more
-        // than one per tile
-        const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
-        const int th = mid ? kMidTileH : kTileH;
-        const int tiles_yy = (H + th - 1) / th;
-        const int budget = mid ? 12 * 1024 : 24 * 1024;      // 14 planes x ~72 x (th + 7) source bytes
-        const int4 *bx = (const int4 *)tile_boxes + (mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0);
-        static int resident[2] = {0, 0};
-        if (!resident[mid]) {
-            int per_cu = 0, dev = 0, cus = 0;
-            const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1>, 256, (size_t)budget + 16)
-                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2>, 256, (size_t)budget + 16);
-            if (e != hipSuccess || per_cu < 1) per_cu = 4;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-            resident[mid] = per_cu * cus;
-        }
-        const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
-        const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
-        const int res = dbg && atoi(dbg) > 0 ? atoi(dbg) : resident[mid];
-        int nbx = res / 8 < per ? res / 8 : per;
-        if (nbx < 1) nbx = 1;
-        if (mid)
-            hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), dim3(8u * (unsigned)nbx), dim3(256), (size_t)budget + 16, s,
-                               pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, bx, phase, valid, tiles_x, tiles_yy, budget);
-        else
-            hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), dim3(8u * (unsigned)nbx), dim3(256), (size_t)budget + 16, s,
-                               pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, bx, phase, valid, tiles_x, tiles_yy, budget);
-        return hipGetLastError();
+    if (rect_lds_ok(pl, pitch, W, H, phase, valid, map_xy, tile_boxes, rect_algo)) {
+        const RectJob job{pl, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid};
+        return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
     }
     if (map_xy) {
         const bool vec = (W % 4 == 0);

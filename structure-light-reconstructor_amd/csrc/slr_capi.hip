@@ -22,7 +22,7 @@ const char *kKernelNames[K_COUNT] = {
     "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
     "slr_ray_triangulate",
-    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table"};
+    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -675,8 +675,24 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
     void *phL, *vL, *phR, *vR;
     SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL)); SLR_TRY(get_scratch(c, S_VALID_L, n, &vL));
     SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vR));
-    SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
-    SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
+    bool paired = false;
+    if (rectify) {                                       // both cameras in one launch when the LDS-tiled form applies
+        MfPlanes mp[2];
+        for (int i = 0; i < SLR_MF_PLANES; i++) { mp[0].p[i] = pL[i]; mp[1].p[i] = pR[i]; }
+        float *const ph[2] = {(float *)phL, (float *)phR};
+        uint8_t *const vd[2] = {(uint8_t *)vL, (uint8_t *)vR};
+        const int16_t *const mxy[2] = {c->d_map_xy[0], c->d_map_xy[1]};
+        const uint16_t *const mfr[2] = {c->d_map_frac[0], c->d_map_frac[1]};
+        const void *const box[2] = {c->d_tile_box[0], c->d_tile_box[1]};
+        ProfScope ps(c, K_MF_RECT_DECODE_PAIR);
+        SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, c->opt_rect_algo,
+                                              &paired, c->stream));
+        if (!paired && ps.on) { ps.on = false; c->free_events.push_back(ps.r.a); c->free_events.push_back(ps.r.b); }
+    }
+    if (!paired) {
+        SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
+        SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
+    }
     return core_mf_match(c, (const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H, xyz,
                          has, nullptr);
 }

@@ -36,7 +36,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_COUNT
 };
 
 // ---- launchers (defined in the .hip files; all asynchronous on `s`) -----------------------------------
@@ -49,6 +49,13 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             const void *tile_boxes /* launch_tile_boxes output for this map, or null */,
                             int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */,
                             int rect_algo /* fused form: 0 = LDS-tiled, 1 = direct gather */, hipStream_t s);
+
+// both cameras of a stereo frame in one launch (LDS-tiled fused form only; *done = false -> not applicable, nothing
+// was launched)
+hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, int H, int black_thr, const float *atan_lut,
+                                      float *const phase[2], uint8_t *const valid[2], const int16_t *const map_xy[2],
+                                      const uint16_t *const map_frac[2], const void *const tile_boxes[2], int rect_algo,
+                                      bool *done, hipStream_t s);
 
 // per-tile source bounding boxes of a rectification map (64x16 destination tiles), int4 per tile
 size_t     tile_boxes_bytes(int W, int H);
