@@ -101,6 +101,14 @@ int slr_set_calibration(slr_ctx *ctx, const slr_calib *calib);
  * (x,y), map_frac = CV_16UC1 [H][W]; copied into library-owned HBM. */
 int slr_set_rectify_maps(slr_ctx *ctx, int cam, const int16_t *map_xy, const uint16_t *map_frac,
                          int W, int H, slr_mem mem);
+/* the same maps computed ON THE DEVICE from the calibration: cv::initUndistortRectifyMap(M, D, R, P, size,
+ * CV_16SC2, map1, map2) of stereoRect::calParameters (stereorect.cpp:42-43).  M 3x3, D = k1 k2 p1 p2 k3, R 3x3
+ * (R1/R2 of cv::stereoRectify), P 3x4 (P1/P2), all row-major f64 host arrays.  Installs the result as camera `cam`'s
+ * rectification maps (bit-identical to the host restatement, which the oracle checks). */
+int slr_init_rectify_maps(slr_ctx *ctx, int cam, const double M[9], const double D[5], const double R[9],
+                          const double P[12], int W, int H);
+/* read back the maps currently installed for `cam` (host or device destination) */
+int slr_get_rectify_maps(slr_ctx *ctx, int cam, int16_t *map_xy, uint16_t *map_frac, int W, int H, slr_mem mem);
 
 /* ---- K1: stereoRect::doStereoRectify -> cv::remap INTER_LINEAR (stereorect.cpp:26-34) ----------------- */
 int slr_remap_u8(slr_ctx *ctx, int cam, const uint8_t *src, int src_pitch,

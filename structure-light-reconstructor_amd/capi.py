@@ -24,7 +24,8 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED
 # every symbol include/slr.h declares (checked by tests/test_capi_symbols.py without a GPU)
 SYMBOLS = [
     "slr_version", "slr_status_string", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
-    "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_remap_u8", "slr_mf_decode",
+    "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_init_rectify_maps",
+    "slr_get_rectify_maps", "slr_remap_u8", "slr_mf_decode",
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch",
@@ -216,6 +217,19 @@ class Context:
         mem = _mem_of([map_xy, map_frac])
         self._chk(self.lib.slr_set_rectify_maps(self.h, C.c_int(cam), _ptr(map_xy), _ptr(map_frac),
                                                 C.c_int(W), C.c_int(H), C.c_int(mem)))
+
+    def init_rectify_maps(self, cam, M, D, R, P, W, H):
+        """cv::initUndistortRectifyMap on the device (stereorect.cpp:42-43); installs the maps for `cam`."""
+        a = [np.ascontiguousarray(x, np.float64).reshape(n) for x, n in ((M, 9), (D, 5), (R, 9), (P, 12))]
+        self._chk(self.lib.slr_init_rectify_maps(self.h, C.c_int(cam), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                                 C.c_int(W), C.c_int(H)))
+
+    def get_rectify_maps(self, cam, W, H):
+        xy = np.empty((H, W, 2), np.int16)
+        fr = np.empty((H, W), np.uint16)
+        self._chk(self.lib.slr_get_rectify_maps(self.h, C.c_int(cam), _ptr(xy), _ptr(fr), C.c_int(W), C.c_int(H),
+                                                C.c_int(MEM_HOST)))
+        return xy, fr
 
     # -- K1
     def remap_u8(self, cam, src, out=None):

@@ -401,6 +401,73 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
 }
 
 // ------------------------------------------------------------------------------------------------------
+// cv::initUndistortRectifyMap(M, D, R, P, size, CV_16SC2) on the device (stereorect.cpp:42-43; SURVEY 8c-3 i, 8f-4).
+// OpenCV walks a row with RUNNING SUMS (_x += iR00, ...), so column j depends on j-1: one lane owns one destination
+// row and walks it left to right -- the f64 sequence is the oracle's, bit for bit -- and 64 rows x 64 columns go
+// through LDS so that the stores are coalesced.  One-time work per calibration (~1 ms at 4096 x 3000).
+// ------------------------------------------------------------------------------------------------------
+struct MapGen { double ir[9], fx, fy, u0, v0, k1, k2, p1, p2, k3; };
+
+__global__ __launch_bounds__(64) void init_rectify_map_kernel(MapGen g, int W, int H, int16_t *__restrict__ map_xy,
+                                                              uint16_t *__restrict__ map_frac)
+{
+    __shared__ unsigned sxy[64][65];
+    __shared__ unsigned short sfr[64][66];
+    const int lane = threadIdx.x, i = blockIdx.x * 64 + lane;
+    double _x = i * g.ir[1] + g.ir[2], _y = i * g.ir[4] + g.ir[5], _w = i * g.ir[7] + g.ir[8];
+    for (int j0 = 0; j0 < W; j0 += 64) {
+        const int nj = W - j0 < 64 ? W - j0 : 64;
+        for (int jj = 0; jj < nj; jj++, _x += g.ir[0], _y += g.ir[3], _w += g.ir[6]) {
+            const double w = 1. / _w, x = _x * w, y = _y * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = 1 + ((g.k3 * r2 + g.k2) * r2 + g.k1) * r2;
+            const double u = g.fx * (x * kr + g.p1 * _2xy + g.p2 * (r2 + 2 * x2)) + g.u0;
+            const double v = g.fy * (y * kr + g.p1 * (r2 + 2 * y2) + g.p2 * _2xy) + g.v0;
+            const long long iu = __double2ll_rn(u * 32), iv = __double2ll_rn(v * 32);   // cvRound: half to even
+            sxy[lane][jj] = (unsigned)(unsigned short)(short)(iu >> 5) | ((unsigned)(unsigned short)(short)(iv >> 5) << 16);
+            sfr[lane][jj] = (unsigned short)((iv & 31) * 32 + (iu & 31));
+        }
+        __syncthreads();
+        for (int r = 0; r < 64; r++) {                       // row r of the block, 64 consecutive columns per store
+            const int row = blockIdx.x * 64 + r;
+            if (row < H && lane < nj) {
+                const size_t m = (size_t)row * W + j0 + lane;
+                reinterpret_cast<unsigned *>(map_xy)[m] = sxy[r][lane];
+                map_frac[m] = sfr[r][lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_init_rectify_map(const double M[9], const double D[5], const double R[9], const double P[12], int W, int H,
+                                   int16_t *map_xy, uint16_t *map_frac, hipStream_t s)
+{
+    // iR = (P[:, :3] * R)^-1 by the adjugate, in f64 on the host (9 numbers)
+    MapGen g;
+    double A[9];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            double t = 0;
+            for (int k = 0; k < 3; k++) t += P[r * 4 + k] * R[k * 3 + c];
+            A[r * 3 + c] = t;
+        }
+    const double det = A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
+                       A[2] * (A[3] * A[7] - A[4] * A[6]);
+    const double d = 1. / det;
+    g.ir[0] = (A[4] * A[8] - A[5] * A[7]) * d; g.ir[1] = (A[2] * A[7] - A[1] * A[8]) * d;
+    g.ir[2] = (A[1] * A[5] - A[2] * A[4]) * d; g.ir[3] = (A[5] * A[6] - A[3] * A[8]) * d;
+    g.ir[4] = (A[0] * A[8] - A[2] * A[6]) * d; g.ir[5] = (A[2] * A[3] - A[0] * A[5]) * d;
+    g.ir[6] = (A[3] * A[7] - A[4] * A[6]) * d; g.ir[7] = (A[1] * A[6] - A[0] * A[7]) * d;
+    g.ir[8] = (A[0] * A[4] - A[1] * A[3]) * d;
+    g.fx = M[0]; g.fy = M[4]; g.u0 = M[2]; g.v0 = M[5];
+    g.k1 = D[0]; g.k2 = D[1]; g.p1 = D[2]; g.p2 = D[3]; g.k3 = D[4];
+    hipLaunchKernelGGL(init_rectify_map_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, s, g, W, H, map_xy, map_frac);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------
 // fused K1+K2, LDS-tiled form (the default): one workgroup rectifies + decodes a 64 x 16 destination tile.
 //   0. (once per map, at slr_set_rectify_maps) tile_boxes_kernel reduces every tile's map entries to the bounding
 //      box of its source footprints with wave shuffles (a smooth map turns 64x16 into roughly 70x19 source pixels);

@@ -455,10 +455,8 @@ int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
     return SLR_OK;
 }
 
-int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint16_t *map_frac, int W, int H,
-                         slr_mem mem)
+static int map_storage(slr_ctx *c, int cam, int W, int H)
 {
-    if (!c || !map_xy || !map_frac) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
     if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 or 1");
     SLR_TRY(check_dims(c, W, H, W));
     SLR_TRY(use_device(c));
@@ -475,10 +473,43 @@ int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint1
     if (!c->d_map_xy[cam]) SLR_HIP(c, hipMalloc(&c->d_map_xy[cam], n * 4));
     if (!c->d_map_frac[cam]) SLR_HIP(c, hipMalloc(&c->d_map_frac[cam], n * 2));
     if (!c->d_tile_box[cam]) SLR_HIP(c, hipMalloc(&c->d_tile_box[cam], tile_boxes_bytes(W, H)));
+    return SLR_OK;
+}
+
+int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint16_t *map_frac, int W, int H,
+                         slr_mem mem)
+{
+    if (!c || !map_xy || !map_frac) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(map_storage(c, cam, W, H));
+    const size_t n = (size_t)W * H;
     const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
     SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
     SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+int slr_init_rectify_maps(slr_ctx *c, int cam, const double M[9], const double D[5], const double R[9], const double P[12],
+                          int W, int H)
+{
+    if (!c || !M || !D || !R || !P) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(map_storage(c, cam, W, H));
+    SLR_HIP(c, launch_init_rectify_map(M, D, R, P, W, H, c->d_map_xy[cam], c->d_map_frac[cam], c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+int slr_get_rectify_maps(slr_ctx *c, int cam, int16_t *map_xy, uint16_t *map_frac, int W, int H, slr_mem mem)
+{
+    if (!c || !map_xy || !map_frac) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_maps(c, cam, W, H));
+    const size_t n = (size_t)W * H;
+    const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    SLR_HIP(c, hipMemcpyAsync(map_xy, c->d_map_xy[cam], n * 4, kind, c->stream));
+    SLR_HIP(c, hipMemcpyAsync(map_frac, c->d_map_frac[cam], n * 2, kind, c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }

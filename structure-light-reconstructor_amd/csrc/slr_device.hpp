@@ -57,6 +57,10 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
                                       const uint16_t *const map_frac[2], const void *const tile_boxes[2], int rect_algo,
                                       bool *done, hipStream_t s);
 
+// cv::initUndistortRectifyMap (CV_16SC2 fixed-point maps) on the device
+hipError_t launch_init_rectify_map(const double M[9], const double D[5], const double R[9], const double P[12], int W, int H,
+                                   int16_t *map_xy, uint16_t *map_frac, hipStream_t s);
+
 // per-tile source bounding boxes of a rectification map (64x16 destination tiles), int4 per tile
 size_t     tile_boxes_bytes(int W, int H);
 hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s);

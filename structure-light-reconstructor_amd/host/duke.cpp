@@ -415,6 +415,17 @@ bool stereoRect::upload(slr_ctx *ctx)
            slr_set_rectify_maps(ctx, 1, map21.data(), map22.data(), w, h, SLR_MEM_HOST) == SLR_OK;
 }
 
+// the same maps generated on the device (slr_init_rectify_maps): no 2 x 74 MB upload; bit-identical to upload()
+bool stereoRect::uploadFromCalibration(slr_ctx *ctx)
+{
+    if (M1.empty() || M2.empty() || R1.empty() || R2.empty() || P1.empty() || P2.empty()) return false;
+    double d1[5] = {0, 0, 0, 0, 0}, d2[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < 5 && i < D1.v.size(); i++) d1[i] = D1.v[i];
+    for (size_t i = 0; i < 5 && i < D2.v.size(); i++) d2[i] = D2.v[i];
+    return slr_init_rectify_maps(ctx, 0, M1.v.data(), d1, R1.v.data(), P1.v.data(), w, h) == SLR_OK &&
+           slr_init_rectify_maps(ctx, 1, M2.v.data(), d2, R2.v.data(), P2.v.data(), w, h) == SLR_OK;
+}
+
 bool stereoRect::doStereoRectify(slr_ctx *ctx, Image8 &img, bool isleft)
 {
     if (img.empty() || img.w != w || img.h != h) return false;
@@ -688,7 +699,7 @@ bool Reconstruct::runReconstruction_GE()
     if (!sr) { lastError = "getParameters not called"; return false; }
     sr->calParameters();
     slr_calib cal;
-    if (!fillCalib(cal) || slr_set_calibration(ctx, &cal) != SLR_OK || !sr->upload(ctx)) {
+    if (!fillCalib(cal) || slr_set_calibration(ctx, &cal) != SLR_OK || !(sr->uploadFromCalibration(ctx) || sr->upload(ctx))) {
         lastError = "calibration incomplete"; warn("Reconstruct", lastError); return false;
     }
     const int W = cameraWidth, H = cameraHeight;
@@ -793,7 +804,7 @@ bool MFReconstruct::runReconstruction()
     cameras[1].fill(cal.cam[1]);
     if (sr->Q.empty()) { lastError = "stereo calibration files missing"; warn("Reconstruct", lastError); return false; }
     memcpy(cal.Q, sr->Q.v.data(), sizeof(double) * 16);
-    if (!load_transfer(savePath_, scanSN, cal) || slr_set_calibration(ctx, &cal) != SLR_OK || !sr->upload(ctx)) {
+    if (!load_transfer(savePath_, scanSN, cal) || slr_set_calibration(ctx, &cal) != SLR_OK || !(sr->uploadFromCalibration(ctx) || sr->upload(ctx))) {
         lastError = "calibration incomplete"; warn("Reconstruct", lastError); return false;
     }
     const int W = cameraWidth, H = cameraHeight;

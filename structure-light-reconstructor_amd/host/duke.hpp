@@ -80,6 +80,7 @@ public:
     void calParameters();                                    // cv::stereoRectify(flags 0, alpha -1) + 2x initUndistortRectifyMap, restated
     bool doStereoRectify(slr_ctx *ctx, Image8 &img, bool isleft);   // cv::remap on the GPU (slr_remap_u8)
     bool upload(slr_ctx *ctx);                               // slr_set_rectify_maps for both cameras
+    bool uploadFromCalibration(slr_ctx *ctx);                // slr_init_rectify_maps: the maps are built on the device
     Matd R1, P1, R2, P2, Q;
     Matd M1, D1, M2, D2, R, T;
     std::vector<int16_t> map11, map21;                       // CV_16SC2

@@ -102,6 +102,27 @@ def test_remap_identity_and_half_pixel(ctx, oracle, synth):
     assert np.array_equal(out1, oracle.remap_u8(img, mx.numpy(), mf.numpy()))
 
 
+@pytest.mark.parametrize("W,H", [(640, 480), (130, 67), (4096, 200)])
+def test_init_rectify_maps_on_device_matches_oracle(ctx, oracle, W, H):
+    """cv::initUndistortRectifyMap restated on the device (running sums along a row, f64, cvRound half-to-even) ==
+    the oracle's host restatement, bit for bit, incl. strong distortion and a rotated R"""
+    f = 0.9 * W
+    M = np.array([[f, 0, W / 2 - 3.3], [0, f * 1.01, H / 2 + 1.7], [0, 0, 1]])
+    D = np.array([-0.28, 0.11, 0.0013, -0.0009, 0.02])
+    a, b = 0.02, -0.013
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]) @ \
+        np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    P = np.array([[f * 0.97, 0, W / 2 + 5.0, -40.0 * f], [0, f * 0.97, H / 2, 0], [0, 0, 1, 0]])
+    exy, efr = oracle.init_undistort_rectify_map(M, D, R, P, W, H)
+    for cam in range(2):
+        ctx.init_rectify_maps(cam, M, D, R, P, W, H)
+        xy, fr = ctx.get_rectify_maps(cam, W, H)
+        assert np.array_equal(xy, exy) and np.array_equal(fr, efr)
+    # and the installed maps drive the remap
+    src = np.random.default_rng(1).integers(0, 256, (H, W)).astype(np.uint8)
+    assert np.array_equal(ctx.remap_u8(0, src), oracle.remap_u8(src, exy, efr))
+
+
 @pytest.mark.parametrize("dx,dy,fx,fy", [(-3, -2, 7, 19), (5, 4, 31, 31), (-1, 0, 0, 13), (0, -1, 30, 0), (700, 0, 3, 3)])
 def test_remap_border_constant(ctx, oracle, synth, dx, dy, fx, fy):
     """taps that leave the image read 0 (BORDER_CONSTANT): partially-outside 2x2 footprints on every side and a
