@@ -11,6 +11,8 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <thread>
+#include <atomic>
 
 namespace duke {
 
@@ -603,19 +605,38 @@ static bool load_transfer(const std::string &savePath, int scanSN, slr_calib &ca
     return true;
 }
 
+// scan-directory reader (reconstruct.cpp:158-164, mfreconstruct.cpp:119-125): <folder><prefix><i><suffix>, 8-bit grey.
+// PNG inflate runs at ~200 MB/s per core, i.e. ~60 ms per 4096x3000 plane and 1.7 s for a 28-image stereo frame if
+// done one file after the other as the reference does -- three orders of magnitude more than the GPU path.  The files of
+// a stack are therefore decoded by a pool of host threads (one file per task, SLR_LOADER_THREADS or the core count).
 static bool load_stack(const std::string &folder, const std::string &prefix, const std::string &suffix, int n, int w, int h,
                        std::vector<Image8> &imgs, std::string &err)
 {
     imgs.clear();
-    for (int i = 0; i < n; i++) {
-        std::ostringstream p;
-        p << folder << prefix << i;
-        Image8 img = imread_gray(p.str() + suffix);
-        if (img.empty() && suffix != ".pgm") img = imread_gray(p.str() + ".pgm");
-        if (img.empty()) { err = "Scan Images not found! (" + p.str() + suffix + ")"; warn("Load Images", err); return false; }
-        if (img.w != w || img.h != h) { err = "image size differs from the configured camera size"; warn("Load Images", err); return false; }
-        imgs.push_back(img);
-    }
+    imgs.resize(n > 0 ? n : 0);
+    std::vector<std::string> errs(n > 0 ? n : 0);
+    std::atomic<int> next(0);
+    auto work = [&]() {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            std::ostringstream p;
+            p << folder << prefix << i;
+            Image8 img = imread_gray(p.str() + suffix);
+            if (img.empty() && suffix != ".pgm") img = imread_gray(p.str() + ".pgm");
+            if (img.empty()) { errs[i] = "Scan Images not found! (" + p.str() + suffix + ")"; continue; }
+            if (img.w != w || img.h != h) { errs[i] = "image size differs from the configured camera size"; continue; }
+            imgs[i] = std::move(img);
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = getenv("SLR_LOADER_THREADS")) nt = (unsigned)atoi(e);
+    if (nt < 1) nt = 1;
+    if (nt > (unsigned)n) nt = (unsigned)(n > 0 ? n : 1);
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    for (int i = 0; i < n; i++)                              // first failing file in index order, like the sequential loop
+        if (!errs[i].empty()) { err = errs[i]; warn("Load Images", err); imgs.clear(); return false; }
     return true;
 }
 

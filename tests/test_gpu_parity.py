@@ -250,6 +250,31 @@ def test_gray_decode_parity(ctx, oracle, synth, W, H, rows):
     assert 0 < ev.mean() < 1
 
 
+def test_config3_gray_plus_phase_share_white_black(ctx, oracle, synth):
+    """BASELINE config 3: one 38-plane stack per camera = white, black, 12 Gray bit pairs, 12 fringe planes; the Gray and
+    the multi-frequency decode both read the SAME white/black planes (plane pointers, no copies).  The reference has
+    no Gray+phase fusion (three exclusive modes), so each decode is checked against the oracle on its own."""
+    W, H, scan_w = 512, 96, 4096
+    ncol = synth.gray_num_bits(scan_w)
+    assert ncol == 12
+    g = synth.render_gray_stack(W, H, scan_w, seed=5)                 # [2][26][H][W]
+    m = synth.render_mf_stack(W, H, seed=5)                           # [2][14][H][W]
+    for cam in range(2):
+        stack = torch.cat([g[cam], m[cam, 2:]], 0).contiguous()       # 26 + 12 = 38 planes
+        assert stack.shape[0] == 38
+        gray_planes = [stack[i] for i in range(26)]
+        mf_planes = [stack[0], stack[1]] + [stack[26 + i] for i in range(12)]
+        ex, _, ev = oracle.gray_decode(np.stack([p.numpy() for p in gray_planes]), ncol, 0, BLACK, 0, scan_w, 0)
+        eph, epv = oracle.mf_decode(np.stack([p.numpy() for p in mf_planes]), BLACK)
+        dev = stack.cuda()
+        cx, _, v = ctx.gray_decode([dev[i] for i in range(26)], ncol, 0, BLACK, 0, scan_w, 0)
+        ph, pv = ctx.mf_decode([dev[0], dev[1]] + [dev[26 + i] for i in range(12)], BLACK)
+        ctx.synchronize()
+        assert bits_equal(np_of(cx), ex) and bits_equal(np_of(v), ev)
+        assert bits_equal(np_of(pv), epv) and bits_equal(np_of(ph), eph)
+        assert ev.sum() > 0.5 * ev.size and epv.sum() > 0.3 * epv.size
+
+
 def test_gray_range_check_uses_greater_than(ctx, oracle):
     """Q9: xDec == scan_w passes (reconstruct.cpp:403 uses '>')"""
     w = 64
