@@ -991,10 +991,14 @@ __global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_c
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fused K1+K3, LDS-tiled form: same scheme as mf_rect_decode_lds_kernel with 64 x 4 tiles (one pixel per lane, one
-// pass) because a Gray stack has 22..66 planes.  LDS layout [row][plane][dword column] (the plane count is a run-time
-// value, so the per-plane step is one v_add instead of an immediate).
+// fused K1+K3, LDS-tiled form: the scheme of mf_rect_decode_lds_kernel for a Gray stack of 22..66 planes.  64 x TH
+// destination tiles, one pixel per lane, TH/4 passes: TH = 8 when the tile's source box fits the LDS budget for this
+// plane count (fill work and halo re-reads per pixel are ~3x lower than with 64 x 4), else TH = 4.  LDS layout
+// [row][plane][dword column] (the plane count is a run-time value, so the per-plane step is one add instead of an
+// immediate).  The samples stay in the high half-word of the dot-product accumulators (weights x 64, see
+// tile_taps_map) and are compared / subtracted in place.
 // ------------------------------------------------------------------------------------------------------
+template <int TH>
 __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl, int n_col_bits, int n_row_bits, int pitch,
                                                                    int W, int H, int black_thr, int white_thr, int scan_w,
                                                                    int scan_h, const int16_t *__restrict__ map_xy,
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl
                                                                    const int4 *__restrict__ boxes,
                                                                    int32_t *__restrict__ code_x, int32_t *__restrict__ code_y,
                                                                    uint8_t *__restrict__ valid, int tiles_x, int tiles_y,
-                                                                   int budget, int aligned)
+                                                                   int budget)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     const int NP = 2 + 2 * n_col_bits + 2 * n_row_bits;
@@ -1015,96 +1019,111 @@ __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl
     const bool any = BW4 > 0;
     const bool fits = any && (long long)BW4 * BH * 4 * NP <= budget;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = tx * kTileW + lane, row = ty * kGrayTileH + wv;
+    const unsigned lane31 = (unsigned)lane & 31u;
+    const int col = tx * kTileW + lane;
     const int rowstep = BW4 * 4;                            // bytes per (row, plane) line
 
     if (fits) {
+        // W % 4 == 0, x0 % 4 == 0 and dword-aligned planes (launcher): a source dword is inside or outside as a whole
         const int E = BH * BW4;
         const float inv = 1.0f / (float)BW4;
         for (int e = threadIdx.x; e < E; e += 256) {
             const int rr = (int)(((float)e + 0.5f) * inv);
             const int cc = e - rr * BW4;
             const int gx = x0 + 4 * cc, gy = y0 + rr;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
             uint8_t *dst = tile + (size_t)(rr * NP) * rowstep + 4 * cc;
-            if (aligned && (unsigned)gy < (unsigned)H && gx >= 0 && gx + 3 < W) {
-                const unsigned off = (unsigned)gy * (unsigned)pitch + (unsigned)gx;
-                // 16 independent loads in flight per thread, then 16 LDS stores (a plain p-loop waits per load)
-                for (int pb = 0; pb < NP; pb += 16) {
-                    unsigned v[16];
+            // 16 independent loads in flight per thread, then 16 LDS stores (a plain p-loop waits per load)
+            for (int pb = 0; pb < NP; pb += 16) {
+                unsigned v[16];
 #pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        v[i] = (pb + i < NP) ? *reinterpret_cast<const unsigned *>(pl.p[pb + i] + off) : 0u;
+                for (int i = 0; i < 16; i++)
+                    v[i] = (pb + i < NP) ? *reinterpret_cast<const unsigned *>(pl.p[pb + i] + off) : 0u;
 #pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = v[i];
-                }
-            } else {
-#pragma unroll 1
-                for (int p = 0; p < NP; p++)
-                    *reinterpret_cast<unsigned *>(dst + p * rowstep) = load_src_dword(pl.p[p], pitch, W, H, gx, gy);
+                for (int i = 0; i < 16; i++)
+                    if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = in ? v[i] : 0u;
             }
         }
         __syncthreads();
     }
-    const bool inb = row < H && col < W;
-    const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
-    Tap t = make_tap(0, 0, 0, pitch, W, H);
-    t.kind = 1;
-    if (inb) {
-        const unsigned xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * (size_t)m);
-        t = make_tap((int)(short)(xy & 0xFFFFu), (int)(short)(xy >> 16), map_frac[m], pitch, W, H);
-    }
-    // tap state shared by all planes
-    const bool out = t.kind == 1;
-    const int bx = out ? 0 : t.sx - x0, r0 = out ? 0 : t.sy - y0;
-    const unsigned sh = (unsigned)bx & 3u;
-    const unsigned sel = sh | 0x0C000C00u | ((sh + 1u) << 16);
-    const unsigned wx0 = out ? 0u : (unsigned)t.wx0, wx1 = out ? 0u : (unsigned)t.wx1;
-    u16x2 w0, w1;
-    w0.x = (unsigned short)__umul24(wx0, (unsigned)t.wy0); w0.y = (unsigned short)__umul24(wx1, (unsigned)t.wy0);
-    w1.x = (unsigned short)__umul24(wx0, (unsigned)t.wy1); w1.y = (unsigned short)__umul24(wx1, (unsigned)t.wy1);
-    const int a0 = fits ? (r0 * NP) * rowstep + (bx & ~3) : 0;
-    const int rowjump = NP * rowstep;                       // same plane, next source row
-    auto fetch = [&](int p) -> int {
-        if (fits) {
-            const unsigned *q0 = reinterpret_cast<const unsigned *>(tile + a0 + p * rowstep);
-            const unsigned *q1 = reinterpret_cast<const unsigned *>(tile + a0 + p * rowstep + rowjump);
-            const unsigned p0 = __builtin_amdgcn_perm(q0[1], q0[0], sel);
-            const unsigned p1 = __builtin_amdgcn_perm(q1[1], q1[0], sel);
-            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), w0, 512u, false);
-            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), w1, acc, false);
-            return (int)(acc >> 10);
+#pragma unroll 1
+    for (int q = 0; q < TH / 4; q++) {
+        const int row = ty * TH + 4 * q + wv;
+        const bool inb = row < H && col < W;
+        const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+        unsigned xy = 0, fr = 0;
+        if (inb) {
+            xy = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+            fr = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
         }
-        return any ? sample(pl.p[p], pitch, W, H, t) : 0;
-    };
-    const int wv_ = fetch(0), bv = fetch(1);
-    int gx_ = 0, gy_ = 0, err = 0;
+        int gx_ = 0, gy_ = 0, err = 0, mask;
+        if (fits) {
+            // tap state shared by all planes (tile_taps_map with this kernel's LDS layout)
+            const int sx = (int)(short)(xy & 0xFFFFu), sy = (int)xy >> 16;
+            const bool out = !inb || (unsigned)(sx + 1) > (unsigned)W || (unsigned)(sy + 1) > (unsigned)H;
+            const unsigned fx = fr & 31u, fy = (fr >> 5) & 31u;
+            const unsigned wxp = out ? 0u : __umul24(fx, 0xFFFFu) + 32u;
+            unsigned w0u = __umul24(wxp, (32u - fy) << 6);
+            const unsigned w1u = __umul24(wxp, fy << 6);
+            w0u = w0u == 0x10000u ? 0xFFFFu : w0u;
+            const u16x2 w0 = __builtin_bit_cast(u16x2, w0u), w1 = __builtin_bit_cast(u16x2, w1u);
+            const int bx = out ? 0 : sx - x0, r0 = out ? 0 : sy - y0;
+            const unsigned sel = __umul24((unsigned)bx & 3u, 0x10001u) + 0x0C010C00u;
+            const uint8_t *base = tile + __mul24(__mul24(r0, NP), rowstep) + (bx & ~3);
+            const int rowjump = __mul24(NP, rowstep);       // same plane, next source row
+            auto fetch = [&](int p) -> unsigned {             // accumulator: the sample is its high half-word
+                const unsigned *q0 = reinterpret_cast<const unsigned *>(base + __mul24(p, rowstep));
+                const unsigned *q1 = reinterpret_cast<const unsigned *>(base + __mul24(p, rowstep) + rowjump);
+                const unsigned p0 = __builtin_amdgcn_perm(q0[1], q0[0], sel);
+                const unsigned p1 = __builtin_amdgcn_perm(q1[1], q1[0], sel);
+                unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), w0, 512u << 6, false);
+                return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), w1, acc, false);
+            };
+            const unsigned aw = fetch(0), ab = fetch(1);
+            mask = ((int)(aw >> 16) - (int)(ab >> 16) > black_thr) ? 1 : 0;
 #pragma unroll 4
-    for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
-        const int v1 = fetch(2 * c + 2), v2 = fetch(2 * c + 3);
-        const int df = v1 - v2;
-        err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
-        gx_ = (gx_ << 1) | (v1 > v2 ? 1 : 0);
-    }
-    for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
-        const int v1 = fetch(2 * c + 2 + 2 * n_col_bits), v2 = fetch(2 * c + 3 + 2 * n_col_bits);
-        const int df = v1 - v2;
-        err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
-        gy_ = (gy_ << 1) | (v1 > v2 ? 1 : 0);
-    }
-    const int mask = (wv_ - bv > black_thr) ? 1 : 0;
-    const int x = gray_to_binary(gx_), y = gray_to_binary(gy_);
-    if (n_row_bits > 0) err |= (y > scan_h || x > scan_w) ? 1 : 0;   // reconstruct.cpp:364 (Q9 '>')
-    else err |= (x > scan_w) ? 1 : 0;                                // reconstruct.cpp:403
-    const int ok = mask & (err ^ 1);
-    unsigned vw = (unsigned)ok;
-    vw |= (unsigned)__shfl_down(ok, 1) << 8;
-    vw |= (unsigned)__shfl_down(ok, 2) << 16;
-    vw |= (unsigned)__shfl_down(ok, 3) << 24;
-    if (inb) {
-        __builtin_nontemporal_store(ok ? x : -1, code_x + m);
-        if (code_y) __builtin_nontemporal_store((ok && n_row_bits > 0) ? y : -1, code_y + m);
-        if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
+                const unsigned a1 = fetch(2 * c + 2), a2 = fetch(2 * c + 3);
+                const int df = (int)(a1 >> 16) - (int)(a2 >> 16);
+                err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gx_ = (gx_ << 1) | (df > 0 ? 1 : 0);
+            }
+            for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
+                const unsigned a1 = fetch(2 * c + 2 + 2 * n_col_bits), a2 = fetch(2 * c + 3 + 2 * n_col_bits);
+                const int df = (int)(a1 >> 16) - (int)(a2 >> 16);
+                err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gy_ = (gy_ << 1) | (df > 0 ? 1 : 0);
+            }
+        } else {                                            // wild map: direct gather for this tile
+            Tap t = make_tap((int)(short)(xy & 0xFFFFu), (int)xy >> 16, fr, pitch, W, H);
+            if (!inb) t.kind = 1;
+            auto fetch = [&](int p) -> int { return any ? sample(pl.p[p], pitch, W, H, t) : 0; };
+            const int wv_ = fetch(0), bv = fetch(1);
+            mask = (wv_ - bv > black_thr) ? 1 : 0;
+            for (int c = 0; c < n_col_bits; c++) {
+                const int df = fetch(2 * c + 2) - fetch(2 * c + 3);
+                err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gx_ = (gx_ << 1) | (df > 0 ? 1 : 0);
+            }
+            for (int c = 0; c < n_row_bits; c++) {
+                const int df = fetch(2 * c + 2 + 2 * n_col_bits) - fetch(2 * c + 3 + 2 * n_col_bits);
+                err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gy_ = (gy_ << 1) | (df > 0 ? 1 : 0);
+            }
+        }
+        const int x = gray_to_binary(gx_), y = gray_to_binary(gy_);
+        if (n_row_bits > 0) err |= (y > scan_h || x > scan_w) ? 1 : 0;   // reconstruct.cpp:364 (Q9 '>')
+        else err |= (x > scan_w) ? 1 : 0;                                // reconstruct.cpp:403
+        const int ok = mask & (err ^ 1);
+        const unsigned long long bal = __ballot(ok != 0);    // valid bytes of 4 lanes -> one dword (see the MF kernel)
+        const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+        const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+        if (inb) {
+            __builtin_nontemporal_store(ok ? x : -1, code_x + m);
+            if (code_y) __builtin_nontemporal_store((ok && n_row_bits > 0) ? y : -1, code_y + m);
+            if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+        }
     }
 }
 
@@ -1114,16 +1133,29 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
                               const void *tile_boxes, int rect_algo, hipStream_t s)
 {
     const int nplanes = 2 + 2 * n_col_bits + 2 * n_row_bits;
-    if (map_xy && tile_boxes && W % 4 == 0 && rect_algo != 1 && ((uintptr_t)valid % 4 == 0)) {
-        bool aligned = pitch % 4 == 0;
-        for (int p = 0; p < nplanes; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
-        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (H + kGrayTileH - 1) / kGrayTileH;
+    bool aligned = pitch % 4 == 0;
+    for (int p = 0; p < nplanes; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
+    if (map_xy && tile_boxes && W % 4 == 0 && aligned && rect_algo != 1 && ((uintptr_t)valid % 4 == 0) &&
+        (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32)) {
+        const int tiles_x = (W + kTileW - 1) / kTileW;
+        // 64 x 8 tiles when a typical box (72 source bytes x 11 rows) of all planes fits 32 KB, else 64 x 4; the LDS
+        // request is sized for a generous box of this plane count (boxes beyond it take the per-tile gather fallback)
+        const bool mid = (size_t)nplanes * 72 * 11 <= 32 * 1024 && rect_algo != 2;
+        const int th = mid ? kMidTileH : kGrayTileH;
+        size_t want = (size_t)nplanes * 76 * (mid ? 12 : 7);
+        want = want < 8 * 1024 ? 8 * 1024 : (want > 32 * 1024 ? 32 * 1024 : want);
+        const int budget = (int)((want + 255) & ~(size_t)255);
+        const int tiles_y = (H + th - 1) / th;
         const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
-        const int budget = 32 * 1024;
-        const int4 *boxes = (const int4 *)tile_boxes + tile_count(W, H, kTileH);
-        hipLaunchKernelGGL(gray_rect_decode_lds_kernel, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl, n_col_bits,
-                           n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac, boxes, code_x,
-                           code_y, valid, tiles_x, tiles_y, budget, aligned ? 1 : 0);
+        const int4 *boxes = (const int4 *)tile_boxes + tile_count(W, H, kTileH) + (mid ? tile_count(W, H, kGrayTileH) : 0);
+        if (mid)
+            hipLaunchKernelGGL(gray_rect_decode_lds_kernel<kMidTileH>, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,
+                               n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac,
+                               boxes, code_x, code_y, valid, tiles_x, tiles_y, budget);
+        else
+            hipLaunchKernelGGL(gray_rect_decode_lds_kernel<kGrayTileH>, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,
+                               n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac,
+                               boxes, code_x, code_y, valid, tiles_x, tiles_y, budget);
         return hipGetLastError();
     }
     bool a4 = (W % 4 == 0) && ((uintptr_t)code_x % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
