@@ -618,13 +618,16 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 
 // ------------------------------------------------------------------------------------------------------
 // K5: one workgroup per row.
-//   1. keys (code<<16 | k) of the valid right pixels are bitonic-sorted in LDS -> for every code an
-//      ascending list of columns.
-//   2. wave 0 walks the left row 64 pixels at a time.  The reference carries `kstart` from match to match
-//      (reconstruct.cpp:556,561,604), a sequential dependency.  Each lane first searches with the incoming
-//      kstart (speculation); an exclusive prefix-max over the lanes' matches (wave shuffles) gives every
-//      lane the kstart it would really have seen; lanes whose kstart moved re-search.  Lane l is final after
-//      at most l rounds, a fixed point equals the sequential answer, and monotone rows finish in one round.
+//   1. keys (code<<16 | k) of the valid right pixels are radix-sorted in LDS on the code bits (stable) -> for every
+//      code an ascending list of columns, with a direct list-head table first[code].
+//   2. The reference carries `kstart` from match to match (reconstruct.cpp:556,561,604): pixel j searches its code's
+//      list from the column of the LAST match of any earlier pixel -- a sequential dependency along the row.  It is
+//      resolved as a fixed point over the whole row at once: thread t owns IPT consecutive left pixels and walks
+//      them sequentially (exact, given its incoming kstart ks_in(t)); ks_in(t) is the exclusive prefix max of the
+//      threads' last matches (one block scan).  Round 1 speculates ks_in = 0.  kstart only ever grows, and a thread's
+//      results stay valid as long as its new ks_in does not pass its FIRST match, so on the usual monotone rows
+//      nothing is redone: one walk + one scan.  Thread t is final after at most t+1 rounds; a fixed point equals the
+//      sequential answer (induction over t), which the adversarial tests check against the oracle.
 // ------------------------------------------------------------------------------------------------------
 template <int IPT>
 __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
@@ -636,14 +639,16 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
 {
     constexpr int N = 256 * IPT;
     typedef hipcub::BlockRadixSort<unsigned, 256, IPT> Sort;
+    typedef hipcub::BlockScan<int, 256> ScanI;
     __shared__ union { typename Sort::TempStorage sort; unsigned S[N]; } sh;
     __shared__ short mk[N];                        // match column per left pixel (-1 = none), written by the walk
+    __shared__ typename ScanI::TempStorage scan_tmp;
     extern __shared__ unsigned short first[];      // TC list heads: first[code] = index in S of the code's smallest
     unsigned *S = sh.S;                            // column (0xFFFF = none)
     const int row = blockIdx.x;
     const size_t base = (size_t)row * W;
     // keys (code << 16 | k) in blocked order (= ascending k); a stable radix sort on the 16 code bits alone keeps the
-    // columns of every code ascending: 2 passes of 8 bits instead of a 78-stage bitonic network
+    // columns of every code ascending
     unsigned keys[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
@@ -662,54 +667,60 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
             first[v >> 16] = (unsigned short)i;
     }
     __syncthreads();
-    if (threadIdx.x < 64) {                        // wave 0 walks the row; the matches go to LDS
-    const int lane = threadIdx.x;
-    int ks = 0;                                    // reconstruct.cpp:556
-    for (int j0 = 0; j0 < W; j0 += 64) {
-        const int j = j0 + lane;
-        const bool inb = j < W;
-        const int c = (inb && validL[base + j]) ? codeL[base + j] : -1;
-        int my_ks = ks, m = -1, inc = -1;
-        while (true) {
-            m = -1;
-            if (c >= 0) {
-                const unsigned target = ((unsigned)c << 16) | (unsigned)my_ks;
-                int lo = 0, hi = N;                // first index with S[idx] >= target
-                if (c < TC) {
-                    // direct list head, then a short forward scan over the code's ascending columns; only long
-                    // lists (degenerate rows) fall back to the binary search, restricted to [lo, N)
-                    const unsigned f = first[c];
-                    lo = f == 0xFFFFu ? N : (int)f;
-                    int steps = 0;
-                    while (lo < N && S[lo] < target && steps < 6) { lo++; steps++; }
-                    if (lo >= N || S[lo] >= target) hi = lo;
-                }
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (S[mid] < target) lo = mid + 1; else hi = mid;
-                }
-                if (lo < N) {
-                    const unsigned v = S[lo];
-                    if ((v >> 16) == (unsigned)c) m = (int)(v & 0xFFFFu);
-                }
-            }
-            inc = m;                               // inclusive prefix max over lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(inc, d);
-                if (lane >= d) inc = inc > t ? inc : t;
-            }
-            int exc = __shfl_up(inc, 1);
-            if (lane == 0) exc = -1;
-            const int new_ks = ks > exc ? ks : exc;
-            const bool changed = (c >= 0) && (new_ks != my_ks);
-            my_ks = new_ks;
-            if (!__any(changed)) break;
+
+    // smallest column >= ks in code c's list, or -1
+    auto find = [&](int c, int ks) -> int {
+        const unsigned target = ((unsigned)c << 16) | (unsigned)ks;
+        int lo = 0, hi = N;                        // first index with S[idx] >= target
+        if (c < TC) {
+            // direct list head, then a short forward scan over the code's ascending columns; only long lists
+            // (degenerate rows) fall back to the binary search, restricted to [lo, N)
+            const unsigned f = first[c];
+            lo = f == 0xFFFFu ? N : (int)f;
+            int steps = 0;
+            while (lo < N && S[lo] < target && steps < 6) { lo++; steps++; }
+            if (lo >= N || S[lo] >= target) hi = lo;
         }
-        const int last = __shfl(inc, 63);
-        ks = ks > last ? ks : last;                // kstart = k of the last match (reconstruct.cpp:604)
-        if (inb) mk[j] = (short)m;                 // W <= 32768: columns fit 15 bits, -1 = no match
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (S[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        if (lo < N) {
+            const unsigned v = S[lo];
+            if ((v >> 16) == (unsigned)c) return (int)(v & 0xFFFFu);
+        }
+        return -1;
+    };
+
+    const int j0 = threadIdx.x * IPT;
+    int cl[IPT];                                   // this thread's left codes (-1 = no code)
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const int j = j0 + i;
+        cl[i] = (j < W && validL[base + j]) ? codeL[base + j] : -1;
     }
+    int ks_in = 0, lm = -1, fm = 0x7FFFFFFF;       // incoming kstart, last and first match of this thread
+    bool dirty = true;
+    for (;;) {
+        if (dirty) {
+            int ks = ks_in;                        // reconstruct.cpp:556 / :604
+            lm = -1; fm = 0x7FFFFFFF;
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                int m = -1;
+                if (cl[i] >= 0) {
+                    m = find(cl[i], ks);
+                    if (m >= 0) { ks = m; lm = m; if (fm == 0x7FFFFFFF) fm = m; }
+                }
+                if (j0 + i < W) mk[j0 + i] = (short)m;     // W <= 32768: columns fit 15 bits, -1 = no match
+            }
+        }
+        int exc;
+        ScanI(scan_tmp).ExclusiveScan(lm, exc, -1, hipcub::Max());
+        const int new_in = exc > 0 ? exc : 0;
+        dirty = new_in > fm;                       // kstart passed this thread's first match: its walk must be redone
+        ks_in = new_in > ks_in ? new_in : ks_in;
+        if (!__syncthreads_or(dirty ? 1 : 0)) break;
     }
     __syncthreads();
     // all four waves: reprojection + coalesced stores
