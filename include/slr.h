@@ -40,6 +40,9 @@ extern "C" {
 #define SLR_MF_PLANES 14           /* mfreconstruct.cpp:22 numberOfImgs: white, black, 3 freq x 4 steps */
 #define SLR_MAX_GRAY_BITS 16       /* per axis; reference allows 44 planes total (graycodes.h:12) */
 #define SLR_MAX_GRAY_PLANES (2 + 4 * SLR_MAX_GRAY_BITS)
+#define SLR_MFN_MAX_FREQ 6         /* generalised multi-frequency decode (build extension, slr_mfn_decode) */
+#define SLR_MFN_MAX_STEPS 16
+#define SLR_MFN_MAX_PLANES (2 + SLR_MFN_MAX_FREQ * SLR_MFN_MAX_STEPS)
 
 typedef enum slr_status {
     SLR_OK = 0,
@@ -122,6 +125,17 @@ int slr_mf_decode(slr_ctx *ctx, const uint8_t *const planes[SLR_MF_PLANES], int 
 int slr_mf_rectify_decode(slr_ctx *ctx, int cam, const uint8_t *const planes[SLR_MF_PLANES], int pitch,
                           int W, int H, int black_thr, float *phase, uint8_t *valid, slr_mem mem);
 
+/* ---- BUILD EXTENSION, no reference counterpart (the reference is hard-wired to 3 frequencies x 4 steps of u8,
+ * mfreconstruct.cpp:21-22,237-242; BASELINE config 5; parity unpinned): n_freq x n_step phase-shift decode of fp16
+ * planes with f32 accumulation.  planes[0] = white, planes[1] = black, planes[2 + f*n_step + k] = shift k (phase
+ * offset 2*pi*k/n_step) of frequency f; elements are IEEE binary16 bit patterns, pitch in ELEMENTS.  Keeps the
+ * reference's structure: shadow mask white - black > black_thr (mfreconstruct.cpp:190-207), one wrapped phase per
+ * frequency (here atan2 of the n_step-point DFT bin, in [0, 2 pi)), the heterodyne cascade of neighbouring differences
+ * with the "a > b ? a-b : a-b+2pi" rule (:265-267) down to one value, output scaled to 0..255 (:268).  valid = mask &&
+ * every frequency has a modulation amplitude above half a grey level.  2 <= n_freq <= SLR_MFN_MAX_FREQ, 3 <= n_step <= SLR_MFN_MAX_STEPS. */
+int slr_mfn_decode(slr_ctx *ctx, const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                   float black_thr, float *phase, uint8_t *valid, slr_mem mem);
+
 /* ---- K3 / K3': Reconstruct::computeShadows + decodePatterns_GE/getProjPixel_GE (reconstruct.cpp:79-97,
  * 210-227,381-407) or decodePaterns/getProjPixel (:56-74,:325-370) + GrayCodes::grayToDec
  * (graycodes.cpp:116-128).  n_row_bits==0 -> GRAY_EPI (code_y may be NULL).  code = -1 where invalid. */
@@ -140,6 +154,12 @@ int slr_gray_rectify_decode(slr_ctx *ctx, int cam, const uint8_t *const *planes,
 int slr_mf_triangulate(slr_ctx *ctx, const float *phaseL, const uint8_t *validL,
                        const float *phaseR, const uint8_t *validR, int W, int H,
                        float *xyz, uint8_t *has, int32_t *match_k, slr_mem mem);
+
+/* the same for a band of `rows` image rows starting at row0 of an H-row image (arrays are [rows][W]): the match is
+ * row-local, only the reprojection needs the absolute row.  This is how ONE frame shards over GPUs by row bands. */
+int slr_mf_triangulate_rows(slr_ctx *ctx, const float *phaseL, const uint8_t *validL,
+                            const float *phaseR, const uint8_t *validR, int W, int H, int row0, int rows,
+                            float *xyz, uint8_t *has, int32_t *match_k, slr_mem mem);
 
 /* ---- K5: Reconstruct::triangulation_ge (reconstruct.cpp:555-611).  whiteL/whiteR: rectified white planes
  * (pitch W) or NULL; color [H][W] u8 grey or NULL (haveColor, reconstruct.cpp:597-601). */

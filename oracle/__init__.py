@@ -137,6 +137,20 @@ def mf_decode(planes, black_thr, W=None):
     return phase, valid
 
 
+def mfn_decode_f64(planes, n_freq, n_step, black_thr, W=None):
+    """BUILD EXTENSION model (no reference counterpart): planes [2+F*N][H][pitch] float16 -> (phase f64, valid u8)."""
+    planes = np.ascontiguousarray(planes).view(np.uint16)
+    n, H, pitch = planes.shape
+    assert n == 2 + n_freq * n_step
+    W = pitch if W is None else W
+    ptrs = (C.c_void_p * n)(*[planes[i].ctypes.data for i in range(n)])
+    phase = np.empty((H, W), np.float64)
+    valid = np.empty((H, W), np.uint8)
+    lib().slro_mfn_decode_f64(ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch), C.c_int(W), C.c_int(H),
+                              C.c_double(black_thr), _p(phase), _p(valid))
+    return phase, valid
+
+
 def wrapped_phase(G1, G2, G3, G4):
     P = C.c_float(0)
     ok = lib().slro_wrapped_phase(C.c_int(G1), C.c_int(G2), C.c_int(G3), C.c_int(G4), C.byref(P))

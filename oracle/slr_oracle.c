@@ -597,3 +597,46 @@ void slro_pointcloud_get(const float *pc_sum, const uint8_t *pc_count, int n, fl
         out[3 * i + 2] = (float)((double)pc_sum[3 * i + 2] / dnum);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* build extension (no reference counterpart): fp64 model of the generalised n_freq x n_step decode   */
+/* ------------------------------------------------------------------------------------------------ */
+static double slro_half_to_double(uint16_t h)
+{
+    const int sign = h >> 15, e = (h >> 10) & 31, m = h & 1023;
+    double v;
+    if (e == 0) v = ldexp((double)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexp((double)(m + 1024), e - 25);
+    return sign ? -v : v;
+}
+
+void slro_mfn_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                         double black_thr, double *phase, uint8_t *valid)
+{
+    const double PI = 3.14159265358979323846, TWO_PI = 2 * PI;
+    double D[16];
+    for (int row = 0; row < H; row++)
+        for (int col = 0; col < W; col++) {
+            const size_t s = (size_t)row * pitch + col, o = (size_t)row * W + col;
+            const int mask = slro_half_to_double(planes[0][s]) - slro_half_to_double(planes[1][s]) > black_thr;
+            int ok = mask;
+            for (int f = 0; f < n_freq; f++) {
+                double S = 0, C = 0;
+                for (int k = 0; k < n_step; k++) {
+                    const double I = slro_half_to_double(planes[2 + f * n_step + k][s]);
+                    S += I * sin(TWO_PI * k / n_step);
+                    C += I * cos(TWO_PI * k / n_step);
+                }
+                double p = atan2(-S, C);
+                if (p < 0) p += TWO_PI;
+                if (!(S * S + C * C > (0.25 * n_step) * (0.25 * n_step))) ok = 0;   /* modulation < 0.5 grey levels */
+                D[f] = p;
+            }
+            for (int lvl = 1; lvl < n_freq; lvl++)
+                for (int i = 0; i + lvl < n_freq; i++)
+                    D[i] = (D[i] > D[i + 1]) ? (D[i] - D[i + 1]) : (D[i] - D[i + 1] + TWO_PI);
+            phase[o] = mask ? D[0] / TWO_PI * 255 : 0.0;
+            valid[o] = (uint8_t)ok;
+        }
+}

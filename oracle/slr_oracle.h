@@ -134,6 +134,14 @@ void slro_pointcloud_from_grid(const float *xyz, const uint8_t *has, const uint8
 /* getPoint: sum / (float)count, pointcloudimage.cpp:56-67 ; out [n][3] */
 void slro_pointcloud_get(const float *pc_sum, const uint8_t *pc_count, int n, float *out);
 
+/* ---- BUILD EXTENSION, NO REFERENCE COUNTERPART (BASELINE config 5; parity unpinned by construction) --------
+ *      fp64 model of the generalised n_freq x n_step decode that slr_mfn_decode implements: planes are IEEE
+ *      binary16 bit patterns, planes[0] white, planes[1] black, planes[2 + f*n_step + k]; phase in f64
+ *      (0 where shadow-masked), valid = mask && every frequency has modulation.  Not a restatement of anything in
+ *      /root/reference: the reference is hard-wired to 3 x 4 steps of u8 (mfreconstruct.cpp:21-22,237-242). */
+void slro_mfn_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                         double black_thr, double *phase, uint8_t *valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,4 +94,15 @@ if "--ray" in sys.argv:
     d2 = [ctx.gray_decode(g2[cam], nc, nr, 40, 0, sw, sh) for cam in range(2)]
     run("gray_decode col+row", lambda: ctx.gray_decode(g2[0], nc, nr, 40, 0, sw, sh), 2 + 2 * (nc + nr) + 9.0)
     run("ray (keys+sort+triangulate)", lambda: ctx.ray_triangulate(d2[0][0], d2[0][1], d2[0][2], d2[1][0], d2[1][1], d2[1][2], sw, sh), 31.0)
+if "--mfn" in sys.argv:
+    # BASELINE config 5 (build extension): 8192x6000, 4 freq x 8 step, fp16 planes -> 73 B/px algorithmic
+    W5, H5, F5, N5 = 8192, 6000, 4, 8
+    del st
+    torch.cuda.empty_cache()
+    st5 = synth.render_mfn_stack(W5, H5, F5, N5, device=dev)[0].contiguous()
+    torch.cuda.synchronize()
+    p5 = torch.empty((H5, W5), dtype=torch.float32, device=dev)
+    v5 = torch.empty((H5, W5), dtype=torch.uint8, device=dev)
+    npx = float(W5) * H5
+    run("mfn_decode 8192x6000 4x8 fp16", lambda: ctx.mfn_decode(st5, F5, N5, 40.0, phase=p5, valid=v5), 2.0 * (2 + F5 * N5) + 5.0)
 ctx.close()

@@ -25,8 +25,9 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED
 SYMBOLS = [
     "slr_version", "slr_status_string", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
     "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_init_rectify_maps",
-    "slr_get_rectify_maps", "slr_remap_u8", "slr_mf_decode",
+    "slr_get_rectify_maps", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
+    "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
@@ -142,9 +143,10 @@ def _plane_ptrs(planes):
         return arr, n, H, pitch
     n, H, pitch = planes.shape
     base = _ptr(planes).value
+    isz = planes.element_size() if _is_torch(planes) else planes.itemsize
     arr = (C.c_void_p * n)()
     for i in range(n):
-        arr[i] = base + i * H * pitch
+        arr[i] = base + i * H * pitch * isz
     return arr, n, H, pitch
 
 
@@ -258,6 +260,21 @@ class Context:
         self._chk(st)
         return phase, valid
 
+    # -- build extension (no reference counterpart): n_freq x n_step fp16 decode
+    def mfn_decode(self, planes, n_freq, n_step, black_thr, W=None, phase=None, valid=None):
+        """planes: [2 + n_freq*n_step][H][pitch] float16 (numpy = host, torch.cuda = device)."""
+        ptrs, n, H, pitch = _plane_ptrs(planes)
+        assert n == 2 + n_freq * n_step
+        first = _flat(planes)[0]
+        assert (first.element_size() if _is_torch(first) else first.itemsize) == 2
+        W = pitch if W is None else W
+        mem = _mem_of(_flat(planes) + [phase, valid])
+        phase = self._new(mem, (H, W), np.float32, first) if phase is None else phase
+        valid = self._new(mem, (H, W), np.uint8, first) if valid is None else valid
+        self._chk(self.lib.slr_mfn_decode(self.h, ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch), C.c_int(W),
+                                          C.c_int(H), C.c_float(black_thr), _ptr(phase), _ptr(valid), C.c_int(mem)))
+        return phase, valid
+
     # -- K3 / K3'
     def gray_decode(self, planes, n_col_bits, n_row_bits, black_thr, white_thr, scan_w, scan_h, W=None,
                     rectify_cam=None):
@@ -280,14 +297,20 @@ class Context:
         return cx, cy, valid
 
     # -- K4
-    def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True):
+    def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True, row0=0, image_h=None):
+        """row0 / image_h: the arrays are a band of rows [row0, row0 + H) of an image_h-row image (row-band sharding)."""
         H, W = phaseL.shape
         mem = _mem_of([phaseL, validL, phaseR, validR])
         xyz = self._new(mem, (H, W, 3), np.float32, phaseL)
         has = self._new(mem, (H, W), np.uint8, phaseL)
         mk = self._new(mem, (H, W), np.int32, phaseL) if want_match else None
-        self._chk(self.lib.slr_mf_triangulate(self.h, _ptr(phaseL), _ptr(validL), _ptr(phaseR), _ptr(validR),
-                                              C.c_int(W), C.c_int(H), _ptr(xyz), _ptr(has), _ptr(mk), C.c_int(mem)))
+        if image_h is None and row0 == 0:
+            self._chk(self.lib.slr_mf_triangulate(self.h, _ptr(phaseL), _ptr(validL), _ptr(phaseR), _ptr(validR),
+                                                  C.c_int(W), C.c_int(H), _ptr(xyz), _ptr(has), _ptr(mk), C.c_int(mem)))
+        else:
+            self._chk(self.lib.slr_mf_triangulate_rows(self.h, _ptr(phaseL), _ptr(validL), _ptr(phaseR), _ptr(validR),
+                                                       C.c_int(W), C.c_int(H if image_h is None else image_h), C.c_int(row0),
+                                                       C.c_int(H), _ptr(xyz), _ptr(has), _ptr(mk), C.c_int(mem)))
         return xyz, has, mk
 
     # -- K5

@@ -90,12 +90,12 @@ __device__ __forceinline__ void apply_T(const float *T, float X[3])
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                        const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
-                                                       int W, int H, DevCalib cal, float *__restrict__ xyz,
+                                                       int W, int H, int row0, DevCalib cal, float *__restrict__ xyz,
                                                        uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
 {
     extern __shared__ float phR[];                 // W rounded up to a multiple of 4, NaN padded
-    const int row = blockIdx.x;
-    const size_t base = (size_t)row * W;
+    const int row = blockIdx.x + row0;                   // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)blockIdx.x * W;
     const int Wp = (W + 3) & ~3;
     for (int k = threadIdx.x; k < Wp; k += 256)
         phR[k] = (k < W && validR[base + k]) ? phaseR[base + k] : __builtin_nanf("");
@@ -203,6 +203,7 @@ __device__ __forceinline__ void load_u8_blocked(const uint8_t *__restrict__ p, i
 // reprojection and wide stores (mfreconstruct.cpp:297-326)
 template <int IPT>
 __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0, int row, int W, bool vec,
+                                        /* base: band-local pixel offset of the row; the tables use the absolute row */
                                         const DevCalib &cal, const float2 *__restrict__ undL,
                                         const float *__restrict__ undRx, float *__restrict__ xyz,
                                         uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
@@ -214,9 +215,9 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
         for (int i = 0; i < IPT; i++) {
             ulx[i] = uly[i] = urx[i] = 0.0f;
             if (best[i] >= 0) {
-                const float2 u = undL[base + k0 + i];
+                const float2 u = undL[(size_t)row * W + k0 + i];
                 ulx[i] = u.x; uly[i] = u.y;
-                urx[i] = undRx[base + best[i]];
+                urx[i] = undRx[(size_t)row * W + best[i]];
             }
         }
     } else {
@@ -284,7 +285,7 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
 template <int BLOCK, int IPT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binned_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                                 const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
-                                                                int W, int H, DevCalib cal, int vec_ok,
+                                                                int W, int H, int row0, DevCalib cal, int vec_ok,
                                                                 const float2 *__restrict__ undL, const float *__restrict__ undRx,
                                                                 float *__restrict__ xyz,
                                                                 uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
@@ -300,8 +301,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     } sh;
     __shared__ typename ScanU::TempStorage scan_tmp;
 
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const size_t base = (size_t)row * W;
+    const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)blockIdx.x * W;
     const int k0 = tid * IPT;
     const bool vec = (vec_ok & 1) != 0;
     const int stop = vec_ok >> 8;                        // debug: leave after phase N (SLR_DEBUG_K4_STOP), 0 = run all
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
 template <int BLOCK, int IPT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
-                                                              int W, int H, DevCalib cal, int vec_ok,
+                                                              int W, int H, int row0, DevCalib cal, int vec_ok,
                                                               const float2 *__restrict__ undL, const float *__restrict__ undRx,
                                                               float *__restrict__ xyz,
                                                               uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     __shared__ unsigned chunk_min[BLOCK];
     __shared__ typename ScanU::TempStorage scanu_tmp;
 
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const size_t base = (size_t)row * W;
+    const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)blockIdx.x * W;
     const int k0 = tid * IPT;
     const bool vec = (vec_ok & 1) != 0;
     const int stop = vec_ok >> 8;                        // debug: leave after phase N (SLR_DEBUG_K4_STOP), 0 = run all
@@ -582,7 +583,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 // algo: 0 = auto (binned indexed form when the row fits 8192 items, else the sweep), 1 = sweep, 2 = sorted indexed form,
 // 3 = binned indexed form
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
-                           int W, int H, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
+                           int W, int H, int row0, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
                            int algo, const float *undL_xy, const float *undRx, hipStream_t s)
 {
     const float2 *undL = (const float2 *)undL_xy;
@@ -595,10 +596,10 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
     do {                                                                                                           \
         if (algo == 2)                                                                                             \
             hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
-                               phaseR, validR, W, H, cal, vec_ok, undL, undRx, xyz, has, match_k);                 \
+                               phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
         else                                                                                                       \
             hipLaunchKernelGGL((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
-                               phaseR, validR, W, H, cal, vec_ok, undL, undRx, xyz, has, match_k);                 \
+                               phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
     } while (0)
         // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
         if (W <= 256) SLR_SORTED(256, 1);
@@ -611,7 +612,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         return hipGetLastError();
     }
     const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, cal,
+    hipLaunchKernelGGL(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, row0, cal,
                        xyz, has, match_k);
     return hipGetLastError();
 }

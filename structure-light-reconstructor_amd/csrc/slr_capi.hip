@@ -22,7 +22,7 @@ const char *kKernelNames[K_COUNT] = {
     "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
     "slr_ray_triangulate",
-    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair"};
+    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair", "slr_mfn_decode"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -246,8 +246,10 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
 
 // K4 with the per-(calibration,size) undistortion tables (built lazily, invalidated by slr_set_calibration)
 int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *phR, const uint8_t *vR, int W, int H,
-                  float *xyz, uint8_t *has, int32_t *match_k)
+                  float *xyz, uint8_t *has, int32_t *match_k, int row0 = 0, int rows = -1)
 {
+    // H: height of the IMAGE (tables); the arrays hold `rows` rows starting at image row row0 (default: all of it)
+    if (rows < 0) rows = H;
     const size_t n = (size_t)W * H;
     const float *undL = nullptr, *undR = nullptr;
     if (c->opt_mf_match_algo != 1 && W <= 256 * 32) {
@@ -263,7 +265,7 @@ int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *
         undL = (const float *)a; undR = (const float *)b;
     }
     ProfScope ps(c, K_MF_MATCH);
-    SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, H, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
+    SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, rows, row0, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
                                c->stream));
     return SLR_OK;
 }
@@ -587,6 +589,43 @@ static int gray_decode_entry(slr_ctx *c, int cam, bool rectify, const uint8_t *c
     return st.finish();
 }
 
+int slr_mfn_decode(slr_ctx *c, const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                   float black_thr, float *phase, uint8_t *valid, slr_mem mem)
+{
+    if (!c || !planes || !phase || !valid) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (n_freq < 2 || n_freq > SLR_MFN_MAX_FREQ || n_step < 3 || n_step > SLR_MFN_MAX_STEPS)
+        return fail(c, SLR_ERR_INVALID_ARG, "n_freq must be 2..6 and n_step 3..16");
+    const int np = 2 + n_freq * n_step;
+    for (int i = 0; i < np; i++) if (!planes[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    const uint16_t *dp[SLR_MFN_MAX_PLANES];
+    void *dph, *dv;
+    if (mem == SLR_MEM_DEVICE) {
+        for (int i = 0; i < np; i++) dp[i] = planes[i];
+        dph = phase; dv = valid;
+    } else {                                             // one contiguous staging buffer for the whole stack
+        const size_t plane = (size_t)pitch * H * 2, n = (size_t)W * H;
+        void *d;
+        SLR_TRY(get_scratch(c, S_STAGE0, plane * np, &d));
+        for (int i = 0; i < np; i++) {
+            SLR_HIP(c, hipMemcpyAsync((uint8_t *)d + plane * i, planes[i], plane, hipMemcpyHostToDevice, c->stream));
+            dp[i] = (const uint16_t *)((uint8_t *)d + plane * i);
+        }
+        SLR_TRY(get_scratch(c, S_STAGE0 + 1, n * 4, &dph));
+        SLR_TRY(get_scratch(c, S_STAGE0 + 2, n, &dv));
+    }
+    { ProfScope ps(c, K_MFN_DECODE);
+      SLR_HIP(c, launch_mfn_decode(dp, n_freq, n_step, pitch, W, H, black_thr, (float *)dph, (uint8_t *)dv, c->stream)); }
+    if (mem != SLR_MEM_DEVICE) {
+        const size_t n = (size_t)W * H;
+        SLR_HIP(c, hipMemcpyAsync(phase, dph, n * 4, hipMemcpyDeviceToHost, c->stream));
+        SLR_HIP(c, hipMemcpyAsync(valid, dv, n, hipMemcpyDeviceToHost, c->stream));
+        SLR_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return SLR_OK;
+}
+
 int slr_gray_decode(slr_ctx *c, const uint8_t *const *planes, int ncol, int nrow, int pitch, int W, int H,
                     int black_thr, int white_thr, int scan_w, int scan_h, int32_t *cx, int32_t *cy, uint8_t *valid,
                     slr_mem mem)
@@ -619,6 +658,28 @@ int slr_mf_triangulate(slr_ctx *c, const float *phaseL, const uint8_t *validL, c
     SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh)); SLR_TRY(st.out(match_k, n * 4, &dk));
     SLR_TRY(core_mf_match(c, (const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
                           (float *)dx, (uint8_t *)dh, (int32_t *)dk));
+    return st.finish();
+}
+
+int slr_mf_triangulate_rows(slr_ctx *c, const float *phaseL, const uint8_t *validL, const float *phaseR,
+                            const uint8_t *validR, int W, int H, int row0, int rows, float *xyz, uint8_t *has,
+                            int32_t *match_k, slr_mem mem)
+{
+    if (!c || !phaseL || !validL || !phaseR || !validR || !xyz || !has) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(check_dims(c, W, H, W));
+    if (row0 < 0 || rows < 0 || row0 + rows > H) return fail(c, SLR_ERR_INVALID_ARG, "row band outside the image");
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    if (rows == 0) return SLR_OK;
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    Stage st(c, mem);
+    const size_t n = (size_t)W * rows;
+    const void *pl, *vl, *pr, *vr; void *dx, *dh, *dk;
+    SLR_TRY(st.in(phaseL, n * 4, &pl)); SLR_TRY(st.in(validL, n, &vl));
+    SLR_TRY(st.in(phaseR, n * 4, &pr)); SLR_TRY(st.in(validR, n, &vr));
+    SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh)); SLR_TRY(st.out(match_k, n * 4, &dk));
+    SLR_TRY(core_mf_match(c, (const float *)pl, (const uint8_t *)vl, (const float *)pr, (const uint8_t *)vr, W, H,
+                          (float *)dx, (uint8_t *)dh, (int32_t *)dk, row0, rows));
     return st.finish();
 }
 

@@ -36,7 +36,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_COUNT
 };
 
 // ---- launchers (defined in the .hip files; all asynchronous on `s`) -----------------------------------
@@ -72,7 +72,8 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
                               hipStream_t s);
 
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR,
-                           const uint8_t *validR, int W, int H, const DevCalib &cal,
+                           const uint8_t *validR, int W, int H /* rows handed over */, int row0 /* image row of the
+                           first one: the reprojection and the tables use absolute rows */, const DevCalib &cal,
                            float *xyz, uint8_t *has, int32_t *match_k, int algo,
                            const float *undL_xy /* [H][W][2] or null */, const float *undRx /* [H][W] or null */,
                            hipStream_t s);
@@ -83,6 +84,10 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
                            const uint8_t *whiteL, const uint8_t *whiteR,
                            float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s);
+
+// build extension: generalised n_freq x n_step fp16 multi-frequency decode (kernels_mfn.hip)
+hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
+                             float *phase, uint8_t *valid, hipStream_t s);
 
 // GRAY_ONLY: counting sort of camera pixels by projector cell (both cameras share one histogram / offsets
 // array: left cells [0,nb), right cells [nb,2nb), +1 pad), then one thread per cell

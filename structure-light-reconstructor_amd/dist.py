@@ -60,3 +60,35 @@ def reconstruct_sharded(n_frames, H, W, load_frame, reconstruct, device, group=N
         xyz[s].copy_(x)
         has[s].copy_(h)
     return gather_point_clouds(xyz, has, n_frames, group)
+
+
+# ---- one huge frame (BASELINE config 5): shard by ROW BANDS ------------------------------------------------
+def shard_rows(H, rank, world):
+    """rows [r0, r1) of rank `rank`: `world` bands of ceil(H / world) rows (the last ones may be short or empty).
+    Every kernel of the unrectified path is row-local (decode is per pixel, the match runs along a row), so a band
+    needs no halo and no collective."""
+    band = (H + world - 1) // world
+    r0 = min(H, rank * band)
+    return r0, min(H, r0 + band)
+
+
+def reconstruct_row_sharded(H, W, reconstruct_rows, device, group=None):
+    """reconstruct_rows(r0, r1) -> (xyz [r1-r0][W][3] f32, has [r1-r0][W] u8) for this rank's band, e.g. the HIP path on
+    row views of the planes.  One all-gather of the (padded, equal-sized) bands assembles the frame on every rank."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    band = (H + world - 1) // world
+    r0, r1 = shard_rows(H, rank, world)
+    xyz = torch.zeros((band, W, 3), dtype=torch.float32, device=device)
+    has = torch.zeros((band, W), dtype=torch.uint8, device=device)
+    if r1 > r0:
+        x, h = reconstruct_rows(r0, r1)
+        xyz[:r1 - r0].copy_(x)
+        has[:r1 - r0].copy_(h)
+    if world == 1:
+        return xyz[:H], has[:H]
+    g_xyz = torch.empty((world * band, W, 3), dtype=torch.float32, device=device)
+    g_has = torch.empty((world * band, W), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(g_xyz, xyz, group=group)
+    dist.all_gather_into_tensor(g_has, has, group=group)
+    return g_xyz[:H].contiguous(), g_has[:H].contiguous()          # bands are consecutive: padding only at the end

@@ -163,6 +163,37 @@ def render_mf_stack(W, H, proj_w=None, seed=1234, noise=2, device="cpu"):
     return out
 
 
+MFN_FREQ = (72.0, 64.0, 58.0, 53.0, 49.0, 46.0)     # 72-3*64+3*58-53 = 1: the 4-frequency cascade spans one period
+
+
+def render_mfn_stack(W, H, n_freq=4, n_step=8, proj_w=None, seed=1234, noise=0.5, device="cpu", continuous=True):
+    """BUILD EXTENSION input (BASELINE config 5, no reference counterpart): [2 cams][2 + F*N][H][W] float16 --
+    white, black, then for every frequency f its N equally spaced shifts  A + B cos(2 pi u f / proj_w + 2 pi k / N).
+    continuous=True samples the fringe at the sub-pixel projector coordinate (a smooth phase field)."""
+    proj_w = W if proj_w is None else proj_w
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    uL, uR, _ = projector_columns(W, H, proj_w, device)
+    lit = _shadow_mask(W, H, device)
+    out = torch.empty((2, 2 + n_freq * n_step, H, W), dtype=torch.float16, device=device)
+
+    def fin(img):
+        n = (torch.rand((H, W), generator=gen, device=device, dtype=torch.float64) - 0.5) * 2 * noise
+        return (img + n).to(torch.float16)
+
+    for cam, u in enumerate((uL, uR)):
+        inside = (u >= 0) & (u <= proj_w - 1) & lit
+        uu = u if continuous else torch.clamp(torch.round(u), 0, proj_w - 1)
+        out[cam, 0] = fin(torch.where(inside, 215.0, 70.0))
+        out[cam, 1] = fin(torch.where(inside, 55.0, 52.0))
+        for f in range(n_freq):
+            for k in range(n_step):
+                arg = 2 * math.pi * uu * MFN_FREQ[f] / proj_w + 2 * math.pi * k / n_step
+                img = torch.where(inside, 135 + 79 * torch.cos(arg), torch.full_like(u, 58.0))
+                out[cam, 2 + f * n_step + k] = fin(img)
+    return out
+
+
 def render_gray_stack(W, H, scan_w, scan_h=None, seed=1234, noise=2, device="cpu", rows=False):
     """[2 cams][2+2n(+2m)][H][W] u8 Gray-code stack.  rows=True adds the row-bit planes (GRAY_ONLY mode); the
     projector row seen by a pixel is a smooth function of the image row."""
