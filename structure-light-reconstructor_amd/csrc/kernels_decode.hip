@@ -650,7 +650,7 @@ struct RectJob {
 };
 
 template <int TH, int ROUNDS>
-__global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(RectJob job0, RectJob job1, int njobs, int pitch, int W, int H,
+__global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJob job0, RectJob job1, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
 {
@@ -661,9 +661,8 @@ __global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(RectJob job0, R
     const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
     const bool second = blockIdx.x >= nblk;
     const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
-    MfPlanes pl;
-#pragma unroll
-    for (int p = 0; p < NP; p++) pl.p[p] = second ? job1.pl.p[p] : job0.pl.p[p];
+    // (no local copy of the plane table: a dynamically indexed local array would live in scratch)
+    auto plane = [&](int p) -> const uint8_t * { return second ? job1.pl.p[p] : job0.pl.p[p]; };
     const int16_t *__restrict__ map_xy = second ? job1.map_xy : job0.map_xy;
     const uint16_t *__restrict__ map_frac = second ? job1.map_frac : job0.map_frac;
     const int4 *__restrict__ boxes = second ? job1.boxes : job0.boxes;
@@ -692,7 +691,7 @@ __global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(RectJob job0, R
             const bool in = e < E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
 #pragma unroll
-            for (int p = 0; p < NP; p++) pre[r][p] = *reinterpret_cast<const unsigned *>(pl.p[p] + off);
+            for (int p = 0; p < NP; p++) pre[r][p] = *reinterpret_cast<const unsigned *>(plane(p) + off);
         }
     };
     auto commit = [&](const BoxGeom &g) {                   // same predicate as issue(); outside the image -> 0
@@ -760,7 +759,7 @@ __global__ __launch_bounds__(256) void mf_rect_decode_lds_kernel(RectJob job0, R
                 if (!inb) t.kind = 1;
                 int gpx[NP];
 #pragma unroll 1
-                for (int p = 0; p < NP; p++) gpx[p] = gc.any ? sample(pl.p[p], pitch, W, H, t) : 0;
+                for (int p = 0; p < NP; p++) gpx[p] = gc.any ? sample(plane(p), pitch, W, H, t) : 0;
                 ph = mf_pixel(gpx, black_thr, lut, v);
             }
             // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane: the wave's ballot, this lane's
