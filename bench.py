@@ -9,9 +9,11 @@ frame.  Inputs are resident in HBM when the timed region starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): frames shard across ranks (weak scaling, no
 data-path collective inside the kernels); the per-step point cloud is assembled on every rank with one RCCL
-all-gather (north_star: "RCCL all-gather over xGMI only to assemble the final point cloud"): by default once per job,
-inside the timed region (--gather final); --gather step gathers after every step on a side stream, double-buffered so it
-overlaps the next step's compute (160 MB per frame per peer: that mode measures xGMI, not the kernels); --gather off
+all-gather (north_star: "RCCL all-gather over xGMI only to assemble the final point cloud").  The metric is Mpix/s of
+decode + unwrap + triangulate, so by default that one assembly runs right AFTER the K timed steps, bracketed and timed on
+its own and reported as "final_allgather_ms" (--gather after); --gather final puts it inside the timed region; --gather
+step gathers after every step on a side stream, double-buffered so it overlaps the next step's compute (160 MB per frame
+per peer: that mode measures xGMI, not the kernels); --gather off
 measures the sharded path alone.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed inside the timed
@@ -49,8 +51,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--rectify", type=int, default=1, help="1: raw planes + fused rectification (the reference path)")
-    ap.add_argument("--gather", choices=["final", "step", "off"], default="final",
-                    help="N>1: RCCL all-gather of the point cloud: once per job (the final assembly, inside the timed region), "
+    ap.add_argument("--gather", choices=["after", "final", "step", "off"], default="after",
+                    help="N>1: RCCL all-gather of the point cloud: once per job right after the timed steps, timed separately "
+                         "(after, default), once per job inside the timed region (final), "
                          "after every step (overlapped with the next step's compute), or never")
     ap.add_argument("--profile", type=int, default=1, help="bracket every kernel with HIP events (roofline)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
@@ -206,7 +209,8 @@ def main():
     has = [torch.empty((1, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
-    if do_gather or final_gather:
+    after_gather = world > 1 and args.gather == "after"
+    if do_gather or final_gather or after_gather:
         comm = torch.cuda.Stream(device=dev)
         # output = concatenation of the per-rank clouds along dim 0 (the form every backend accepts)
         g_xyz = torch.empty((world * H, W, 3), dtype=torch.float32, device=dev)
@@ -255,6 +259,17 @@ def main():
             dist.all_gather_into_tensor(g_has, has[b][0])
     sync_all()
     elapsed = time.perf_counter() - t0
+    gather_ms = None
+    if after_gather:                                    # the job's one exchange step, timed on its own (max over ranks)
+        b = (args.steps - 1) % nbuf
+        tg = time.perf_counter()
+        with torch.cuda.stream(comm):
+            dist.all_gather_into_tensor(g_xyz, xyz[b][0])
+            dist.all_gather_into_tensor(g_has, has[b][0])
+        sync_all()
+        tt = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        gather_ms = float(tt.item()) * 1e3
     prof = {}
     if args.profile:
         for c_ in ctxs:                                   # merge the per-context HIP-event profiles
@@ -345,7 +360,11 @@ def main():
                        "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify), "streams_per_gpu": S,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else
-                           (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else ""))},
+                           (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else
+                            (", one RCCL all-gather of the final XYZ+mask right after the timed steps (final_allgather_ms)"
+                             if after_gather else "")))},
+            "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * npix * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
             "roofline": roofline, "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
             "host_buffers_pcie_inclusive": hostio,
