@@ -649,8 +649,10 @@ struct RectJob {
     uint8_t *valid;
 };
 
+struct RectJobs { RectJob j[2]; };
+
 template <int TH, int ROUNDS>
-__global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJob job0, RectJob job1, int njobs, int pitch, int W, int H,
+__global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
 {
@@ -661,13 +663,15 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
     const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
     const bool second = blockIdx.x >= nblk;
     const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
-    // (no local copy of the plane table: a dynamically indexed local array would live in scratch)
-    auto plane = [&](int p) -> const uint8_t * { return second ? job1.pl.p[p] : job0.pl.p[p]; };
-    const int16_t *__restrict__ map_xy = second ? job1.map_xy : job0.map_xy;
-    const uint16_t *__restrict__ map_frac = second ? job1.map_frac : job0.map_frac;
-    const int4 *__restrict__ boxes = second ? job1.boxes : job0.boxes;
-    float *__restrict__ phase = second ? job1.phase : job0.phase;
-    uint8_t *__restrict__ valid = second ? job1.valid : job0.valid;
+    // the job table stays in the kernarg segment and is indexed there (scalar loads on demand): no local copy (a
+    // dynamically indexed local array would live in scratch) and no 2 x 19 pointers held in SGPRs
+    const int ji = second ? 1 : 0;
+    auto plane = [&](int p) -> const uint8_t * { return jobs.j[ji].pl.p[p]; };
+    const int16_t *__restrict__ map_xy = jobs.j[ji].map_xy;
+    const uint16_t *__restrict__ map_frac = jobs.j[ji].map_frac;
+    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
+    float *__restrict__ phase = jobs.j[ji].phase;
+    uint8_t *__restrict__ valid = jobs.j[ji].valid;
     // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
     // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
     // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
@@ -810,8 +814,9 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     const int tiles_yy = (H + th - 1) / th;
     const int budget = mid ? 12 * 1024 : 24 * 1024;      // 14 planes x ~72 x (th + 7) source bytes
     const size_t box_off = mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0;
-    RectJob j[2] = {jobs[0], jobs[njobs - 1]};
-    j[0].boxes += box_off; j[1].boxes += box_off;
+    RectJobs j;
+    j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
+    j.j[0].boxes += box_off; j.j[1].boxes += box_off;
     static int resident[2] = {0, 0};
     if (!resident[mid]) {
         int per_cu = 0, dev = 0, cus = 0;
@@ -829,10 +834,10 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     if (nbx < 1) nbx = 1;
     const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);
     if (mid)
-        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), grid, dim3(256), (size_t)budget + 16, s, j[0], j[1], njobs,
+        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                            pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     else
-        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), grid, dim3(256), (size_t)budget + 16, s, j[0], j[1], njobs,
+        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                            pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     return hipGetLastError();
 }
