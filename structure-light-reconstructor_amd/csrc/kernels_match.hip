@@ -252,10 +252,13 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
         const size_t o = base + k0 + i0;
         if (full) {
             float4 *dst = reinterpret_cast<float4 *>(xyz + 3 * o);
-            dst[0] = make_float4(out[0], out[1], out[2], out[3]);
-            dst[1] = make_float4(out[4], out[5], out[6], out[7]);
-            dst[2] = make_float4(out[8], out[9], out[10], out[11]);
-            *reinterpret_cast<unsigned *>(has + o) = hw;
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);                  // streaming output: non-temporal stores
+            f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+            __builtin_nontemporal_store(v0, d4);
+            __builtin_nontemporal_store(v1, d4 + 1);
+            __builtin_nontemporal_store(v2, d4 + 2);
+            __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
             if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(mk[0], mk[1], mk[2], mk[3]);
         } else {
 #pragma unroll
