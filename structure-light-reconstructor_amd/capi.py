@@ -155,7 +155,12 @@ def _flat(planes):
 
 
 class Context:
-    """One slr_ctx: one GPU, one HIP stream.  Mirrors the C ABI one to one."""
+    """One slr_ctx: one GPU, one HIP stream.  Mirrors the C ABI one to one.
+
+    Stream ordering: device-pointer calls are asynchronous on the ctx stream.  When that stream is a torch stream (the
+    default: one is created here; or pass `stream=`), every device-pointer call first makes it wait for torch's current
+    stream, so tensors torch has just produced are safe to pass in.  Results must not be read by torch before
+    `ctx.synchronize()` (or a `torch.cuda.current_stream().wait_stream(ctx.stream)`) -- the rule of any two HIP streams."""
 
     def __init__(self, device_id=0, stream=None):
         self.lib = load_library()
@@ -165,8 +170,24 @@ class Context:
             raise SlrError(st, self.lib.slr_status_string(st).decode())
         self.h = h
         self.device_id = device_id
+        self.stream = None                               # torch.cuda.Stream when known (input ordering, see above)
+        if stream is None:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    stream = torch.cuda.Stream(device=device_id)
+            except Exception:                            # torch is plumbing, not a requirement of the binding
+                stream = None
         if stream is not None:
             self.set_stream(stream)
+
+    def _mem(self, arrs):
+        """host/device mode of a call; device mode: order the ctx stream after torch's current stream"""
+        mem = _mem_of(arrs)
+        if mem == MEM_DEVICE and self.stream is not None:
+            import torch
+            self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+        return mem
 
     # -- plumbing
     def _chk(self, st):
@@ -196,6 +217,7 @@ class Context:
         """stream: raw hipStream_t as int, a torch.cuda.Stream, or None for the ctx-owned stream."""
         raw = getattr(stream, "cuda_stream", stream)
         self._chk(self.lib.slr_set_stream(self.h, C.c_void_p(raw)))
+        self.stream = stream if hasattr(stream, "wait_stream") else None
 
     def set_option(self, option, value):
         self._chk(self.lib.slr_set_option(self.h, C.c_int(option), C.c_int(value)))
@@ -216,7 +238,7 @@ class Context:
 
     def set_rectify_maps(self, cam, map_xy, map_frac):
         H, W = map_frac.shape
-        mem = _mem_of([map_xy, map_frac])
+        mem = self._mem([map_xy, map_frac])
         self._chk(self.lib.slr_set_rectify_maps(self.h, C.c_int(cam), _ptr(map_xy), _ptr(map_frac),
                                                 C.c_int(W), C.c_int(H), C.c_int(mem)))
 
@@ -236,7 +258,7 @@ class Context:
     # -- K1
     def remap_u8(self, cam, src, out=None):
         H, W = src.shape
-        mem = _mem_of([src, out])
+        mem = self._mem([src, out])
         out = self._new(mem, (H, W), np.uint8, src) if out is None else out
         self._chk(self.lib.slr_remap_u8(self.h, C.c_int(cam), _ptr(src), C.c_int(W), _ptr(out), C.c_int(W),
                                         C.c_int(W), C.c_int(H), C.c_int(mem)))
@@ -247,7 +269,7 @@ class Context:
         ptrs, n, H, pitch = _plane_ptrs(planes)
         assert n == MF_PLANES
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planes) + [phase, valid])
+        mem = self._mem(_flat(planes) + [phase, valid])
         like = _flat(planes)[0]
         phase = self._new(mem, (H, W), np.float32, like) if phase is None else phase
         valid = self._new(mem, (H, W), np.uint8, like) if valid is None else valid
@@ -268,7 +290,7 @@ class Context:
         first = _flat(planes)[0]
         assert (first.element_size() if _is_torch(first) else first.itemsize) == 2
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planes) + [phase, valid])
+        mem = self._mem(_flat(planes) + [phase, valid])
         phase = self._new(mem, (H, W), np.float32, first) if phase is None else phase
         valid = self._new(mem, (H, W), np.uint8, first) if valid is None else valid
         self._chk(self.lib.slr_mfn_decode(self.h, ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch), C.c_int(W),
@@ -281,7 +303,7 @@ class Context:
         ptrs, n, H, pitch = _plane_ptrs(planes)
         assert n >= 2 + 2 * n_col_bits + 2 * n_row_bits
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planes))
+        mem = self._mem(_flat(planes))
         like = _flat(planes)[0]
         cx = self._new(mem, (H, W), np.int32, like)
         cy = self._new(mem, (H, W), np.int32, like) if n_row_bits > 0 else None
@@ -300,7 +322,7 @@ class Context:
     def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True, row0=0, image_h=None):
         """row0 / image_h: the arrays are a band of rows [row0, row0 + H) of an image_h-row image (row-band sharding)."""
         H, W = phaseL.shape
-        mem = _mem_of([phaseL, validL, phaseR, validR])
+        mem = self._mem([phaseL, validL, phaseR, validR])
         xyz = self._new(mem, (H, W, 3), np.float32, phaseL)
         has = self._new(mem, (H, W), np.uint8, phaseL)
         mk = self._new(mem, (H, W), np.int32, phaseL) if want_match else None
@@ -316,7 +338,7 @@ class Context:
     # -- K5
     def ge_triangulate(self, codeL, validL, codeR, validR, whiteL=None, whiteR=None, want_match=True):
         H, W = codeL.shape
-        mem = _mem_of([codeL, validL, codeR, validR, whiteL, whiteR])
+        mem = self._mem([codeL, validL, codeR, validR, whiteL, whiteR])
         xyz = self._new(mem, (H, W, 3), np.float32, codeL)
         has = self._new(mem, (H, W), np.uint8, codeL)
         color = self._new(mem, (H, W), np.uint8, codeL) if whiteL is not None else None
@@ -329,7 +351,7 @@ class Context:
     # -- K3' scatter + K6
     def ray_triangulate(self, cxL, cyL, vL, cxR, cyR, vR, scan_w, scan_h):
         H, W = cxL.shape
-        mem = _mem_of([cxL, cyL, vL, cxR, cyR, vR])
+        mem = self._mem([cxL, cyL, vL, cxR, cyR, vR])
         xyz = self._new(mem, (scan_h, scan_w, 3), np.float32, cxL)
         cnt = self._new(mem, (scan_h, scan_w), np.uint8, cxL)
         self._chk(self.lib.slr_ray_triangulate(self.h, _ptr(cxL), _ptr(cyL), _ptr(vL), _ptr(cxR), _ptr(cyR), _ptr(vR),
@@ -340,7 +362,7 @@ class Context:
     # -- PointCloudImage
     def pointcloud_from_grid(self, xyz, has, scan_w, scan_h, color=None):
         H, W = has.shape
-        mem = _mem_of([xyz, has, color])
+        mem = self._mem([xyz, has, color])
         s = self._new(mem, (scan_h, scan_w, 3), np.float32, xyz)
         c = self._new(mem, (scan_h, scan_w), np.uint8, xyz)
         col = self._new(mem, (scan_h, scan_w), np.uint8, xyz) if color is not None else None
@@ -350,7 +372,7 @@ class Context:
         return s, c, col
 
     def pointcloud_get(self, pc_sum, pc_count):
-        mem = _mem_of([pc_sum, pc_count])
+        mem = self._mem([pc_sum, pc_count])
         n = int(np.prod(pc_count.shape))
         out = self._new(mem, tuple(pc_count.shape) + (3,), np.float32, pc_sum)
         self._chk(self.lib.slr_pointcloud_get(self.h, _ptr(pc_sum), _ptr(pc_count), C.c_size_t(n), _ptr(out),
@@ -363,7 +385,7 @@ class Context:
         pr, n2, H2, pitch2 = _plane_ptrs(planesR)
         assert n == MF_PLANES and n2 == MF_PLANES and (H, pitch) == (H2, pitch2)
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planesL) + _flat(planesR) + [xyz, has])
+        mem = self._mem(_flat(planesL) + _flat(planesR) + [xyz, has])
         like = _flat(planesL)[0]
         xyz = self._new(mem, (H, W, 3), np.float32, like) if xyz is None else xyz
         has = self._new(mem, (H, W), np.uint8, like) if has is None else has
@@ -380,6 +402,7 @@ class Context:
         W = pitch if W is None else W
         xyz = torch.empty((nf, H, W, 3), dtype=torch.float32, device=stack.device) if xyz is None else xyz
         has = torch.empty((nf, H, W), dtype=torch.uint8, device=stack.device) if has is None else has
+        self._mem([stack, xyz, has])
         self._chk(self.lib.slr_reconstruct_mf_batch(self.h, C.c_int(nf), _ptr(stack), C.c_int(pitch), C.c_int(W),
                                                     C.c_int(H), C.c_int(black_thr), C.c_int(1 if rectify else 0),
                                                     _ptr(xyz), _ptr(has)))
@@ -390,7 +413,7 @@ class Context:
         pr, n2, H2, pitch2 = _plane_ptrs(planesR)
         assert n >= 2 + 2 * n_col_bits and n2 >= 2 + 2 * n_col_bits and (H, pitch) == (H2, pitch2)
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planesL) + _flat(planesR))
+        mem = self._mem(_flat(planesL) + _flat(planesR))
         like = _flat(planesL)[0]
         xyz = self._new(mem, (H, W, 3), np.float32, like)
         has = self._new(mem, (H, W), np.uint8, like)
@@ -406,7 +429,7 @@ class Context:
         pr, n2, H2, pitch2 = _plane_ptrs(planesR)
         assert (H, pitch) == (H2, pitch2)
         W = pitch if W is None else W
-        mem = _mem_of(_flat(planesL) + _flat(planesR))
+        mem = self._mem(_flat(planesL) + _flat(planesR))
         like = _flat(planesL)[0]
         xyz = self._new(mem, (scan_h, scan_w, 3), np.float32, like)
         cnt = self._new(mem, (scan_h, scan_w), np.uint8, like)

@@ -817,19 +817,23 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     RectJobs j;
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
-    static int resident[2] = {0, 0};
-    if (!resident[mid]) {
-        int per_cu = 0, dev = 0, cus = 0;
+    // resident workgroups of this kernel on the CURRENT device (cached per device and kernel variant)
+    static int resident_cache[64][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &resident_slot = resident_cache[dev & 63][mid];
+    if (!resident_slot) {
+        int per_cu = 0, cus = 0;
         const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1>, 256, (size_t)budget + 16)
                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2>, 256, (size_t)budget + 16);
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
-        (void)hipGetDevice(&dev);
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        resident[mid] = per_cu * cus;
+        resident_slot = per_cu * cus;
     }
+    const int resident_blocks = resident_slot;
     const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
     const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
-    const int res = (dbg && atoi(dbg) > 0 ? atoi(dbg) : resident[mid]) / njobs;
+    const int res = (dbg && atoi(dbg) > 0 ? atoi(dbg) : resident_blocks) / njobs;
     int nbx = res / 8 < per ? res / 8 : per;
     if (nbx < 1) nbx = 1;
     const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);

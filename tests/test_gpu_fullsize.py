@@ -97,3 +97,22 @@ def test_fullsize_gray_decode_and_ge(ctx, oracle, synth, scene):
     Z = info["f"] * info["Tx"] / ((info["cx1"] - info["cx2"]) - d)
     sel = ehas.astype(bool)
     assert np.allclose(np_of(xyz)[..., 2][sel], Z[sel], rtol=1e-5)
+
+
+def test_fullsize_whole_path_pair_launch_equals_step_by_step(ctx, scene):
+    """slr_reconstruct_mf_batch (both cameras' fused rectify+decode in ONE launch, then K4) == the three separate calls,
+    bit for bit, on the bench workload; two frames in the batch so that the frame stride is exercised too"""
+    st, maps, calib, _ = scene
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    st2 = torch.stack([st, torch.flip(st, dims=[0])]).contiguous()       # frame 1 = cameras swapped
+    torch.cuda.synchronize()            # the ctx has its own stream: inputs made by torch must be complete first
+    xyz, has = ctx.reconstruct_mf_batch(st2, BLACK, True)
+    ctx.synchronize()
+    for f in range(2):
+        dec = [ctx.mf_decode(st2[f, cam], BLACK, rectify_cam=cam) for cam in range(2)]
+        ex, eh, _ = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
+        ctx.synchronize()
+        assert torch.equal(has[f], eh) and torch.equal(xyz[f], ex), f
+    assert 0.2 < has[0].float().mean().item() < 1.0
