@@ -474,7 +474,7 @@ def test_ge_reprojection_known_answer(ctx, synth):
 # ---------------------------------------------------------------------------------------------------------
 # K3' scatter + K6
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("W,H,scan_w,scan_h,with_T", [(160, 120, 64, 48, False), (96, 64, 40, 33, True)])
+@pytest.mark.parametrize("W,H,scan_w,scan_h,with_T", [(160, 120, 64, 48, False), (96, 64, 40, 33, True), (1024, 768, 300, 200, False), (1000, 300, 1000, 300, True)])
 def test_ray_triangulate_parity(ctx, oracle, synth, W, H, scan_w, scan_h, with_T):
     calib, _ = synth.make_calibration(W, H, with_T=with_T, baseline=400.0, theta=0.6)
     ctx.set_calibration(calib)
