@@ -468,21 +468,24 @@ hipError_t launch_init_rectify_map(const double M[9], const double D[5], const d
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fused K1+K2, LDS-tiled form (the default): one workgroup rectifies + decodes a 64 x 16 destination tile.
-//   0. (once per map, at slr_set_rectify_maps) tile_boxes_kernel reduces every tile's map entries to the bounding
-//      box of its source footprints with wave shuffles (a smooth map turns 64x16 into roughly 70x19 source pixels);
-//   1. the box of all 14 planes is copied HBM -> LDS once, with coalesced dword loads (14 independent loads in
-//      flight per thread); everything outside the image is stored as 0, which IS cv::remap's BORDER_CONSTANT, so
-//      the border cases need no special code at all.  LDS layout: [row][dword column][plane], i.e. the 14 planes
-//      of one source dword sit next to each other -> every tap read is base + immediate (ds_read2_b32);
+// fused K1+K2, LDS-tiled form (the default): a workgroup rectifies + decodes 64 x 8 destination tiles (64 x 16 with
+// SLR_OPT_RECT_DECODE_ALGO = 2), one pixel per lane, TH / 4 passes of four rows.
+//   0. (once per map, at slr_set_rectify_maps / slr_init_rectify_maps) tile_boxes_kernel reduces every tile's map
+//      entries to the bounding box of its source footprints with wave shuffles (a smooth map turns 64 x 8 into
+//      roughly 70 x 10 source pixels);
+//   1. the box of all 14 planes goes HBM -> registers -> LDS with coalesced dword loads (14 independent loads per
+//      thread and round); everything outside the image is stored as 0, which IS cv::remap's BORDER_CONSTANT, so the
+//      border cases need no special code at all.  LDS layout: [row][dword column][plane], i.e. the 14 planes of one
+//      source dword sit next to each other -> every tap read is base + immediate (one ds_read2_b64 per plane);
 //   2. per pixel the 2x2 footprint of each plane is two dword pairs; v_perm_b32 cuts the two bytes out as a u16
-//      pair and two v_dot2_u32_u16 with the 16-bit weights wx*wy accumulate the whole bilinear sum:
-//      (dot2(row1, w1, dot2(row0, w0, 512))) >> 10 == OpenCV's (sum tap*w + 16384) >> 15 exactly;
+//      pair and two v_dot2_u32_u16 with the 16-bit weights wx*wy*64 accumulate the whole bilinear sum; the sample
+//      (dot2(row1, w1, dot2(row0, w0, 512 << 6))) >> 16 == OpenCV's (sum tap*w + 16384) >> 15 exactly, and it stays
+//      in the accumulator's high half-word for the consumer (SDWA operand select instead of a shift);
 //   3. the same per-pixel decode as K2.
-// One pixel per lane and four passes of four rows: a wave writes 64 consecutive pixels, live state stays small.
-// Square-ish tiles keep the halo small under rotation; an XCD-banded tile order keeps vertically adjacent tiles
-// (which share source rows) on one L2 (PMC: 248 MB fetched per camera vs 246 MB ideal).  A box that does not fit
-// the LDS budget (wild maps) falls back, per workgroup, to the direct gather of the generic kernel.
+// The workgroups are persistent and software-pipelined (see below); an XCD-banded tile walk keeps horizontally
+// adjacent tiles on one L2.  PMC: 64 x 16 tiles fetch 1.01..1.07x the ideal bytes, 64 x 8 tiles 1.13..1.17x (their two
+// halo rows are re-read from HBM) but run 7 % faster (5 instead of 4 workgroups per CU).  A box that does not fit
+// (wild maps) falls back, per tile, to the direct gather of the generic kernel.
 // ------------------------------------------------------------------------------------------------------
 constexpr int kTileW = 64, kTileH = 16;
 
