@@ -47,3 +47,24 @@ def test_no_gpu_means_loud_failure(slr):
     with pytest.raises(slr.SlrError) as e:
         slr.Context(0)
     assert e.value.status == slr.capi.ERR_NO_DEVICE
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/slr.h compiles as strict C99 (and as C++), and a C program that takes the address of every declared
+    function links against libslr_hip.so -- what a maintainer of the reference application would do first"""
+    import subprocess
+    names = _declared_functions()
+    src = tmp_path / "link_all.c"
+    src.write_text('#include "slr.h"\n#include <stdio.h>\nint main(void)\n{\n    const void *f[] = {\n'
+                   + "".join("        (const void *)%s,\n" % n for n in names)
+                   + '    };\n    unsigned i, n = 0;\n    for (i = 0; i < sizeof f / sizeof f[0]; i++) n += f[i] != 0;\n'
+                     '    printf("%u %d\\n", n, slr_version());\n    return 0;\n}\n')
+    pkg = os.path.join(ROOT, "structure-light-reconstructor_amd")
+    exe = tmp_path / "link_all"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+           "-o", str(exe), "-L", pkg, "-lslr_hip", "-Wl,-rpath," + pkg]
+    subprocess.run(cmd, check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) == len(names) and int(out[1]) == 100
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I",
+                    os.path.join(ROOT, "include"), str(src)], check=True, capture_output=True)
