@@ -62,6 +62,7 @@ def parse_args():
                     help="frames in flight per GPU: S contexts (one HIP stream each) take the steps in turn, so the match of frame i "
                          "overlaps the decode of frame i+1 (application-level double buffering).  Default 1: kernels run back to "
                          "back and the per-kernel roofline is undisturbed")
+    ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 default, 1 gather, 2 64x16 tiles, 3 ring)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
     return ap.parse_args()
@@ -197,6 +198,8 @@ def main():
         torch.cuda.synchronize()
     for c_ in ctxs:
         c_.set_calibration(calib)
+        if args.rect_algo:
+            c_.set_option(slr.capi.OPT_RECT_DECODE_ALGO, args.rect_algo)
         if args.rectify:
             for cam in range(2):
                 c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])

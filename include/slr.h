@@ -91,7 +91,9 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2
 /* SLR_OPT_RECT_DECODE_ALGO: fused rectify+decode form: 0 = LDS-tiled, 64x8 tiles per persistent workgroup with a
- * register prefetch pipeline (default), 1 = direct gather, 2 = as 0 with 64x16 tiles (identical results) */
+ * register prefetch pipeline (default), 1 = direct gather, 2 = as 0 with 64x16 tiles, 3 = as 0 but walking down tile
+ * columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of 1.13x the algorithmic HBM bytes, ~3 %
+ * slower because the kernel is VALU-bound).  Identical results. */
 #define SLR_OPT_RECT_DECODE_ALGO 3
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 

@@ -8,7 +8,7 @@ for PMC in "$@"; do
   python - <<PY
 import csv,glob,collections
 f=glob.glob('/tmp/cw/p$i/**/*counter_collection.csv',recursive=True)
-rows=[r for r in csv.DictReader(open(f[0])) if 'mf_rect_decode_lds' in r['Kernel_Name']]
+rows=[r for r in csv.DictReader(open(f[0])) if 'mf_rect_decode_' in r['Kernel_Name']]
 by=collections.defaultdict(dict)
 for r in rows: by[int(r['Dispatch_Id'])][r['Counter_Name']]=float(r['Counter_Value'])
 ids=sorted(by)

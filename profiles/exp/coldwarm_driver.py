@@ -16,6 +16,7 @@ for cam in range(2):
     ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
 st = synth.render_mf_stack(W, H, seed=1234, device=dev)
 torch.cuda.synchronize()
+ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, int(os.environ.get('SLR_RECT_ALGO', '0')))
 ph = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
 vd = [torch.empty((H, W), dtype=torch.uint8, device=dev) for _ in range(2)]
 for _ in range(8):                       # dispatches 0..7: warm

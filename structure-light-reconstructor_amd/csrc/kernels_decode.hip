@@ -787,6 +787,213 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fused K1+K2, sliding-window form (SLR_OPT_RECT_DECODE_ALGO = 3): the pipelined kernel above re-reads the two halo
+// rows of every 64 x 8 tile from HBM (1.13..1.17x the ideal traffic).  Here a workgroup walks DOWN a tile column and
+// keeps the source rows in a 16-row LDS ring (slot = source row & 15): the next tile only loads the rows below the
+// ones already there.  Work item = (tile column, vertical segment of the XCD's band of tile rows); the items of one
+// segment are handed to consecutive workgroups, so horizontally adjacent tiles are decoded at the same time and share
+// their source lines in L2.  All tiles of an item use one LDS geometry (the union of their source column ranges).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRingRows = 16, kRingBW = 20;               // ring: 16 source rows x <= 20 dwords x 14 planes = 17.9 KB
+
+struct RingTile {                                        // one 64 x 8 tile and the LDS geometry of its item
+    int tx, ty, item;
+    int x0, bw;                                          // item geometry: source columns [x0, x0 + 4 bw)
+    int y0, bh;                                          // this tile's source rows [y0, y0 + bh)
+    bool any, ok, valid;                                 // has a footprint / the item fits the ring / tile exists
+};
+
+__global__ __launch_bounds__(256, 5) void mf_rect_decode_ring_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
+                                                                     int black_thr, const float *__restrict__ lut_g,
+                                                                     int tiles_x, int tiles_y, int seg_len)
+{
+    constexpr int NP = SLR_MF_PLANES, TH = kMidTileH;
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    __shared__ float lut[kLutWords + 1];
+    load_lut(lut, lut_g);
+    const unsigned nblk = gridDim.x / (unsigned)njobs;
+    const bool second = blockIdx.x >= nblk;
+    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
+    const int ji = second ? 1 : 0;
+    auto plane = [&](int p) -> const uint8_t * { return jobs.j[ji].pl.p[p]; };
+    const int16_t *__restrict__ map_xy = jobs.j[ji].map_xy;
+    const uint16_t *__restrict__ map_frac = jobs.j[ji].map_frac;
+    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
+    float *__restrict__ phase = jobs.j[ji].phase;
+    uint8_t *__restrict__ valid = jobs.j[ji].valid;
+    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned lane31 = (unsigned)lane & 31u;
+
+    // schedule: XCD x owns tile rows [band0, band1); items = columns x segments of seg_len tile rows, segment-major
+    const int R = (tiles_y + 7) >> 3;
+    const int band0 = xcd * R, band1 = band0 + R < tiles_y ? band0 + R : tiles_y;
+    const int nseg = band1 > band0 ? (band1 - band0 + seg_len - 1) / seg_len : 0;
+    const int nitems = nseg * tiles_x;
+
+    auto enter_item = [&](int item, RingTile &t) {         // geometry of an item = union over its tiles
+        t.item = item;
+        t.valid = item < nitems;
+        if (!t.valid) return;
+        const int seg = item / tiles_x;
+        t.tx = item - seg * tiles_x;
+        const int r0 = band0 + seg * seg_len, r1 = r0 + seg_len < band1 ? r0 + seg_len : band1;
+        int xa = 0x7FFFFFFF, xb = -0x7FFFFFFF, mh = 0;
+        for (int r = r0; r < r1; r++) {
+            const int4 b = boxes[r * tiles_x + t.tx];
+            if (b.z > 0) {
+                xa = b.x < xa ? b.x : xa;
+                xb = b.x + 4 * b.z > xb ? b.x + 4 * b.z : xb;
+                mh = b.w > mh ? b.w : mh;
+            }
+        }
+        t.x0 = xb > xa ? xa : 0;
+        t.bw = xb > xa ? (xb - xa) >> 2 : 1;
+        t.ok = t.bw <= kRingBW && mh <= kRingRows - 2 && t.bw * mh <= 256;
+        t.ty = r0;
+    };
+    auto load_box = [&](RingTile &t) {
+        const int4 b = boxes[t.ty * tiles_x + t.tx];
+        t.any = b.z > 0;
+        t.y0 = b.y; t.bh = b.w;
+    };
+    auto advance = [&](const RingTile &c, RingTile &n) {   // the tile after c in this workgroup's walk
+        n = c;
+        const int seg = c.item / tiles_x;
+        const int r1 = band0 + (seg + 1) * seg_len < band1 ? band0 + (seg + 1) * seg_len : band1;
+        if (c.ty + 1 < r1) n.ty = c.ty + 1;
+        else enter_item(c.item + nbx, n);
+        if (n.valid) load_box(n);
+    };
+
+    // ring state (uniform): rows [lo, hi) of geometry (rx0, rbw) are in LDS
+    int lo = 0, hi = 0, rx0 = 0, rbw = -1;
+    struct Ld { int y0, y1, x0, bw; bool on; };
+    auto plan = [&](const RingTile &t, int plo, int phi, int px0, int pbw) -> Ld {   // rows to load for tile t
+        Ld l; l.on = t.valid && t.ok && t.any; l.x0 = t.x0; l.bw = t.bw; l.y0 = l.y1 = 0;
+        if (!l.on) return l;
+        const bool cont = pbw == t.bw && px0 == t.x0 && t.y0 >= plo && t.y0 <= phi;
+        l.y0 = cont ? (phi > t.y0 ? phi : t.y0) : t.y0;
+        l.y1 = t.y0 + t.bh;
+        if (l.y1 < l.y0) l.y1 = l.y0;
+        return l;
+    };
+    auto after = [&](const RingTile &t, const Ld &l, int &plo, int &phi, int &px0, int &pbw) {   // ring after the commit
+        if (!l.on) return;
+        const bool cont = pbw == t.bw && px0 == t.x0 && t.y0 >= plo && t.y0 <= phi;
+        phi = cont ? (phi > l.y1 ? phi : l.y1) : l.y1;
+        plo = t.y0; px0 = t.x0; pbw = t.bw;
+    };
+
+    unsigned pre[NP];
+    auto issue = [&](const Ld &l) {
+        const int E = l.on ? (l.y1 - l.y0) * l.bw : 0;
+        const float inv = 1.0f / (float)(l.bw > 0 ? l.bw : 1);
+        const int e = (int)threadIdx.x;
+        const int rr = (int)(((float)e + 0.5f) * inv);
+        const int cc = e - rr * l.bw;
+        const int gx = l.x0 + 4 * cc, gy = l.y0 + rr;
+        const bool in = e < E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
+#pragma unroll
+        for (int p = 0; p < NP; p++) pre[p] = *reinterpret_cast<const unsigned *>(plane(p) + off);
+    };
+    auto commit = [&](const Ld &l) {
+        if (!l.on) return;
+        const int E = (l.y1 - l.y0) * l.bw;
+        const int e = (int)threadIdx.x;
+        if (e < E) {
+            const float inv = 1.0f / (float)l.bw;
+            const int rr = (int)(((float)e + 0.5f) * inv);
+            const int cc = e - rr * l.bw;
+            const int gx = l.x0 + 4 * cc, gy = l.y0 + rr;
+            const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            u32x2 *dst = reinterpret_cast<u32x2 *>(tile + (size_t)(((gy & (kRingRows - 1)) * l.bw + cc) * (NP * 4)));
+#pragma unroll
+            for (int p = 0; p < NP; p += 2) {
+                u32x2 w2;
+                w2.x = in ? pre[p] : 0u; w2.y = in ? pre[p + 1] : 0u;
+                dst[p >> 1] = w2;
+            }
+        }
+    };
+
+    RingTile cur;
+    enter_item(lb, cur);
+    if (!cur.valid) return;
+    load_box(cur);
+    Ld ld = plan(cur, lo, hi, rx0, rbw);
+    issue(ld);
+    for (;;) {
+        commit(ld);
+        after(cur, ld, lo, hi, rx0, rbw);
+        __syncthreads();
+        RingTile nxt;
+        advance(cur, nxt);
+        const int col = cur.tx * kTileW + lane;
+        unsigned xy[TH / 4], fr[TH / 4];
+#pragma unroll
+        for (int q = 0; q < TH / 4; q++) {                  // this tile's map entries first (older than the prefetch)
+            const int row = cur.ty * TH + 4 * q + wv;
+            const bool inb = row < H && col < W;
+            const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
+            xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+            fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
+        }
+        const Ld ldn = plan(nxt, lo, hi, rx0, rbw);
+        issue(ldn);
+#pragma unroll
+        for (int q = 0; q < TH / 4; q++) {
+            const int row = cur.ty * TH + 4 * q + wv;
+            const bool inb = row < H && col < W;
+            const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+            int v;
+            float ph;
+            if (cur.ok) {
+                // tile_taps_map with ring addressing: row slot = source row & 15, columns relative to the item
+                TileTaps<NP> k;
+                const int sx = (int)(short)(xy[q] & 0xFFFFu), sy = (int)xy[q] >> 16;
+                const bool out = !inb || !cur.any || (unsigned)(sx + 1) > (unsigned)W || (unsigned)(sy + 1) > (unsigned)H;
+                const unsigned fx = fr[q] & 31u, fy = (fr[q] >> 5) & 31u;
+                const unsigned wxp = out ? 0u : __umul24(fx, 0xFFFFu) + 32u;
+                unsigned w0 = __umul24(wxp, (32u - fy) << 6);
+                const unsigned w1 = __umul24(wxp, fy << 6);
+                w0 = w0 == 0x10000u ? 0xFFFFu : w0;
+                const int bx = out ? 0 : sx - cur.x0;
+                const int s0 = out ? 0 : (sy & (kRingRows - 1)), s1 = out ? 0 : ((sy + 1) & (kRingRows - 1));
+                k.a0 = __mul24(__mul24(s0, cur.bw) + (bx >> 2), NP * 4);
+                k.a1 = __mul24(__mul24(s1, cur.bw) + (bx >> 2), NP * 4);
+                k.sel = __umul24((unsigned)bx & 3u, 0x10001u) + 0x0C010C00u;
+                k.w0 = __builtin_bit_cast(u16x2, w0);
+                k.w1 = __builtin_bit_cast(u16x2, w1);
+                int acc[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) acc[p] = tile_sample<NP, 6>(tile, k, p);
+                ph = mf_pixel_sh<16>(acc, black_thr, lut, v);
+            } else {                                        // the item does not fit the ring: direct gather
+                Tap t = make_tap((int)(short)(xy[q] & 0xFFFFu), (int)xy[q] >> 16, fr[q], pitch, W, H);
+                if (!inb) t.kind = 1;
+                int gpx[NP];
+#pragma unroll 1
+                for (int p = 0; p < NP; p++) gpx[p] = cur.any ? sample(plane(p), pitch, W, H, t) : 0;
+                ph = mf_pixel(gpx, black_thr, lut, v);
+            }
+            const unsigned long long bal = __ballot(v != 0);
+            const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+            const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+            if (inb) {
+                __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
+                if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            }
+        }
+        if (!nxt.valid) break;
+        __syncthreads();
+        cur = nxt;
+        ld = ldn;
+    }
+}
+
 static unsigned pick_blocks(size_t groups)
 {
     // One workgroup per 256 work items (no persistent grid-stride): with a capped grid the last sweep leaves
@@ -810,6 +1017,34 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
                                   const float *atan_lut, int rect_algo, hipStream_t s)
 {
     const int tiles_x = (W + kTileW - 1) / kTileW;
+    if (rect_algo == 3) {                                // sliding-window form
+        const int tiles_y8 = (H + kMidTileH - 1) / kMidTileH;
+        RectJobs jr;
+        jr.j[0] = jobs[0]; jr.j[1] = jobs[njobs - 1];
+        const size_t off8 = tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH);
+        jr.j[0].boxes += off8; jr.j[1].boxes += off8;
+        const size_t lds = (size_t)kRingRows * kRingBW * SLR_MF_PLANES * 4 + 16;
+        static int ring_cache[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!ring_cache[dev & 63]) {
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_ring_kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            ring_cache[dev & 63] = per_cu * cus;
+        }
+        const char *dbgr = getenv("SLR_DEBUG_RECT_RESIDENT");
+        const int res = (dbgr && atoi(dbgr) > 0 ? atoi(dbgr) : ring_cache[dev & 63]) / njobs;
+        int nbx = res / 8 > 0 ? res / 8 : 1;
+        const int R = (tiles_y8 + 7) / 8;                    // tile rows per XCD band
+        if (nbx > R * tiles_x) nbx = R * tiles_x;
+        int seg_len = (R * tiles_x + 4 * nbx - 1) / (4 * nbx);   // ~4 items per workgroup
+        if (seg_len < 4) seg_len = 4;
+        if (seg_len > R) seg_len = R > 0 ? R : 1;
+        hipLaunchKernelGGL(mf_rect_decode_ring_kernel, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(256), lds, s, jr, njobs,
+                           pitch, W, H, black_thr, atan_lut, tiles_x, tiles_y8, seg_len);
+        return hipGetLastError();
+    }
     // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
     // than one per tile
     const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two

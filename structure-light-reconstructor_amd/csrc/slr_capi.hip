@@ -927,7 +927,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->opt_mf_decode_vec = value;
             return SLR_OK;
         case SLR_OPT_RECT_DECODE_ALGO:
-            if (value < 0 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0, 1 or 2");
+            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..3");
             c->opt_rect_algo = value;
             return SLR_OK;
         default:
