@@ -84,6 +84,10 @@ if "--gray" in sys.argv:
     torch.cuda.synchronize()
     run("gray_decode", lambda: ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0), 2 + 2 * ncol + 5.0)
     run("gray_rectify_decode", lambda: ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0, rectify_cam=0), 2 + 2 * ncol + 6 + 5.0)
+    def _gboth():
+        ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0, rectify_cam=0)
+        ctx.gray_decode(g[1], ncol, 0, 40, 0, W, 0, rectify_cam=1)
+    run("gray_rectify_decode L,R alternating (cold)", _gboth, 2 + 2 * ncol + 6 + 5.0)
     dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0) for cam in range(2)]
     run("ge_match", lambda: ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False), 23.0)
 if "--ray" in sys.argv:
