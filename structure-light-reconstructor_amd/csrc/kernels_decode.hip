@@ -645,6 +645,7 @@ __device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int 
 // decodes job 0, the second half job 1 -- one launch gap and one tail less per frame).
 struct RectJob {
     MfPlanes pl;
+    unsigned plane_stride;       // > 0: the 14 planes are pl.p[0] + i * plane_stride (one buffer descriptor serves all)
     const int16_t *map_xy;
     const uint16_t *map_frac;
     const int4 *boxes;
@@ -654,7 +655,11 @@ struct RectJob {
 
 struct RectJobs { RectJob j[2]; };
 
-template <int TH, int ROUNDS>
+// STRIDED: the planes of a job are equally spaced in ONE allocation (every stack this library stages itself, and the
+// batch entry point).  The box is then fetched with raw buffer loads: one descriptor per job, the plane as the scalar
+// offset -- no per-plane 64-bit address arithmetic -- and everything outside the image is given an out-of-range offset,
+// for which the hardware returns 0 (= BORDER_CONSTANT): no select on the way into LDS either.
+template <int TH, int ROUNDS, bool STRIDED>
 __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
@@ -669,7 +674,13 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
     // the job table stays in the kernarg segment and is indexed there (scalar loads on demand): no local copy (a
     // dynamically indexed local array would live in scratch) and no 2 x 19 pointers held in SGPRs
     const int ji = second ? 1 : 0;
-    auto plane = [&](int p) -> const uint8_t * { return jobs.j[ji].pl.p[p]; };
+    auto plane = [&](int p) -> const uint8_t * {
+        if constexpr (STRIDED) return jobs.j[ji].pl.p[0] + (size_t)p * jobs.j[ji].plane_stride;
+        else return jobs.j[ji].pl.p[p];
+    };
+    const unsigned pstride = jobs.j[ji].plane_stride;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)jobs.j[ji].pl.p[0], 0, (int)((NP - 1) * pstride + (unsigned)H * (unsigned)pitch), 0x00020000);
     const int16_t *__restrict__ map_xy = jobs.j[ji].map_xy;
     const uint16_t *__restrict__ map_frac = jobs.j[ji].map_frac;
     const int4 *__restrict__ boxes = jobs.j[ji].boxes;
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
     unsigned pre[ROUNDS][NP];
     auto issue = [&](const BoxGeom &g, bool live) {
         const int E = live && g.fits ? g.BH * g.BW4 : 0;
-        const float inv = 1.0f / (float)(g.BW4 > 0 ? g.BW4 : 1);
+        const float inv = __builtin_amdgcn_rcpf((float)(g.BW4 > 0 ? g.BW4 : 1));   // v_rcp_f32: 1 ulp, see the margin below
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
             const int e = (int)threadIdx.x + 256 * r;
@@ -696,14 +707,22 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
             const int gx = g.x0 + 4 * cc, gy = g.y0 + rr;
             // W % 4 == 0 and gx % 4 == 0: a dword is completely inside or completely outside the image
             const bool in = e < E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
+            // branch-free 32-bit offset: keeps the loads in the scalar-base + 32-bit-VGPR-offset addressing form
+            if constexpr (STRIDED) {
+                const unsigned off = in ? __umul24((unsigned)gy, (unsigned)pitch) + (unsigned)gx : 0xFFFFFFF0u;   // out of range -> 0
 #pragma unroll
-            for (int p = 0; p < NP; p++) pre[r][p] = *reinterpret_cast<const unsigned *>(plane(p) + off);
+                for (int p = 0; p < NP; p++)
+                    pre[r][p] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, (int)(p * pstride), 0);
+            } else {
+                const unsigned off = (__umul24((unsigned)gy, (unsigned)pitch) + (unsigned)gx) & (0u - (unsigned)in);
+#pragma unroll
+                for (int p = 0; p < NP; p++) pre[r][p] = *reinterpret_cast<const unsigned *>(plane(p) + off);
+            }
         }
     };
     auto commit = [&](const BoxGeom &g) {                   // same predicate as issue(); outside the image -> 0
         const int E = g.BH * g.BW4;
-        const float inv = 1.0f / (float)g.BW4;
+        const float inv = __builtin_amdgcn_rcpf((float)g.BW4);
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
             const int e = (int)threadIdx.x + 256 * r;
@@ -711,7 +730,7 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
                 const int rr = (int)(((float)e + 0.5f) * inv);
                 const int cc = e - rr * g.BW4;
                 const int gx = g.x0 + 4 * cc, gy = g.y0 + rr;
-                const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+                const bool in = STRIDED || ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W);   // STRIDED: zeros came from the load
                 u32x2 *dst = reinterpret_cast<u32x2 *>(tile + (size_t)e * (NP * 4));
 #pragma unroll
                 for (int p = 0; p < NP; p += 2) {
@@ -889,13 +908,13 @@ __global__ __launch_bounds__(256, 5) void mf_rect_decode_ring_kernel(RectJobs jo
     unsigned pre[NP];
     auto issue = [&](const Ld &l) {
         const int E = l.on ? (l.y1 - l.y0) * l.bw : 0;
-        const float inv = 1.0f / (float)(l.bw > 0 ? l.bw : 1);
+        const float inv = __builtin_amdgcn_rcpf((float)(l.bw > 0 ? l.bw : 1));
         const int e = (int)threadIdx.x;
         const int rr = (int)(((float)e + 0.5f) * inv);
         const int cc = e - rr * l.bw;
         const int gx = l.x0 + 4 * cc, gy = l.y0 + rr;
         const bool in = e < E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
+        const unsigned off = (__umul24((unsigned)gy, (unsigned)pitch) + (unsigned)gx) & (0u - (unsigned)in);
 #pragma unroll
         for (int p = 0; p < NP; p++) pre[p] = *reinterpret_cast<const unsigned *>(plane(p) + off);
     };
@@ -904,7 +923,7 @@ __global__ __launch_bounds__(256, 5) void mf_rect_decode_ring_kernel(RectJobs jo
         const int E = (l.y1 - l.y0) * l.bw;
         const int e = (int)threadIdx.x;
         if (e < E) {
-            const float inv = 1.0f / (float)l.bw;
+            const float inv = __builtin_amdgcn_rcpf((float)l.bw);
             const int rr = (int)(((float)e + 0.5f) * inv);
             const int cc = e - rr * l.bw;
             const int gx = l.x0 + 4 * cc, gy = l.y0 + rr;
@@ -1010,7 +1029,8 @@ static bool rect_lds_ok(const MfPlanes &pl, int pitch, int W, int H, const float
     bool aligned = pitch % 4 == 0;
     for (int p = 0; p < SLR_MF_PLANES; p++) aligned = aligned && ((uintptr_t)pl.p[p] % 4 == 0);
     return map_xy && tile_boxes && W % 4 == 0 && aligned && rect_algo != 1 && ((uintptr_t)phase % 16 == 0) &&
-           ((uintptr_t)valid % 4 == 0) && (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32);
+           ((uintptr_t)valid % 4 == 0) && (long long)W * H < (1ll << 30) && (long long)H * pitch < (1ll << 32) &&
+           pitch < (1 << 24);                                  // (row * pitch is a 24-bit multiply)
 }
 
 static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int W, int H, int black_thr,
@@ -1056,14 +1076,25 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
     // resident workgroups of this kernel on the CURRENT device (cached per device and kernel variant)
+    // strided planes?  (both jobs)
+    bool strided = true;
+    for (int jq = 0; jq < 2; jq++) {
+        const uint8_t *const *pp = j.j[jq].pl.p;
+        const long long st = (long long)(pp[1] - pp[0]);
+        bool ok = st >= (long long)H * pitch && st * SLR_MF_PLANES < (1ll << 31);
+        for (int i = 2; i < SLR_MF_PLANES && ok; i++) ok = (long long)(pp[i] - pp[0]) == st * i;
+        j.j[jq].plane_stride = ok ? (unsigned)st : 0u;
+        strided = strided && ok;
+    }
+    if (getenv("SLR_DEBUG_RECT_NO_BUFFER")) strided = false;   // tests: force the pointer form
     static int resident_cache[64][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     int &resident_slot = resident_cache[dev & 63][mid];
     if (!resident_slot) {
         int per_cu = 0, cus = 0;
-        const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1>, 256, (size_t)budget + 16)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2>, 256, (size_t)budget + 16);
+        const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true>, 256, (size_t)budget + 16)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, (size_t)budget + 16);
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident_slot = per_cu * cus;
@@ -1075,12 +1106,12 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     int nbx = res / 8 < per ? res / 8 : per;
     if (nbx < 1) nbx = 1;
     const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);
-    if (mid)
-        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
-                           pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
-    else
-        hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kTileH, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
-                           pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+#define SLR_RECT_LAUNCH(TH_, R_, S_)                                                                                  \
+    hipLaunchKernelGGL((mf_rect_decode_lds_kernel<TH_, R_, S_>), grid, dim3(256), (size_t)budget + 16, s, j, njobs, pitch, W, \
+                       H, black_thr, atan_lut, tiles_x, tiles_yy, budget)
+    if (mid) { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
+    else     { if (strided) SLR_RECT_LAUNCH(kTileH, 2, true); else SLR_RECT_LAUNCH(kTileH, 2, false); }
+#undef SLR_RECT_LAUNCH
     return hipGetLastError();
 }
 
@@ -1095,7 +1126,7 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
     for (int c = 0; c < 2; c++)
         if (!rect_lds_ok(pl[c], pitch, W, H, phase[c], valid[c], map_xy[c], tile_boxes[c], rect_algo)) return hipSuccess;
     RectJob jobs[2];
-    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c]};
+    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], 0u, map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c]};
     *done = true;
     return launch_rect_lds(jobs, 2, pitch, W, H, black_thr, atan_lut, rect_algo, s);
 }
@@ -1105,7 +1136,7 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
     if (rect_lds_ok(pl, pitch, W, H, phase, valid, map_xy, tile_boxes, rect_algo)) {
-        const RectJob job{pl, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid};
+        const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid};
         return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
     }
     if (map_xy) {
@@ -1272,7 +1303,7 @@ __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl
     if (fits) {
         // W % 4 == 0, x0 % 4 == 0 and dword-aligned planes (launcher): a source dword is inside or outside as a whole
         const int E = BH * BW4;
-        const float inv = 1.0f / (float)BW4;
+        const float inv = __builtin_amdgcn_rcpf((float)BW4);
         for (int e = threadIdx.x; e < E; e += 256) {
             const int rr = (int)(((float)e + 0.5f) * inv);
             const int cc = e - rr * BW4;
