@@ -1275,8 +1275,8 @@ __global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_c
 // immediate).  The samples stay in the high half-word of the dot-product accumulators (weights x 64, see
 // tile_taps_map) and are compared / subtracted in place.
 // ------------------------------------------------------------------------------------------------------
-template <int TH>
-__global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl, int n_col_bits, int n_row_bits, int pitch,
+template <int TH, bool STRIDED>
+__global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl, unsigned pstride, int n_col_bits, int n_row_bits, int pitch,
                                                                    int W, int H, int black_thr, int white_thr, int scan_w,
                                                                    int scan_h, const int16_t *__restrict__ map_xy,
                                                                    const uint16_t *__restrict__ map_frac,
@@ -1309,17 +1309,33 @@ __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl
             const int cc = e - rr * BW4;
             const int gx = x0 + 4 * cc, gy = y0 + rr;
             const bool in = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
             uint8_t *dst = tile + (size_t)(rr * NP) * rowstep + 4 * cc;
             // 16 independent loads in flight per thread, then 16 LDS stores (a plain p-loop waits per load)
-            for (int pb = 0; pb < NP; pb += 16) {
-                unsigned v[16];
+            if constexpr (STRIDED) {
+                // equally spaced planes: raw buffer loads, plane = scalar offset, outside the image -> hardware zero
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)pl.p[0], 0, (int)((unsigned)(NP - 1) * pstride + (unsigned)H * (unsigned)pitch), 0x00020000);
+                const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0xFFFFFFF0u;
+                for (int pb = 0; pb < NP; pb += 16) {
+                    unsigned v[16];
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    v[i] = (pb + i < NP) ? *reinterpret_cast<const unsigned *>(pl.p[pb + i] + off) : 0u;
+                    for (int i = 0; i < 16; i++)
+                        v[i] = (pb + i < NP) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, (int)((pb + i) * pstride), 0) : 0u;
 #pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = in ? v[i] : 0u;
+                    for (int i = 0; i < 16; i++)
+                        if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = v[i];
+                }
+            } else {
+                const unsigned off = in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : 0u;
+                for (int pb = 0; pb < NP; pb += 16) {
+                    unsigned v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        v[i] = (pb + i < NP) ? *reinterpret_cast<const unsigned *>(pl.p[pb + i] + off) : 0u;
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (pb + i < NP) *reinterpret_cast<unsigned *>(dst + (pb + i) * rowstep) = in ? v[i] : 0u;
+                }
             }
         }
         __syncthreads();
@@ -1425,14 +1441,16 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
         const int tiles_y = (H + th - 1) / th;
         const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
         const int4 *boxes = (const int4 *)tile_boxes + tile_count(W, H, kTileH) + (mid ? tile_count(W, H, kGrayTileH) : 0);
-        if (mid)
-            hipLaunchKernelGGL(gray_rect_decode_lds_kernel<kMidTileH>, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,
-                               n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac,
-                               boxes, code_x, code_y, valid, tiles_x, tiles_y, budget);
-        else
-            hipLaunchKernelGGL(gray_rect_decode_lds_kernel<kGrayTileH>, dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,
-                               n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, map_frac,
-                               boxes, code_x, code_y, valid, tiles_x, tiles_y, budget);
+        long long st = nplanes > 1 ? (long long)(pl.p[1] - pl.p[0]) : 0;
+        bool strided = st >= (long long)H * pitch && st * nplanes < (1ll << 31) && !getenv("SLR_DEBUG_RECT_NO_BUFFER");
+        for (int i = 2; i < nplanes && strided; i++) strided = (long long)(pl.p[i] - pl.p[0]) == st * i;
+#define SLR_GRAY_LDS(TH_, S_)                                                                                          \
+        hipLaunchKernelGGL((gray_rect_decode_lds_kernel<TH_, S_>), dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,     \
+                           (unsigned)st, n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, \
+                           map_frac, boxes, code_x, code_y, valid, tiles_x, tiles_y, budget)
+        if (mid) { if (strided) SLR_GRAY_LDS(kMidTileH, true); else SLR_GRAY_LDS(kMidTileH, false); }
+        else     { if (strided) SLR_GRAY_LDS(kGrayTileH, true); else SLR_GRAY_LDS(kGrayTileH, false); }
+#undef SLR_GRAY_LDS
         return hipGetLastError();
     }
     bool a4 = (W % 4 == 0) && ((uintptr_t)code_x % 16 == 0) && ((uintptr_t)valid % 4 == 0) &&
