@@ -95,6 +95,12 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of 1.13x the algorithmic HBM bytes, ~3 %
  * slower because the kernel is VALU-bound).  Identical results. */
 #define SLR_OPT_RECT_DECODE_ALGO 3
+/* SLR_OPT_ASYNC_HOST: 1 = calls with SLR_MEM_HOST buffers return once the H2D copies, the kernels and the D2H copies
+ * are ENQUEUED on the ctx stream; outputs are valid (and inputs reusable) only after slr_synchronize(ctx).  The host
+ * buffers should be pinned (hipHostMalloc / cudaHostRegister-style) for the copies to be truly asynchronous.  Two ctx on
+ * one GPU, fed alternately, overlap the upload of frame i+1, the kernels of frame i and the download of frame i-1
+ * (the pinned double-buffered loader of SURVEY 8f-1).  Default 0: host-buffer calls are synchronous. */
+#define SLR_OPT_ASYNC_HOST 4
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */

@@ -53,6 +53,7 @@ struct slr_ctx {
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
     int opt_rect_algo = 0;         // SLR_OPT_RECT_DECODE_ALGO
+    int opt_async_host = 0;        // SLR_OPT_ASYNC_HOST
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
@@ -163,7 +164,7 @@ struct Stage {
     {
         if (mem == SLR_MEM_DEVICE) return SLR_OK;
         for (auto &o : outs) SLR_HIP(c, hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, c->stream));
-        SLR_HIP(c, hipStreamSynchronize(c->stream));
+        if (!c->opt_async_host) SLR_HIP(c, hipStreamSynchronize(c->stream));   // SLR_OPT_ASYNC_HOST: the caller syncs
         return SLR_OK;
     }
 };
@@ -929,6 +930,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_RECT_DECODE_ALGO:
             if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..3");
             c->opt_rect_algo = value;
+            return SLR_OK;
+        case SLR_OPT_ASYNC_HOST:
+            if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_ASYNC_HOST must be 0 or 1");
+            c->opt_async_host = value;
             return SLR_OK;
         default:
             return fail(c, SLR_ERR_INVALID_ARG, "unknown option");

@@ -616,3 +616,30 @@ def test_error_paths(slr, synth):
         c.mf_decode(pl, 40, W=32)                      # pitch < W
     assert e.value.status == slr.capi.ERR_INVALID_ARG
     c.close()
+
+
+def test_async_host_option_double_buffering(slr, synth, oracle):
+    """SLR_OPT_ASYNC_HOST: host-buffer calls only enqueue; two contexts fed alternately (the double-buffered loader of
+    SURVEY 8f-1) must give the results of the synchronous call once synchronised"""
+    W, H = 256, 64
+    calib, _ = synth.make_calibration(W, H)
+    frames = [synth.render_mf_stack(W, H, seed=900 + f) for f in range(4)]
+    pinned = [[f[c].contiguous().pin_memory().numpy() for c in range(2)] for f in frames]
+    ref = slr.Context(0)
+    ref.set_calibration(calib)
+    exp = [ref.reconstruct_mf(p[0], p[1], BLACK, False) for p in pinned]
+    ref.close()
+    ctxs = [slr.Context(0) for _ in range(2)]
+    outs = [(torch.empty((H, W, 3), dtype=torch.float32).pin_memory().numpy(), torch.empty((H, W), dtype=torch.uint8).pin_memory().numpy())
+            for _ in range(4)]
+    for c in ctxs:
+        c.set_calibration(calib)
+        c.set_option(slr.capi.OPT_ASYNC_HOST, 1)
+    for f in range(4):
+        ctxs[f % 2].reconstruct_mf(pinned[f][0], pinned[f][1], BLACK, False, xyz=outs[f][0], has=outs[f][1])
+    for c in ctxs:
+        c.synchronize()
+    for f in range(4):
+        assert bits_equal(outs[f][1], exp[f][1]) and bits_equal(outs[f][0], exp[f][0]), f
+    for c in ctxs:
+        c.close()
