@@ -62,6 +62,10 @@ def parse_args():
                     help="frames in flight per GPU: S contexts (one HIP stream each) take the steps in turn, so the match of frame i "
                          "overlaps the decode of frame i+1 (application-level double buffering).  Default 1: kernels run back to "
                          "back and the per-kernel roofline is undisturbed")
+    ap.add_argument("--pitch-pad", type=int, default=0,
+                    help="bytes of row padding of the HBM-resident stacks (pitch = width + pad).  A pitch that is a power of two "
+                         "(4096) puts the ~10 source rows of every tile of the rectifying decode on the same HBM channels: the "
+                         "fused kernel is 3-6 %% faster with 64..1152 bytes of padding (the unfused one 1-3 %% slower)")
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 default, 1 gather, 2 64x16 tiles, 3 ring)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
@@ -148,10 +152,10 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
     L, R = host[0].numpy(), host[1].numpy()
     xyz = torch.empty((H, W, 3), dtype=torch.float32).pin_memory().numpy()
     has = torch.empty((H, W), dtype=torch.uint8).pin_memory().numpy()
-    ctx.reconstruct_mf(L, R, BLACK_THR, rectify, xyz=xyz, has=has)
+    ctx.reconstruct_mf(L, R, BLACK_THR, rectify, W=W, xyz=xyz, has=has)
     t0 = time.perf_counter()
     for _ in range(3):
-        ctx.reconstruct_mf(L, R, BLACK_THR, rectify, xyz=xyz, has=has)
+        ctx.reconstruct_mf(L, R, BLACK_THR, rectify, W=W, xyz=xyz, has=has)
     dt = (time.perf_counter() - t0) / 3
     out = {"value": round(W * H / dt / 1e6, 1), "unit": "Mpix/s", "ms_per_frame": round(dt * 1e3, 3),
            "bytes_in": int(host.numel()), "bytes_out": int(xyz.nbytes + has.nbytes),
@@ -172,7 +176,7 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
             outs.append((torch.empty((H, W, 3), dtype=torch.float32).pin_memory().numpy(),
                          torch.empty((H, W), dtype=torch.uint8).pin_memory().numpy()))
         for k in range(2):
-            ctxs[k].reconstruct_mf(L, R, BLACK_THR, rectify, xyz=outs[k][0], has=outs[k][1])
+            ctxs[k].reconstruct_mf(L, R, BLACK_THR, rectify, W=W, xyz=outs[k][0], has=outs[k][1])
         for k in range(2):
             ctxs[k].synchronize()
         n = 8
@@ -180,7 +184,7 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
         for i in range(n):
             k = i % 2
             ctxs[k].synchronize()                           # frame i-2 of this slot is complete: its buffers are free again
-            ctxs[k].reconstruct_mf(L, R, BLACK_THR, rectify, xyz=outs[k][0], has=outs[k][1])
+            ctxs[k].reconstruct_mf(L, R, BLACK_THR, rectify, W=W, xyz=outs[k][0], has=outs[k][1])
         for k in range(2):
             ctxs[k].synchronize()
         dt2 = (time.perf_counter() - t0) / n
@@ -241,7 +245,11 @@ def main():
             for cam in range(2):
                 c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
     # one synthetic stereo frame per rank (seed 1234 + rank), resident in HBM
-    stack = synth.render_mf_stack(W, H, seed=1234 + rank, noise=2, device=dev).unsqueeze(0).contiguous()
+    rendered = synth.render_mf_stack(W, H, seed=1234 + rank, noise=2, device=dev)
+    pitch = W + max(0, args.pitch_pad)
+    stack = torch.zeros((1, 2, 14, H, pitch), dtype=torch.uint8, device=dev)      # rows padded: see --pitch-pad
+    stack[0, :, :, :, :W] = rendered
+    del rendered
     torch.cuda.synchronize()
 
     nbuf = 2 if S == 1 else S
@@ -262,7 +270,7 @@ def main():
         b = i % nbuf
         if do_gather:
             streams[i % S].wait_event(done_gather[b])   # buffer b is free again once its gather finished
-        ctxs[i % S].reconstruct_mf_batch(stack, BLACK_THR, bool(args.rectify), xyz=xyz[b], has=has[b])
+        ctxs[i % S].reconstruct_mf_batch(stack, BLACK_THR, bool(args.rectify), W=W, xyz=xyz[b], has=has[b])
         if do_gather:
             done_compute[b].record(streams[i % S])
             comm.wait_event(done_compute[b])
@@ -363,11 +371,12 @@ def main():
         ph = torch.empty((H, W), dtype=torch.float32, device=dev)
         vd = torch.empty((H, W), dtype=torch.uint8, device=dev)
         for _ in range(reps):
-            ctx.mf_decode(stack[0, 0], BLACK_THR, phase=ph, valid=vd)
+            ctx.mf_decode(stack[0, 0], BLACK_THR, W=W, phase=ph, valid=vd)
         if args.rectify:
             tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
+            plane3 = stack[0, 0, 3, :, :W].contiguous()
             for _ in range(reps):
-                ctx.remap_u8(0, stack[0, 0, 3], out=tmp)
+                ctx.remap_u8(0, plane3, out=tmp)
         for name, (ms, n) in sorted(ctx.profile().items()):
             gbs = ALG_BYTES[name] * npix / (ms / n * 1e-3) / 1e9
             extras.append({"name": name, "launches": n, "avg_us": round(ms / n * 1e3, 2), "alg_bytes_per_px": ALG_BYTES[name],
@@ -387,7 +396,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_baseline:
         rows = args.cpu_rows or H          # whole frame: ~8 s of single-thread CPU work at 4096x3000
         maps_cpu = None if maps is None else [(m[0].cpu().numpy(), m[1].cpu().numpy()) for m in maps]
-        cpu = cpu_baseline(synth, W, H, stack[0].cpu().numpy(), maps_cpu, calib, rows)
+        cpu = cpu_baseline(synth, W, H, np.ascontiguousarray(stack[0, :, :, :, :W].cpu().numpy()), maps_cpu, calib, rows)
 
     if rank == 0:
         out = {
@@ -398,6 +407,7 @@ def main():
             "config": {"workload": "1x %dx%d stereo, 3-freq x 4-step (14 planes/camera) rectify+decode+unwrap+match+"
                                    "triangulate per GPU per step" % (W, H),
                        "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify), "streams_per_gpu": S,
+                       "stack_row_pitch_bytes": pitch,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else
                            (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else

@@ -220,10 +220,7 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
     constexpr int V = 4 * NW;
     const int gpr = W / V;                                  // launcher guarantees W % V == 0
     const unsigned total = (unsigned)gpr * (unsigned)H;
-    for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
-        unsigned row, col0;
-        if (pitch == W) { row = 0; col0 = g * V; }          // flat image: no row arithmetic
-        else { row = g / gpr; col0 = (g - row * gpr) * V; }
+    auto process = [&](unsigned row, unsigned col0) {
         // 32-bit byte offsets (image < 2 GiB, checked by the C ABI): lets the compiler use the SGPR-base + VGPR-offset
         // addressing form instead of a 64-bit add per plane
         const unsigned so = row * (unsigned)pitch + col0, oo = row * (unsigned)W + col0;
@@ -254,6 +251,15 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
         else if constexpr (NW == 2) { vv.x = vout[0]; vv.y = vout[1]; }
         else { vv.x = vout[0]; vv.y = vout[1]; vv.z = vout[2]; vv.w = vout[3]; }
         __builtin_nontemporal_store(vv, reinterpret_cast<vec_t *>(valid + oo));
+    };
+    if (gridDim.y > 1) {                                    // padded rows: one image row per blockIdx.y, no division
+        const unsigned c = blockIdx.x * 256u + threadIdx.x;
+        if (c < (unsigned)gpr) process(blockIdx.y, c * V);
+    } else {                                                // flat image (pitch == W): no row arithmetic at all
+        for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
+            if (pitch == W) process(0u, g * V);
+            else { const unsigned row = g / gpr; process(row, (g - row * gpr) * V); }
+        }
     }
 }
 
@@ -1164,6 +1170,9 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a8 && vec_hint == 8)
                   hipLaunchKernelGGL(mf_decode_kernel<2>, dim3(pick_blocks((size_t)(W / 8) * H)), dim3(256), 0, s,
+                                     pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    else if (a4 && pitch != W && H > 1 && H <= 65535)       // padded rows: (row, column group) grid
+                  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3((unsigned)((W / 4 + 255) / 256), (unsigned)H), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
