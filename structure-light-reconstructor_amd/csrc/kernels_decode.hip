@@ -547,7 +547,43 @@ static size_t tile_count(int W, int H, int tile_h)
 {
     return (size_t)((W + kTileW - 1) / kTileW) * ((H + tile_h - 1) / tile_h);
 }
-hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s)
+// The same buffer also carries a TILED copy of the map for the 64 x 8 kernel: the 512 entries of a tile are contiguous and
+// ordered (pass, wave, lane) = the order in which the workgroup's threads consume them, so a wave reads 256 contiguous
+// bytes per pass instead of 8 x 256 B pieces 16 KB apart (rows of a 4096-wide map are a power of two apart: the same HBM
+// channel and bank).  Entries of ragged tiles beyond the image are "outside the source" (x = y = 32767).
+static size_t tiled_map_offset(int W, int H)
+{
+    const size_t b = (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) + tile_count(W, H, kMidTileH)) * sizeof(int4);
+    return (b + 255) & ~(size_t)255;
+}
+size_t tile_boxes_bytes(int W, int H)
+{
+    return tiled_map_offset(W, H) + tile_count(W, H, kMidTileH) * 512 * (sizeof(unsigned) + sizeof(uint16_t));
+}
+
+__global__ __launch_bounds__(256) void tile_maps_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                        int W, int H, int tiles_x, unsigned *__restrict__ xy_t,
+                                                        uint16_t *__restrict__ fr_t)
+{
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < kMidTileH / 4; q++) {
+        const int row = ty * kMidTileH + 4 * q + wv, col = tx * kTileW + lane;
+        unsigned xy = 0x7FFF7FFFu;
+        unsigned fr = 0;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
+            fr = map_frac[m];
+        }
+        const size_t d = (size_t)blockIdx.x * 512 + q * 256 + threadIdx.x;
+        xy_t[d] = xy;
+        fr_t[d] = (uint16_t)fr;
+    }
+}
+
+hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, hipStream_t s)
 {
     const int tiles_x = (W + kTileW - 1) / kTileW;
     hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
@@ -556,13 +592,12 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, h
                        kGrayTileH, boxes + tile_count(W, H, kTileH));
     hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kMidTileH, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH));
+    unsigned *xy_t = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tiled_map_offset(W, H));
+    uint16_t *fr_t = reinterpret_cast<uint16_t *>(xy_t + tile_count(W, H, kMidTileH) * 512);
+    hipLaunchKernelGGL(tile_maps_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, map_frac, W, H,
+                       tiles_x, xy_t, fr_t);
     return hipGetLastError();
 }
-size_t tile_boxes_bytes(int W, int H)
-{
-    return (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) + tile_count(W, H, kMidTileH)) * sizeof(int4);
-}
-
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
 __device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ plane, int pitch, int W, int H, int gx, int gy)
 {
@@ -657,6 +692,8 @@ struct RectJob {
     const int4 *boxes;
     float *phase;
     uint8_t *valid;
+    const unsigned *xy_t;        // tiled copy of the map for 64 x 8 tiles (see tile_maps_kernel), or null
+    const uint16_t *fr_t;
 };
 
 struct RectJobs { RectJob j[2]; };
@@ -692,6 +729,8 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
     const int4 *__restrict__ boxes = jobs.j[ji].boxes;
     float *__restrict__ phase = jobs.j[ji].phase;
     uint8_t *__restrict__ valid = jobs.j[ji].valid;
+    const unsigned *__restrict__ xy_t = jobs.j[ji].xy_t;
+    const uint16_t *__restrict__ fr_t = jobs.j[ji].fr_t;
     // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
     // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
     // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
@@ -766,11 +805,17 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds
         unsigned xy[TH / 4], fr[TH / 4];
 #pragma unroll
         for (int q = 0; q < TH / 4; q++) {
-            const int row = ty * TH + 4 * q + wv;
-            const bool inb = row < H && col < W;
-            const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
-            xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
-            fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
+            if (TH == kMidTileH && xy_t) {                  // tiled map: contiguous per tile, padded -> no bounds
+                const unsigned d = (unsigned)cur * 512u + (unsigned)(q * 256) + threadIdx.x;
+                xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(xy_t) + d * 4u);
+                fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(fr_t) + d * 2u);
+            } else {
+                const int row = ty * TH + 4 * q + wv;
+                const bool inb = row < H && col < W;
+                const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
+                xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+                fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
+            }
         }
         issue(gn, has_next);
 #pragma unroll
@@ -1080,6 +1125,11 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     const size_t box_off = mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0;
     RectJobs j;
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
+    for (int jq = 0; jq < 2; jq++) {                      // the tiled map copy lives behind the box tables (launch_tile_boxes)
+        const char *basep = reinterpret_cast<const char *>(j.j[jq].boxes);
+        j.j[jq].xy_t = mid && !getenv("SLR_DEBUG_RECT_NO_TILED_MAP") ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
+        j.j[jq].fr_t = j.j[jq].xy_t ? reinterpret_cast<const uint16_t *>(j.j[jq].xy_t + tile_count(W, H, kMidTileH) * 512) : nullptr;
+    }
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
     // resident workgroups of this kernel on the CURRENT device (cached per device and kernel variant)
     // strided planes?  (both jobs)
@@ -1132,7 +1182,7 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
     for (int c = 0; c < 2; c++)
         if (!rect_lds_ok(pl[c], pitch, W, H, phase[c], valid[c], map_xy[c], tile_boxes[c], rect_algo)) return hipSuccess;
     RectJob jobs[2];
-    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], 0u, map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c]};
+    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], 0u, map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c], nullptr, nullptr};
     *done = true;
     return launch_rect_lds(jobs, 2, pitch, W, H, black_thr, atan_lut, rect_algo, s);
 }
@@ -1142,7 +1192,7 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
     if (rect_lds_ok(pl, pitch, W, H, phase, valid, map_xy, tile_boxes, rect_algo)) {
-        const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid};
+        const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, nullptr, nullptr};
         return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
     }
     if (map_xy) {

@@ -488,7 +488,7 @@ int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint1
     const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
     SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
-    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }
@@ -499,7 +499,7 @@ int slr_init_rectify_maps(slr_ctx *c, int cam, const double M[9], const double D
     if (!c || !M || !D || !R || !P) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
     SLR_TRY(map_storage(c, cam, W, H));
     SLR_HIP(c, launch_init_rectify_map(M, D, R, P, W, H, c->d_map_xy[cam], c->d_map_frac[cam], c->stream));
-    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }

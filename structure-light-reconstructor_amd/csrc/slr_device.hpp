@@ -63,7 +63,7 @@ hipError_t launch_init_rectify_map(const double M[9], const double D[5], const d
 
 // per-tile source bounding boxes of a rectification map (64x16 destination tiles), int4 per tile
 size_t     tile_boxes_bytes(int W, int H);
-hipError_t launch_tile_boxes(const int16_t *map_xy, int W, int H, int4 *boxes, hipStream_t s);
+hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, hipStream_t s);
 
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
