@@ -55,7 +55,10 @@ def parse_args():
                     help="N>1: RCCL all-gather of the point cloud: once per job right after the timed steps, timed separately "
                          "(after, default), once per job inside the timed region (final), "
                          "after every step (overlapped with the next step's compute), or never")
-    ap.add_argument("--profile", type=int, default=1, help="bracket every kernel with HIP events (roofline)")
+    ap.add_argument("--profile", type=int, default=1, help="bracket kernels with HIP events (roofline)")
+    ap.add_argument("--profile-stride", type=int, default=4,
+                    help="bracket every n-th launch of a kernel inside the timed region (two event records per launch cost ~2.5 %% "
+                         "of a 0.35 ms step each; 1 = every launch)")
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the CPU triangulation sample (0 = auto)")
     ap.add_argument("--streams", type=int, default=1,
@@ -290,6 +293,7 @@ def main():
     sync_all()
     if args.profile:
         for c_ in ctxs:
+            c_.set_option(slr.capi.OPT_PROFILE_STRIDE, max(1, args.profile_stride))
             c_.profile_enable(True)
             c_.profile_reset()
     sync_all()
@@ -325,6 +329,7 @@ def main():
                 a = prof.get(name, (0.0, 0))
                 prof[name] = (a[0] + ms, a[1] + n)
             c_.profile_enable(False)
+            c_.set_option(slr.capi.OPT_PROFILE_STRIDE, 1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -407,7 +412,7 @@ def main():
             "config": {"workload": "1x %dx%d stereo, 3-freq x 4-step (14 planes/camera) rectify+decode+unwrap+match+"
                                    "triangulate per GPU per step" % (W, H),
                        "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify), "streams_per_gpu": S,
-                       "stack_row_pitch_bytes": pitch,
+                       "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else
                            (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else

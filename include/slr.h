@@ -101,6 +101,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * one GPU, fed alternately, overlap the upload of frame i+1, the kernels of frame i and the download of frame i-1
  * (the pinned double-buffered loader of SURVEY 8f-1).  Default 0: host-buffer calls are synchronous. */
 #define SLR_OPT_ASYNC_HOST 4
+/* SLR_OPT_PROFILE_STRIDE: the built-in HIP-event profiler brackets every n-th launch of a kernel (default 1 = all) */
+#define SLR_OPT_PROFILE_STRIDE 5
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */
