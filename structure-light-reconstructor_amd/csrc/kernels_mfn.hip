@@ -16,6 +16,8 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 
+#pragma clang diagnostic ignored "-Wpass-failed"   // the run-time (FS = NS = 0) variant cannot fully unroll its plane loops
+
 namespace slr {
 
 constexpr float kTruePI = 3.14159265358979323846f;
@@ -57,12 +59,12 @@ __global__ __launch_bounds__(256) void mfn_decode_kernel(MfnPlanes pl, MfnTrig t
         const float mod2 = (0.25f * n_step) * (0.25f * n_step);        // (B_min * N / 2)^2 with B_min = 0.5
 #pragma unroll
         for (int v = 0; v < V; v++) ok[v] = wh[v] - bk[v] > black_thr;
-#pragma unroll(FS ? FS : 1)
+#pragma unroll
         for (int f = 0; f < n_freq; f++) {
             float S[V], C[V];
 #pragma unroll
             for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
-#pragma unroll(NS ? NS : 1)
+#pragma unroll
             for (int k = 0; k < n_step; k++) {
                 float I[V];
                 load(2 + f * n_step + k, I);
