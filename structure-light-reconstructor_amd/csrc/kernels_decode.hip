@@ -27,44 +27,48 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // per-pixel math
 // ------------------------------------------------------------------------------------------------------
 
-// mfreconstruct.cpp:246-261.  n = G4-G2, d = G1-G3.  These kernels turned out to be VALU-bound on MI355X (PMC: ~140
-// integer/f32 instructions per pixel at 16 lanes/clk, HBM traffic already at the algorithmic minimum), so the branch
-// chain is folded into three small LDS tables (LDS reads run on their own pipe) filled by the host:
-//   lutA[q + 255]   = atanf((float)q), q = the C integer quotient n / d in [-255, 255]
-//   lutR[d + 255]   = 65536 / |d| + 1 (0 for d == 0):  floor(|n| / |d|) == (|n| * R) >> 16 exactly for |n|,|d| <= 255
-//                     (checked for all 256 x 255 pairs in tests/test_oracle_known_answers.py and, on the device, by the
-//                     exhaustive 511 x 511 image of tests/test_gpu_parity.py)
-//   lutO[3*(sgn d + 1) + (sgn n + 1)] = the quadrant offset: d<0 -> PI; d>0 -> (n>0 ? 2PI : 0);
-//                     d==0 -> (n<0 ? PI/2 : n>0 ? 3PI/2 : 0)
-// P = a + offset reproduces every branch: for d == 0 the quotient is forced to 0 (R = 0), atanf(0) = +0 and +0 + x = x;
-// the n == 0 branches (:246-249) equal the general formula for the same reason; a + 0.0f == a for the no-offset branch.
-constexpr int kLutA = 0, kLutR = 511, kLutO = 1022, kLutWords = 1031;
+// mfreconstruct.cpp:246-261.  n = G4-G2, d = G1-G3.  These kernels turned out to be VALU-bound on MI355X (PMC: the
+// fused decode issues ~190 integer/f32 instructions per pixel at 16 lanes/clk, HBM traffic already at the algorithmic
+// minimum), so the whole branch chain of a wrapped phase is folded into two LDS tables (LDS reads run on their own pipe)
+// filled by the host (slr_capi.hip, slr_create):
+//   lutR[d + 255] = R | S << 24.  R = 65536 / |d| + 1 (0 for d == 0): with t = n * R (24-bit signed multiply, the upper
+//                   byte is ignored) s = t >> 16 (arithmetic) is floor(|n| / |d|) for n >= 0 and ~floor(|n| / |d|)
+//                   for n < 0 -- exact for all |n|,|d| <= 255 (tests/test_oracle_known_answers.py; on the device the
+//                   exhaustive 511 x 511 image of tests/test_gpu_parity.py).  S = 2 / 9 / 6 for d < 0 / == 0 / > 0.
+//   lutP[((S + sgn n) << 8) + s] = P * 2^24 as an integer, P = atanf((float)q) + offset exactly as the f32 expression
+//                   of the reference evaluates it (host libm: the device never evaluates a transcendental), q = the C
+//                   quotient n / d, offset: d<0 -> PI; d>0 -> (n>0 ? 2PI : 0); d==0 -> (n<0 ? PI/2 : n>0 ? 3PI/2 : 0;
+//                   n == 0 is the reference's undefined P, Q5).  The slots (S-2 full, S one entry, S+1 full) of the
+//                   three signs of d do not overlap.  Every P is 0 or at least 0.5 in magnitude and below 8, i.e. a
+//                   multiple of 2^-24 below 2^27: the integer holds it exactly.
+constexpr int kLutR = 0, kLutP = 512, kLutWords = kDecodeLutWords;
+constexpr int kQ24TwoPI = (int)(kTwoPI * 16777216.0f);      // 2*PI as the reference's float, times 2^24: an integer
 
-__device__ __forceinline__ float wrapped_phase(int G1, int G2, int G3, int G4, const float *lut, int &nz)
+__device__ __forceinline__ int wrapped_phase_q24(int G1, int G2, int G3, int G4, const float *lut, int &nz)
 {
-    const unsigned *lutu = reinterpret_cast<const unsigned *>(lut);
+    const int *luti = reinterpret_cast<const int *>(lut);
     const int n = G4 - G2, d = G1 - G3;
-    const int an = n < 0 ? -n : n;
-    const unsigned R = lutu[kLutR + 255 + d];
-    const int qa = (int)(__umul24((unsigned)an, R) >> 16);           // |n| <= 255, R <= 65537: 24-bit multiply is exact
-    const int m = (n ^ d) >> 31;                      // 0 or -1: the quotient's sign
-    const float a = lut[kLutA + 255 + ((qa ^ m) - m)];
-    int sd, sn;                                       // sign() = clamp to [-1, 1] = one v_med3_i32 (hipcc otherwise
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sd) : "v"(d));      // emits two compares and two selects per sign)
-    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sn) : "v"(n));
-    const float off = lut[kLutO + 4 + __mul24(3, sd) + sn];
+    const int e = luti[kLutR + 255 + d];
+    const int s = __mul24(n, e) >> 16;
+    int sn;                                           // sign() = clamp to [-1, 1] = one v_med3_i32 (hipcc otherwise
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sn) : "v"(n));      // emits two compares and two selects)
     nz = n | d;                                       // == 0 <=> the reference leaves P[count] undefined (:254-255, Q5)
-    return a + off;
+    return luti[kLutP + ((int)(((unsigned)e >> 24) + sn) << 8) + s];
 }
 
-// mfreconstruct.cpp:265-268: P[] are doubles, P12/P23 computed in f64 and narrowed once, rest f32.
-__device__ __forceinline__ float heterodyne(float P0f, float P1f, float P2f)
+// mfreconstruct.cpp:265-268: P[] are doubles (holding f32 values), P12/P23 computed in f64 and narrowed once, the rest
+// f32.  The f64 difference of two P (plus the f64 image of the float 2*PI) is exact, and so is the same expression on
+// the 2^24-scaled integers; the one rounding of the f64 -> f32 narrowing is the rounding of v_cvt_f32_i32 (both
+// round-to-nearest-even).  The f32 part runs on the scaled values (a power-of-two scale commutes with every rounding:
+// nothing is near the subnormal range) and is scaled back once.
+__device__ __forceinline__ float heterodyne_q24(int P0, int P1, int P2)
 {
-    const double P0 = P0f, P1 = P1f, P2 = P2f;
-    const double two_pi = (double)kTwoPI;
-    const float P12 = (float)((P0 > P1) ? (P0 - P1) : (P0 - P1 + two_pi));
-    const float P23 = (float)((P1 > P2) ? (P1 - P2) : (P1 - P2 + two_pi));
-    const float P123 = (P12 > P23) ? (P12 - P23) : (P12 - P23 + kTwoPI);
+    const int d12 = P0 - P1, d23 = P1 - P2;
+    const float F12 = (float)(d12 + ((P0 > P1) ? 0 : kQ24TwoPI));
+    const float F23 = (float)(d23 + ((P1 > P2) ? 0 : kQ24TwoPI));
+    constexpr float two_pi_q24 = kTwoPI * 16777216.0f;
+    const float F123 = (F12 > F23) ? (F12 - F23) : (F12 - F23 + two_pi_q24);
+    const float P123 = F123 * (1.0f / 16777216.0f);
     // P123 / (2*PI) * 255 (:268).  The correctly rounded quotient by a constant without the 10-instruction IEEE division
     // sequence (Markstein): q = x*rc, r = fma(-q, c, x) (exact), q' = fma(r, rc, q) == RN(x / c) when rc = RN(1/c) --
     // checked against x / c for every finite f32 x with 1e-30 <= |x| <= 1e30 (P123 is in (0, 4*PI]).
@@ -86,10 +90,10 @@ __device__ __forceinline__ float mf_pixel_sh(const int *gs, int black_thr, const
     // computeShadows :198-204: (float)white - (float)black > blackThreshold (exact in integers)
     const bool mask = g[0] - g[1] > black_thr;
     int nz0, nz1, nz2;
-    const float P0 = wrapped_phase(g[2], g[3], g[4], g[5], lut, nz0);
-    const float P1 = wrapped_phase(g[6], g[7], g[8], g[9], lut, nz1);
-    const float P2 = wrapped_phase(g[10], g[11], g[12], g[13], lut, nz2);
-    const float ph = heterodyne(P0, P1, P2);
+    const int P0 = wrapped_phase_q24(g[2], g[3], g[4], g[5], lut, nz0);
+    const int P1 = wrapped_phase_q24(g[6], g[7], g[8], g[9], lut, nz1);
+    const int P2 = wrapped_phase_q24(g[10], g[11], g[12], g[13], lut, nz2);
+    const float ph = heterodyne_q24(P0, P1, P2);
     valid = (mask && nz0 != 0 && nz1 != 0 && nz2 != 0) ? 1 : 0;   // Q5 rule: an undefined P makes the pixel invalid
     return mask ? ph : 0.0f;
 }
@@ -252,9 +256,10 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
         else { vv.x = vout[0]; vv.y = vout[1]; vv.z = vout[2]; vv.w = vout[3]; }
         __builtin_nontemporal_store(vv, reinterpret_cast<vec_t *>(valid + oo));
     };
-    if (gridDim.y > 1) {                                    // padded rows: one image row per blockIdx.y, no division
+    if (gridDim.y > 1) {                                    // padded rows: image rows blockIdx.y + k gridDim.y, no division
         const unsigned c = blockIdx.x * 256u + threadIdx.x;
-        if (c < (unsigned)gpr) process(blockIdx.y, c * V);
+        if (c < (unsigned)gpr)
+            for (unsigned row = blockIdx.y; row < (unsigned)H; row += gridDim.y) process(row, c * V);
     } else {                                                // flat image (pitch == W): no row arithmetic at all
         for (unsigned g = blockIdx.x * 256u + threadIdx.x; g < total; g += gridDim.x * 256u) {
             if (pitch == W) process(0u, g * V);
@@ -703,7 +708,7 @@ struct RectJobs { RectJob j[2]; };
 // offset -- no per-plane 64-bit address arithmetic -- and everything outside the image is given an out-of-range offset,
 // for which the hardware returns 0 (= BORDER_CONSTANT): no select on the way into LDS either.
 template <int TH, int ROUNDS, bool STRIDED>
-__global__ __launch_bounds__(256, (ROUNDS == 1 ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
+__global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
 {
@@ -1073,6 +1078,21 @@ static unsigned pick_blocks(size_t groups)
     return (unsigned)(((b ? b : 1) + 7) & ~(size_t)7);
 }
 
+// K2's grid: every workgroup first copies the 12 KB decode tables to LDS, so beyond the resident set (8 workgroups of
+// 256 on each CU) the grid is capped and the kernel's grid-stride loop takes over -- 12 000 one-shot workgroups at
+// 4096x3000 re-read 147 MB of tables from L2 next to 233 MB of pixels (measured: 48.6 instead of 44 us).  Few sweeps
+// keep the old back-filling grid (see above); from 4 sweeps on the uneven last sweep costs less than the tables.
+static unsigned pick_blocks_k2(size_t groups)
+{
+    static int cus_of[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &cus = cus_of[dev & 63];
+    if (cus == 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)) cus = 256;
+    const unsigned b = pick_blocks(groups), resident = (unsigned)cus * 8u;
+    return b >= 4 * resident ? resident : b;
+}
+
 // the LDS-tiled fused kernel needs dword-aligned planes and outputs and 32-bit offsets
 static bool rect_lds_ok(const MfPlanes &pl, int pitch, int W, int H, const float *phase, const uint8_t *valid,
                         const int16_t *map_xy, const void *tile_boxes, int rect_algo)
@@ -1143,14 +1163,18 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         strided = strided && ok;
     }
     if (getenv("SLR_DEBUG_RECT_NO_BUFFER")) strided = false;   // tests: force the pointer form
-    static int resident_cache[64][2] = {};
+    static int resident_cache[64][2][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &resident_slot = resident_cache[dev & 63][mid];
+    int &resident_slot = resident_cache[dev & 63][mid][strided];
     if (!resident_slot) {
         int per_cu = 0, cus = 0;
-        const hipError_t e = mid ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true>, 256, (size_t)budget + 16)
-                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, (size_t)budget + 16);
+        const size_t dyn = (size_t)budget + 16;
+        const hipError_t e =
+            mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true>, 256, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false>, 256, dyn))
+                : (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, false>, 256, dyn));
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident_slot = per_cu * cus;
@@ -1216,17 +1240,23 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
     // measured on MI355X at 4096x3000: 4 px/thread 56.8 us, 8 px 58.5 us, 16 px 69.4 us (the 16-px form stores 64-byte
     // strided fragments per lane; the 4-px form writes one contiguous KiB per wave instruction) -> default 4
     if (a16 && vec_hint == 16)
-                  hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 16) * H)), dim3(256), 0, s,
+                  hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks_k2((size_t)(W / 16) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a8 && vec_hint == 8)
-                  hipLaunchKernelGGL(mf_decode_kernel<2>, dim3(pick_blocks((size_t)(W / 8) * H)), dim3(256), 0, s,
+                  hipLaunchKernelGGL(mf_decode_kernel<2>, dim3(pick_blocks_k2((size_t)(W / 8) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
-    else if (a4 && pitch != W && H > 1 && H <= 65535)       // padded rows: (row, column group) grid
-                  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3((unsigned)((W / 4 + 255) / 256), (unsigned)H), dim3(256), 0, s,
+    else if (a4 && pitch != W && H > 1) {                   // padded rows: (column group, row) grid, rows strided
+        const unsigned gx = (unsigned)((W / 4 + 255) / 256), cap = pick_blocks_k2((size_t)(W / 4) * H);
+        unsigned gy = (cap + gx - 1) / gx;
+        if (gy > (unsigned)H) gy = (unsigned)H;
+        if (gy > 65535u) gy = 65535u;
+        if (gy < 2u) gy = 2u;                               // gridDim.y > 1 selects this form in the kernel
+                  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(gx, gy), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
-    else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
+    }
+    else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks_k2((size_t)(W / 4) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
-    else          hipLaunchKernelGGL(mf_decode_scalar_kernel, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
+    else          hipLaunchKernelGGL(mf_decode_scalar_kernel, dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     return hipGetLastError();
 }

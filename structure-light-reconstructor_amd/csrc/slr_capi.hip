@@ -370,20 +370,39 @@ int slr_create(int device_id, slr_ctx **out)
         if (hipSetDevice(device_id) != hipSuccess) { st = SLR_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { st = SLR_ERR_HIP; break; }
         c->own_stream = true;
-        // decode tables (kernels_decode.hip, wrapped_phase): atanf over the integer quotients -- filled by
-        // the host libm so the device never evaluates a transcendental (no libm-vs-ocml ULP drift) -- the 16-bit
-        // reciprocals of |d| and the 3x3 quadrant offsets of mfreconstruct.cpp:246-261
-        union { float f; unsigned u; } lut[kDecodeLutWords];
-        for (int q = -255; q <= 255; q++) lut[q + 255].f = atanf((float)q);
-        for (int d = -255; d <= 255; d++) lut[511 + d + 255].u = d == 0 ? 0u : 65536u / (unsigned)(d < 0 ? -d : d) + 1u;
+        // decode tables (kernels_decode.hip, wrapped_phase_q24): per difference d the 16-bit reciprocal of |d| with the
+        // table slot of sgn d in the top byte, and the wrapped phase itself -- atanf over the integer quotient (SURVEY
+        // Q1) plus the quadrant offset of mfreconstruct.cpp:246-261, evaluated by the host libm in the reference's f32
+        // arithmetic so the device never evaluates a transcendental (no libm-vs-ocml ULP drift) -- as 2^24-scaled integers
+        int lut[kDecodeLutWords] = {};
         {
+            bool used[kDecodeLutWords] = {}, bad = false;
             const float PI = kPI;
-            const float off[9] = {PI, PI, PI,                      /* d < 0 : atan + PI             (:256-257) */
-                                  PI / 2, 0.0f, 3 * PI / 2,        /* d == 0: n<0 PI/2, n==0 undefined, n>0 3PI/2 (:250-255) */
-                                  0.0f, 0.0f, 2 * PI};             /* d > 0 : n>0 atan + 2PI else atan (:258-261, :246-247) */
-            for (int i = 0; i < 9; i++) lut[1022 + i].f = off[i];
+            const float off[3][3] = {{PI, PI, PI},                  /* d < 0 : atan + PI             (:256-257) */
+                                     {PI / 2, 0.0f, 3 * PI / 2},    /* d == 0: n<0 PI/2, n==0 undefined, n>0 3PI/2 (:250-255) */
+                                     {0.0f, 0.0f, 2 * PI}};         /* d > 0 : n>0 atan + 2PI else atan (:258-261, :246-247) */
+            const int slot[3] = {2, 9, 6};
+            for (int d = -255; d <= 255; d++) {
+                const int sd = (d > 0) - (d < 0);
+                const unsigned R = d == 0 ? 0u : 65536u / (unsigned)(d < 0 ? -d : d) + 1u;
+                lut[d + 255] = (int)(R | (unsigned)slot[sd + 1] << 24);
+            }
+            for (int sd = -1; sd <= 1; sd++)
+                for (int sn = -1; sn <= 1; sn++)
+                    for (int qa = 0; qa <= 255; qa++) {
+                        if ((sd == 0 || sn == 0) && qa != 0) continue;
+                        const int q = sd * sn * qa;                          /* the C quotient n / d */
+                        const int sidx = sn < 0 && sd != 0 ? ~qa : qa;        /* (n * R) >> 16, arithmetic */
+                        volatile float P = atanf((float)q) + off[sd + 1][sn + 1];
+                        const double scaled = (double)P * 16777216.0;
+                        const int w = 512 + ((slot[sd + 1] + sn) << 8) + sidx;
+                        if (scaled != (double)(int)scaled || w < 512 || w >= kDecodeLutWords || used[w]) { bad = true; continue; }
+                        lut[w] = (int)scaled;
+                        used[w] = true;
+                    }
+            if (bad) { st = SLR_ERR_HIP; break; }       /* cannot happen: the table layout is checked here once per context */
         }
-        if (hipMalloc(&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
+        if (hipMalloc((void **)&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
         if (hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) { st = SLR_ERR_HIP; break; }
         if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) { st = SLR_ERR_HIP; break; }
     } while (0);

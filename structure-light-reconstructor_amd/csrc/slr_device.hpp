@@ -13,7 +13,7 @@ constexpr float kPI = 3.1416f;
 constexpr float kTwoPI = 2 * kPI;          // f32 expression, as in the reference (2*PI)
 constexpr float kThreeHalfPI = 3 * kPI / 2;
 constexpr float kHalfPI = kPI / 2;
-constexpr int kDecodeLutWords = 1031;      // 511 atanf + 511 reciprocals + 9 quadrant offsets (kernels_decode.hip)
+constexpr int kDecodeLutWords = 512 + 10 * 256 + 1;   // 511 reciprocal/sign words + the wrapped-phase table (kernels_decode.hip)
 
 struct MfPlanes { const uint8_t *p[SLR_MF_PLANES]; };
 struct GrayPlanes { const uint8_t *p[SLR_MAX_GRAY_PLANES]; };
