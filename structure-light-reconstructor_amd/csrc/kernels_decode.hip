@@ -33,7 +33,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // filled by the host (slr_capi.hip, slr_create):
 //   lutR[d + 255] = R | S << 24.  R = 65536 / |d| + 1 (0 for d == 0): with t = n * R (24-bit signed multiply, the upper
 //                   byte is ignored) s = t >> 16 (arithmetic) is floor(|n| / |d|) for n >= 0 and ~floor(|n| / |d|)
-//                   for n < 0 -- exact for all |n|,|d| <= 255 (tests/test_oracle_known_answers.py; on the device the
+//                   for n < 0 -- exact for all |n|,|d| <= 255 (tests/test_decode_tables.py; on the device the
 //                   exhaustive 511 x 511 image of tests/test_gpu_parity.py).  S = 2 / 9 / 6 for d < 0 / == 0 / > 0.
 //   lutP[((S + sgn n) << 8) + s] = P * 2^24 as an integer, P = atanf((float)q) + offset exactly as the f32 expression
 //                   of the reference evaluates it (host libm: the device never evaluates a transcendental), q = the C
