@@ -93,7 +93,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_RECT_DECODE_ALGO: fused rectify+decode form: 0 = LDS-tiled, 64x8 tiles per persistent workgroup with a
  * register prefetch pipeline (default), 1 = direct gather, 2 = as 0 with 64x16 tiles, 3 = as 0 but walking down tile
  * columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of 1.13x the algorithmic HBM bytes, ~3 %
- * slower because the kernel is VALU-bound).  Identical results. */
+ * slower), 4 = as 0 with 128x8 tiles and two prefetch rounds (fewer, longer source row segments; no faster in the
+ * two-camera launch).  Identical results. */
 #define SLR_OPT_RECT_DECODE_ALGO 3
 /* SLR_OPT_ASYNC_HOST: 1 = calls with SLR_MEM_HOST buffers return once the H2D copies, the kernels and the D2H copies
  * are ENQUEUED on the ctx stream; outputs are valid (and inputs reusable) only after slr_synchronize(ctx).  The host

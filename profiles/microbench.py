@@ -61,6 +61,9 @@ run("mf_decode L,R alternating (cold MALL)", _both_plain, 19.0)
 ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 3)
 run("mf_rectify_decode ring", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
 run("mf_rectify_decode ring L,R alternating", _both, 25.0)
+ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 4)
+run("mf_rectify_decode tiles128x8", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+run("mf_rectify_decode tiles128x8 L,R alternating", _both, 25.0)
 ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 2)
 run("mf_rectify_decode tiles64x16", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
 run("mf_rectify_decode tiles64x16 L,R alternating", _both, 25.0)

@@ -552,10 +552,20 @@ static size_t tile_count(int W, int H, int tile_h)
 {
     return (size_t)((W + kTileW - 1) / kTileW) * ((H + tile_h - 1) / tile_h);
 }
-// The same buffer also carries a TILED copy of the map for the 64 x 8 kernel: the 512 entries of a tile are contiguous and
-// ordered (pass, wave, lane) = the order in which the workgroup's threads consume them, so a wave reads 256 contiguous
-// bytes per pass instead of 8 x 256 B pieces 16 KB apart (rows of a 4096-wide map are a power of two apart: the same HBM
-// channel and bank).  Entries of ragged tiles beyond the image are "outside the source" (x = y = 32767).
+// The same buffer also carries a TILED, PRE-DIGESTED copy of the map for the 64 x 8 kernel: the 512 entries of a tile are
+// contiguous and ordered (pass, wave, lane) = the order in which the workgroup's threads consume them, so a wave reads
+// 256 contiguous bytes per pass instead of 8 x 256 B pieces 16 KB apart (rows of a 4096-wide map are a power of two
+// apart: the same HBM channel and bank) -- and an entry is ONE dword instead of the map's 4 + 2 bytes, already relative
+// to the tile's source box (tile_boxes_kernel), which is what the kernel would compute from it anyway:
+//   [9:0]   dword index of the tap's upper left byte in the box: (sy - y0) * BW4 + ((sx - x0) >> 2)
+//   [11:10] (sx - x0) & 3        [16:12] fx        [21:17] fy        (cv::remap's 5-bit fractions)
+//   [31]    the sample is 0: pixel beyond the ragged image edge, or footprint completely outside the source
+// Tiles whose box does not fit the kernel's LDS budget are decoded by the gather fallback from the caller's map.
+constexpr int kMidBudget = 12 * 1024;                      // LDS bytes of a 64 x 8 tile's box: 14 planes x ~72 x 11
+__device__ __host__ inline bool mid_box_fits(int BW4, int BH)
+{
+    return BW4 > 0 && BW4 * BH <= 256 && BW4 * BH * (SLR_MF_PLANES * 4) <= kMidBudget;
+}
 static size_t tiled_map_offset(int W, int H)
 {
     const size_t b = (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) + tile_count(W, H, kMidTileH)) * sizeof(int4);
@@ -563,28 +573,31 @@ static size_t tiled_map_offset(int W, int H)
 }
 size_t tile_boxes_bytes(int W, int H)
 {
-    return tiled_map_offset(W, H) + tile_count(W, H, kMidTileH) * 512 * (sizeof(unsigned) + sizeof(uint16_t));
+    return tiled_map_offset(W, H) + tile_count(W, H, kMidTileH) * 512 * sizeof(unsigned);
 }
 
 __global__ __launch_bounds__(256) void tile_maps_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
-                                                        int W, int H, int tiles_x, unsigned *__restrict__ xy_t,
-                                                        uint16_t *__restrict__ fr_t)
+                                                        int W, int H, int tiles_x, const int4 *__restrict__ boxes8,
+                                                        unsigned *__restrict__ pk_t)
 {
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int4 box = boxes8[blockIdx.x];
+    const bool fits = mid_box_fits(box.z, box.w);
 #pragma unroll
     for (int q = 0; q < kMidTileH / 4; q++) {
         const int row = ty * kMidTileH + 4 * q + wv, col = tx * kTileW + lane;
-        unsigned xy = 0x7FFF7FFFu;
-        unsigned fr = 0;
-        if (row < H && col < W) {
+        unsigned e = 0x80000000u;
+        if (fits && row < H && col < W) {
             const size_t m = (size_t)row * W + col;
-            xy = *reinterpret_cast<const unsigned *>(map_xy + 2 * m);
-            fr = map_frac[m];
+            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+            const unsigned fr = map_frac[m];
+            if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {
+                const int bx = sx - box.x, r0 = sy - box.y;
+                e = (unsigned)(r0 * box.z + (bx >> 2)) | ((unsigned)bx & 3u) << 10 | (fr & 1023u) << 12;
+            }
         }
-        const size_t d = (size_t)blockIdx.x * 512 + q * 256 + threadIdx.x;
-        xy_t[d] = xy;
-        fr_t[d] = (uint16_t)fr;
+        pk_t[(size_t)blockIdx.x * 512 + q * 256 + threadIdx.x] = e;
     }
 }
 
@@ -597,10 +610,9 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, in
                        kGrayTileH, boxes + tile_count(W, H, kTileH));
     hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kMidTileH, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH));
-    unsigned *xy_t = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tiled_map_offset(W, H));
-    uint16_t *fr_t = reinterpret_cast<uint16_t *>(xy_t + tile_count(W, H, kMidTileH) * 512);
+    unsigned *pk_t = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tiled_map_offset(W, H));
     hipLaunchKernelGGL(tile_maps_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, map_frac, W, H,
-                       tiles_x, xy_t, fr_t);
+                       tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH), pk_t);
     return hipGetLastError();
 }
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
@@ -652,6 +664,24 @@ __device__ __forceinline__ TileTaps<NP> tile_taps_map(unsigned xy, unsigned frac
     return k;
 }
 
+// the same tap state from one pre-digested entry of the tiled map (tile_maps_kernel)
+template <int NP>
+__device__ __forceinline__ TileTaps<NP> tile_taps_packed(unsigned e, int BW4)
+{
+    TileTaps<NP> k;
+    const unsigned fx = (e >> 12) & 31u, fy6 = (e >> 11) & 0x7C0u;         // fy << 6
+    const unsigned wxp = (int)e < 0 ? 0u : __umul24(fx, 0xFFFFu) + 32u;     // (32 - fx) | fx << 16
+    unsigned w0 = __umul24(wxp, 2048u - fy6);                             // see tile_taps_map for the x 64 and the 0xFFFF
+    const unsigned w1 = __umul24(wxp, fy6);
+    w0 = w0 == 0x10000u ? 0xFFFFu : w0;
+    k.a0 = (int)__umul24(e & 1023u, NP * 4);
+    k.a1 = k.a0 + __mul24(BW4, NP * 4);
+    k.sel = __umul24((e >> 10) & 3u, 0x10001u) + 0x0C010C00u;
+    k.w0 = __builtin_bit_cast(u16x2, w0);
+    k.w1 = __builtin_bit_cast(u16x2, w1);
+    return k;
+}
+
 // blended sample of plane p: LDS reads are (base + immediate), 2 perms, 2 dot2, 1 shift
 template <int NP, int WSHIFT>
 __device__ __forceinline__ int tile_sample(const uint8_t *tile, const TileTaps<NP> &k, int p)
@@ -675,12 +705,27 @@ __device__ __forceinline__ int tile_sample(const uint8_t *tile, const TileTaps<N
 // compiler's s_waitcnt for the map entries is vmcnt(28) on every path and never drains the prefetch.
 struct BoxGeom { int x0, y0, BW4, BH; bool any, fits; };
 
-template <int NP, int ROUNDS>
-__device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int tile, int budget)
+// TWV == 2: the tile is 128 x TH, the union of two horizontally adjacent 64 x TH tiles of the box table (`tile` counts
+// 128-wide tiles, tiles_x of them per row; the table has tiles_x64 per row)
+template <int NP, int ROUNDS, int TWV>
+__device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int tile, int budget, int tiles_x, int tiles_x64)
 {
-    const int4 box = boxes[tile];
     BoxGeom g;
-    g.x0 = box.x; g.y0 = box.y; g.BW4 = box.z; g.BH = box.w;
+    if constexpr (TWV == 1) {
+        const int4 box = boxes[tile];
+        g.x0 = box.x; g.y0 = box.y; g.BW4 = box.z; g.BH = box.w;
+    } else {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int t0 = ty * tiles_x64 + 2 * tx;
+        const int4 a = boxes[t0];
+        int4 b = boxes[2 * tx + 1 < tiles_x64 ? t0 + 1 : t0];
+        const int4 l = a.z > 0 ? a : b, r = b.z > 0 ? b : a;           // an empty half takes the other half's box
+        const int x0 = l.x < r.x ? l.x : r.x, y0 = l.y < r.y ? l.y : r.y;
+        const int x1l = l.x + 4 * l.z, x1r = r.x + 4 * r.z, y1l = l.y + l.w, y1r = r.y + r.w;
+        g.x0 = x0; g.y0 = y0;
+        g.BW4 = ((x1l > x1r ? x1l : x1r) - x0) >> 2;
+        g.BH = (y1l > y1r ? y1l : y1r) - y0;
+    }
     g.any = g.BW4 > 0;
     // the LDS budget, and the prefetch registers: at most ROUNDS x 256 dwords per plane
     g.fits = g.any && g.BW4 * g.BH <= 256 * ROUNDS && g.BW4 * g.BH * (NP * 4) <= budget;
@@ -697,8 +742,7 @@ struct RectJob {
     const int4 *boxes;
     float *phase;
     uint8_t *valid;
-    const unsigned *xy_t;        // tiled copy of the map for 64 x 8 tiles (see tile_maps_kernel), or null
-    const uint16_t *fr_t;
+    const unsigned *pk_t;        // tiled, pre-digested copy of the map for 64 x 8 tiles (see tile_maps_kernel), or null
 };
 
 struct RectJobs { RectJob j[2]; };
@@ -707,7 +751,7 @@ struct RectJobs { RectJob j[2]; };
 // batch entry point).  The box is then fetched with raw buffer loads: one descriptor per job, the plane as the scalar
 // offset -- no per-plane 64-bit address arithmetic -- and everything outside the image is given an out-of-range offset,
 // for which the hardware returns 0 (= BORDER_CONSTANT): no select on the way into LDS either.
-template <int TH, int ROUNDS, bool STRIDED>
+template <int TH, int ROUNDS, bool STRIDED, int TWV = 1, bool PACKED = false>
 __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
@@ -734,8 +778,9 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
     const int4 *__restrict__ boxes = jobs.j[ji].boxes;
     float *__restrict__ phase = jobs.j[ji].phase;
     uint8_t *__restrict__ valid = jobs.j[ji].valid;
-    const unsigned *__restrict__ xy_t = jobs.j[ji].xy_t;
-    const uint16_t *__restrict__ fr_t = jobs.j[ji].fr_t;
+    const unsigned *__restrict__ pk_t = jobs.j[ji].pk_t;
+    constexpr bool packed = PACKED;                         // the launcher passes pk_t != null with PACKED only
+    static_assert(!PACKED || (TH == kMidTileH && TWV == 1 && ROUNDS == 1), "the pre-digested map serves 64 x 8 tiles");
     // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
     // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
     // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
@@ -794,7 +839,9 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
 
     if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
     int cur = xcd * per + lb;
-    BoxGeom gc = box_geom<NP, ROUNDS>(boxes, cur, budget);
+    const int tiles_x64 = (W + kTileW - 1) / kTileW;
+    constexpr int QH = TH / 4, NPASS = QH * TWV;            // passes per 64-wide half, passes per tile
+    BoxGeom gc = box_geom<NP, ROUNDS, TWV>(boxes, cur, budget, tiles_x, tiles_x64);
     issue(gc, true);
     for (int it = 1;; it++) {
         if (gc.fits) commit(gc);
@@ -802,42 +849,53 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
         const int nl = lb + it * nbx;
         const bool has_next = nl < per && xcd * per + nl < T;
         const int nxt = has_next ? xcd * per + nl : cur;
-        const BoxGeom gn = box_geom<NP, ROUNDS>(boxes, nxt, budget);
+        const BoxGeom gn = box_geom<NP, ROUNDS, TWV>(boxes, nxt, budget, tiles_x, tiles_x64);
 
         const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
-        const int col = tx * kTileW + lane;
-        // map entries of the four passes first (see the header: they must be older than the prefetch)
-        unsigned xy[TH / 4], fr[TH / 4];
+        // map entries of all passes first (see the header: they must be older than the prefetch)
+        unsigned xy[NPASS], fr[NPASS];
 #pragma unroll
-        for (int q = 0; q < TH / 4; q++) {
-            if (TH == kMidTileH && xy_t) {                  // tiled map: contiguous per tile, padded -> no bounds
+        for (int qq = 0; qq < NPASS; qq++) {
+            const int hx = qq / QH, q = qq - hx * QH;
+            const int col = (tx * TWV + hx) * kTileW + lane;
+            if constexpr (packed) {                         // tiled map: contiguous per 64 x 8 tile, padded -> no bounds
                 const unsigned d = (unsigned)cur * 512u + (unsigned)(q * 256) + threadIdx.x;
-                xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(xy_t) + d * 4u);
-                fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(fr_t) + d * 2u);
+                xy[qq] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pk_t) + d * 4u);
+                fr[qq] = 0;
             } else {
                 const int row = ty * TH + 4 * q + wv;
                 const bool inb = row < H && col < W;
                 const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
-                xy[q] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
-                fr[q] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
+                xy[qq] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
+                fr[qq] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + m * 2u);
             }
         }
         issue(gn, has_next);
 #pragma unroll
-        for (int q = 0; q < TH / 4; q++) {
+        for (int qq = 0; qq < NPASS; qq++) {
+            const int hx = qq / QH, q = qq - hx * QH;
+            const int col = (tx * TWV + hx) * kTileW + lane;
             const int row = ty * TH + 4 * q + wv;
             const bool inb = row < H && col < W;
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             int v;
             float ph;
             if (gc.fits) {
-                const TileTaps<NP> k = tile_taps_map<NP>(xy[q], fr[q], inb, W, H, gc.x0, gc.y0, gc.BW4);
+                TileTaps<NP> k;
+                if constexpr (packed) k = tile_taps_packed<NP>(xy[qq], gc.BW4);
+                else k = tile_taps_map<NP>(xy[qq], fr[qq], inb, W, H, gc.x0, gc.y0, gc.BW4);
                 int acc[NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) acc[p] = tile_sample<NP, 6>(tile, k, p);
                 ph = mf_pixel_sh<16>(acc, black_thr, lut, v);
             } else {                                        // wild map: direct gather for this tile
-                Tap t = make_tap((int)(short)(xy[q] & 0xFFFFu), (int)xy[q] >> 16, fr[q], pitch, W, H);
+                unsigned rxy = xy[qq], rfr = fr[qq];
+                if constexpr (packed) {                     // (the pre-digested entries only serve boxes that fit)
+                    const unsigned mm = inb ? m : 0u;
+                    rxy = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + mm * 4u);
+                    rfr = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(map_frac) + mm * 2u);
+                }
+                Tap t = make_tap((int)(short)(rxy & 0xFFFFu), (int)rxy >> 16, rfr, pitch, W, H);
                 if (!inb) t.kind = 1;
                 int gpx[NP];
 #pragma unroll 1
@@ -1107,7 +1165,7 @@ static bool rect_lds_ok(const MfPlanes &pl, int pitch, int W, int H, const float
 static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int W, int H, int black_thr,
                                   const float *atan_lut, int rect_algo, hipStream_t s)
 {
-    const int tiles_x = (W + kTileW - 1) / kTileW;
+    int tiles_x = (W + kTileW - 1) / kTileW;
     if (rect_algo == 3) {                                // sliding-window form
         const int tiles_y8 = (H + kMidTileH - 1) / kMidTileH;
         RectJobs jr;
@@ -1139,16 +1197,17 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
     // than one per tile
     const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
+    const bool wide = rect_algo == 4;                    // 4: 128 x 8 tiles (pairs of 64 x 8 table entries), two rounds
     const int th = mid ? kMidTileH : kTileH;
     const int tiles_yy = (H + th - 1) / th;
-    const int budget = mid ? 12 * 1024 : 24 * 1024;      // 14 planes x ~72 x (th + 7) source bytes
+    if (wide) tiles_x = (W + 2 * kTileW - 1) / (2 * kTileW);
+    const int budget = wide ? 27 * 1024 : mid ? kMidBudget : 24 * 1024;   // 14 planes x ~(tile width + 8) x (th + 7) source bytes
     const size_t box_off = mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0;
     RectJobs j;
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
     for (int jq = 0; jq < 2; jq++) {                      // the tiled map copy lives behind the box tables (launch_tile_boxes)
         const char *basep = reinterpret_cast<const char *>(j.j[jq].boxes);
-        j.j[jq].xy_t = mid && !getenv("SLR_DEBUG_RECT_NO_TILED_MAP") ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
-        j.j[jq].fr_t = j.j[jq].xy_t ? reinterpret_cast<const uint16_t *>(j.j[jq].xy_t + tile_count(W, H, kMidTileH) * 512) : nullptr;
+        j.j[jq].pk_t = mid && !wide && !getenv("SLR_DEBUG_RECT_NO_TILED_MAP") ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
     }
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
     // resident workgroups of this kernel on the CURRENT device (cached per device and kernel variant)
@@ -1163,16 +1222,18 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         strided = strided && ok;
     }
     if (getenv("SLR_DEBUG_RECT_NO_BUFFER")) strided = false;   // tests: force the pointer form
-    static int resident_cache[64][2][2] = {};
+    static int resident_cache[64][3][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &resident_slot = resident_cache[dev & 63][mid][strided];
+    int &resident_slot = resident_cache[dev & 63][wide ? 2 : mid][strided];
     if (!resident_slot) {
         int per_cu = 0, cus = 0;
         const size_t dyn = (size_t)budget + 16;
         const hipError_t e =
-            mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true>, 256, dyn)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false>, 256, dyn))
+            wide ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>, 256, dyn)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>, 256, dyn)) :
+            mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>, 256, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>, 256, dyn))
                 : (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, dyn)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, false>, 256, dyn));
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
@@ -1189,7 +1250,19 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
 #define SLR_RECT_LAUNCH(TH_, R_, S_)                                                                                  \
     hipLaunchKernelGGL((mf_rect_decode_lds_kernel<TH_, R_, S_>), grid, dim3(256), (size_t)budget + 16, s, j, njobs, pitch, W, \
                        H, black_thr, atan_lut, tiles_x, tiles_yy, budget)
-    if (mid) { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
+    if (wide) {
+        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+    }
+    else if (mid && j.j[0].pk_t) {
+        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+    }
+    else if (mid) { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
     else     { if (strided) SLR_RECT_LAUNCH(kTileH, 2, true); else SLR_RECT_LAUNCH(kTileH, 2, false); }
 #undef SLR_RECT_LAUNCH
     return hipGetLastError();
@@ -1206,7 +1279,7 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
     for (int c = 0; c < 2; c++)
         if (!rect_lds_ok(pl[c], pitch, W, H, phase[c], valid[c], map_xy[c], tile_boxes[c], rect_algo)) return hipSuccess;
     RectJob jobs[2];
-    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], 0u, map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c], nullptr, nullptr};
+    for (int c = 0; c < 2; c++) jobs[c] = RectJob{pl[c], 0u, map_xy[c], map_frac[c], (const int4 *)tile_boxes[c], phase[c], valid[c], nullptr};
     *done = true;
     return launch_rect_lds(jobs, 2, pitch, W, H, black_thr, atan_lut, rect_algo, s);
 }
@@ -1216,7 +1289,7 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
     if (rect_lds_ok(pl, pitch, W, H, phase, valid, map_xy, tile_boxes, rect_algo)) {
-        const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, nullptr, nullptr};
+        const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, nullptr};
         return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
     }
     if (map_xy) {

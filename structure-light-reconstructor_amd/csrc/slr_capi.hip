@@ -952,7 +952,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->opt_mf_decode_vec = value;
             return SLR_OK;
         case SLR_OPT_RECT_DECODE_ALGO:
-            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..3");
+            if (value < 0 || value > 4) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..4");
             c->opt_rect_algo = value;
             return SLR_OK;
         case SLR_OPT_PROFILE_STRIDE:
