@@ -69,7 +69,7 @@ def parse_args():
                     help="bytes of row padding of the HBM-resident stacks (pitch = width + pad).  A pitch that is a power of two "
                          "(4096) puts the ~10 source rows of every tile of the rectifying decode on the same HBM channels: the "
                          "fused kernel is 3-6 %% faster with 64..1152 bytes of padding (the unfused one 1-3 %% slower)")
-    ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 default, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8 tiles)")
+    ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
     return ap.parse_args()

@@ -90,11 +90,18 @@ const char  *slr_last_error(const slr_ctx *ctx);
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2
-/* SLR_OPT_RECT_DECODE_ALGO: fused rectify+decode form: 0 = LDS-tiled, 64x8 tiles per persistent workgroup with a
- * register prefetch pipeline (default), 1 = direct gather, 2 = as 0 with 64x16 tiles, 3 = as 0 but walking down tile
- * columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of 1.13x the algorithmic HBM bytes, ~3 %
- * slower), 4 = as 0 with 128x8 tiles and two prefetch rounds (fewer, longer source row segments; no faster in the
- * two-camera launch).  Identical results. */
+/* SLR_OPT_RECT_DECODE_ALGO: form of the fused rectify+decode kernel (identical results).  All LDS-tiled forms run
+ * persistent workgroups with a register prefetch pipeline and fall back, per tile, to a direct gather when the tile's
+ * source box does not fit their LDS budget.
+ *   0 = auto (default): 5, or 6 when the maps would make more pixels fall back in 5 than in 6
+ *   1 = direct gather (no LDS tiles)
+ *   2 = 64x16 tiles, two prefetch rounds
+ *   3 = 64x8 tiles walking down tile columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of
+ *       1.13x the algorithmic HBM bytes, but ~3 % slower)
+ *   4 = 128x8 tiles, 256 threads, two prefetch rounds
+ *   5 = 128x8 tiles, 512 threads (waves 0-3 left half, 4-7 right half), one round, pre-digested 4-byte map entries
+ *   6 = 64x8 tiles, 256 threads, one round, pre-digested 4-byte map entries
+ * The Gray fused decode only distinguishes 1 (gather), 2 (64x4 tiles) and everything else (64x8 tiles when they fit). */
 #define SLR_OPT_RECT_DECODE_ALGO 3
 /* SLR_OPT_ASYNC_HOST: 1 = calls with SLR_MEM_HOST buffers return once the H2D copies, the kernels and the D2H copies
  * are ENQUEUED on the ctx stream; outputs are valid (and inputs reusable) only after slr_synchronize(ctx).  The host

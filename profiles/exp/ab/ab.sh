@@ -6,7 +6,7 @@ for r in 1 2 3; do
   for v in old new; do
     if [ $v = old ]; then cp "$1" $P; else cp "$2" $P; fi
     echo "== $v run $r"
-    python profiles/microbench.py 4096 3000 10 2>&1 | grep -E "vec=4|tiles64x8|binned" 
+    python profiles/microbench.py 4096 3000 10 2>&1 | grep -E "vec=4|mf_rectify_decode auto|binned" 
     python bench.py --steps 20 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['north_star_kernel']['avg_launch_us'])"
   done
 done

@@ -6,7 +6,7 @@ for r in 1 2; do
   for f in "$@"; do
     cp "$f" $P
     echo "== $(basename $f) run $r"
-    python profiles/microbench.py 4096 3000 10 2>&1 | grep -E "tiles64x8"
+    python profiles/microbench.py 4096 3000 10 2>&1 | grep -E "mf_rectify_decode auto"
   done
 done
 cp /tmp/keep.so $P

@@ -49,11 +49,11 @@ for vec in (16, 8, 4):
     ctx.set_option(cap.OPT_MF_DECODE_VEC, vec)
     run("mf_decode vec=%d" % vec, lambda: ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0]), 19.0)
 ctx.set_option(cap.OPT_MF_DECODE_VEC, 0)
-run("mf_rectify_decode tiles64x8", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+run("mf_rectify_decode auto", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
 def _both():
     ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0])
     ctx.mf_decode(st[1], 40, rectify_cam=1, phase=ph[1], valid=vd[1])
-run("mf_rectify_decode tiles64x8 L,R alternating (cold MALL)", _both, 25.0)
+run("mf_rectify_decode auto L,R alternating (cold MALL)", _both, 25.0)
 def _both_plain():
     ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0])
     ctx.mf_decode(st[1], 40, phase=ph[1], valid=vd[1])
@@ -61,6 +61,12 @@ run("mf_decode L,R alternating (cold MALL)", _both_plain, 19.0)
 ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 3)
 run("mf_rectify_decode ring", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
 run("mf_rectify_decode ring L,R alternating", _both, 25.0)
+ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 6)
+run("mf_rectify_decode tiles64x8 256thr", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+run("mf_rectify_decode tiles64x8 256thr L,R alternating", _both, 25.0)
+ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 5)
+run("mf_rectify_decode tiles128x8 512thr", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
+run("mf_rectify_decode tiles128x8 512thr L,R alternating", _both, 25.0)
 ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 4)
 run("mf_rectify_decode tiles128x8", lambda: ctx.mf_decode(st[0], 40, rectify_cam=0, phase=ph[0], valid=vd[0]), 25.0)
 run("mf_rectify_decode tiles128x8 L,R alternating", _both, 25.0)

@@ -16,8 +16,9 @@ MF_PLANES = 14
 MAX_GRAY_BITS = 16
 MEM_HOST, MEM_DEVICE = 0, 1
 OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort)
-OPT_RECT_DECODE_ALGO = 3       # fused rectify+decode: 0 LDS tiles 64x8 (pipelined, default), 1 direct gather, 2 LDS tiles 64x16,
-                               # 3 sliding LDS window down tile columns (minimal HBM traffic), 4 LDS tiles 128x8
+OPT_RECT_DECODE_ALGO = 3       # fused rectify+decode: 0 auto (5, else 6), 1 direct gather, 2 LDS tiles 64x16, 3 sliding LDS
+                               # window down tile columns, 4 tiles 128x8 / 256 threads, 5 tiles 128x8 / 512 threads,
+                               # 6 tiles 64x8 / 256 threads
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()
 OPT_MF_DECODE_VEC = 2          # 0 auto, 4 / 8 / 16 pixels per thread in the unfused K2 kernel

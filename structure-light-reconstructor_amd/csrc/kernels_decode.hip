@@ -552,6 +552,23 @@ static size_t tile_count(int W, int H, int tile_h)
 {
     return (size_t)((W + kTileW - 1) / kTileW) * ((H + tile_h - 1) / tile_h);
 }
+static size_t wide_tile_count(int W, int H)
+{
+    return (size_t)((W + 2 * kTileW - 1) / (2 * kTileW)) * ((H + kMidTileH - 1) / kMidTileH);
+}
+
+// the box of the 128 x 8 tile (ty, tx): union of the 64 x 8 table entries (ty, 2 tx) and (ty, 2 tx + 1)
+__device__ __forceinline__ int4 union_box(const int4 *__restrict__ boxes, int ty, int tx, int tiles_x64)
+{
+    const int t0 = ty * tiles_x64 + 2 * tx;
+    const int4 a = boxes[t0];
+    const int4 b = boxes[2 * tx + 1 < tiles_x64 ? t0 + 1 : t0];
+    const int4 l = a.z > 0 ? a : b, r = b.z > 0 ? b : a;               // an empty half takes the other half's box
+    const int x0 = l.x < r.x ? l.x : r.x, y0 = l.y < r.y ? l.y : r.y;
+    const int x1l = l.x + 4 * l.z, x1r = r.x + 4 * r.z, y1l = l.y + l.w, y1r = r.y + r.w;
+    return make_int4(x0, y0, ((x1l > x1r ? x1l : x1r) - x0) >> 2, (y1l > y1r ? y1l : y1r) - y0);
+}
+
 // The same buffer also carries a TILED, PRE-DIGESTED copy of the map for the 64 x 8 kernel: the 512 entries of a tile are
 // contiguous and ordered (pass, wave, lane) = the order in which the workgroup's threads consume them, so a wave reads
 // 256 contiguous bytes per pass instead of 8 x 256 B pieces 16 KB apart (rows of a 4096-wide map are a power of two
@@ -571,19 +588,26 @@ static size_t tiled_map_offset(int W, int H)
     const size_t b = (tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) + tile_count(W, H, kMidTileH)) * sizeof(int4);
     return (b + 255) & ~(size_t)255;
 }
+// behind the two digests: two counters -- tiles with a footprint whose box does NOT fit the 64 x 8 form / the 128 x 8 form
+// (those tiles run the per-pixel gather fallback; the C ABI picks the form with fewer of them, see launch_tile_boxes)
+static size_t tile_nofit_offset(int W, int H)
+{
+    return tiled_map_offset(W, H) + (tile_count(W, H, kMidTileH) * 512 + wide_tile_count(W, H) * 1024) * sizeof(unsigned);
+}
 size_t tile_boxes_bytes(int W, int H)
 {
-    return tiled_map_offset(W, H) + tile_count(W, H, kMidTileH) * 512 * sizeof(unsigned);
+    return tile_nofit_offset(W, H) + 16;
 }
 
 __global__ __launch_bounds__(256) void tile_maps_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
                                                         int W, int H, int tiles_x, const int4 *__restrict__ boxes8,
-                                                        unsigned *__restrict__ pk_t)
+                                                        unsigned *__restrict__ pk_t, unsigned *__restrict__ nofit)
 {
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int4 box = boxes8[blockIdx.x];
     const bool fits = mid_box_fits(box.z, box.w);
+    if (threadIdx.x == 0 && box.z > 0 && !fits) atomicAdd(nofit, 1u);
 #pragma unroll
     for (int q = 0; q < kMidTileH / 4; q++) {
         const int row = ty * kMidTileH + 4 * q + wv, col = tx * kTileW + lane;
@@ -601,8 +625,41 @@ __global__ __launch_bounds__(256) void tile_maps_kernel(const int16_t *__restric
     }
 }
 
-hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, hipStream_t s)
+// the same digest for the 128 x 8 form: entries relative to the union box, 1024 per tile in (pass, wave, lane) order of
+// a 512-thread workgroup (waves 0-3: left 64 columns, waves 4-7: right 64 columns)
+constexpr int kWideBudget = 28 * 1024;
+__global__ __launch_bounds__(512) void tile_maps_wide_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                             int W, int H, int tiles_x128, int tiles_x64,
+                                                             const int4 *__restrict__ boxes8, unsigned *__restrict__ pk_t,
+                                                             unsigned *__restrict__ nofit)
 {
+    const int ty = blockIdx.x / tiles_x128, tx = blockIdx.x - ty * tiles_x128;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int4 box = union_box(boxes8, ty, tx, tiles_x64);
+    const bool fits = box.z > 0 && box.z * box.w <= 512 && box.z * box.w * (SLR_MF_PLANES * 4) <= kWideBudget;
+    if (threadIdx.x == 0 && box.z > 0 && !fits) atomicAdd(nofit, 1u);
+#pragma unroll
+    for (int q = 0; q < kMidTileH / 4; q++) {
+        const int row = ty * kMidTileH + 4 * q + (wv & 3), col = (2 * tx + (wv >> 2)) * kTileW + lane;
+        unsigned e = 0x80000000u;
+        if (fits && row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+            const unsigned fr = map_frac[m];
+            if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {
+                const int bx = sx - box.x, r0 = sy - box.y;
+                e = (unsigned)(r0 * box.z + (bx >> 2)) | ((unsigned)bx & 3u) << 10 | (fr & 1023u) << 12;
+            }
+        }
+        pk_t[(size_t)blockIdx.x * 1024 + q * 512 + threadIdx.x] = e;
+    }
+}
+hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, unsigned nofit_host[2],
+                             hipStream_t s)
+{
+    unsigned *nofit = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tile_nofit_offset(W, H));
+    hipError_t me = hipMemsetAsync(nofit, 0, 16, s);
+    if (me != hipSuccess) return me;
     const int tiles_x = (W + kTileW - 1) / kTileW;
     hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kTileH, boxes);
@@ -612,8 +669,14 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, in
                        kMidTileH, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH));
     unsigned *pk_t = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tiled_map_offset(W, H));
     hipLaunchKernelGGL(tile_maps_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, map_frac, W, H,
-                       tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH), pk_t);
-    return hipGetLastError();
+                       tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH), pk_t, nofit);
+    hipLaunchKernelGGL(tile_maps_wide_kernel, dim3((unsigned)wide_tile_count(W, H)), dim3(512), 0, s, map_xy, map_frac, W, H,
+                       (W + 2 * kTileW - 1) / (2 * kTileW), tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH),
+                       pk_t + tile_count(W, H, kMidTileH) * 512, nofit + 1);
+    me = hipGetLastError();
+    if (me != hipSuccess) return me;
+    me = hipMemcpyAsync(nofit_host, nofit, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, s);   // the caller synchronises the stream
+    return me;
 }
 // one dword of a plane at (gx..gx+3, gy), zero outside the image; gx is a multiple of 4
 __device__ __forceinline__ unsigned load_src_dword(const uint8_t *__restrict__ plane, int pitch, int W, int H, int gx, int gy)
@@ -707,28 +770,17 @@ struct BoxGeom { int x0, y0, BW4, BH; bool any, fits; };
 
 // TWV == 2: the tile is 128 x TH, the union of two horizontally adjacent 64 x TH tiles of the box table (`tile` counts
 // 128-wide tiles, tiles_x of them per row; the table has tiles_x64 per row)
-template <int NP, int ROUNDS, int TWV>
+template <int NP, int ROUNDS, int TWV, int NT>
 __device__ __forceinline__ BoxGeom box_geom(const int4 *__restrict__ boxes, int tile, int budget, int tiles_x, int tiles_x64)
 {
+    int4 box;
+    if constexpr (TWV == 1) box = boxes[tile];
+    else { const int ty = tile / tiles_x; box = union_box(boxes, ty, tile - ty * tiles_x, tiles_x64); }
     BoxGeom g;
-    if constexpr (TWV == 1) {
-        const int4 box = boxes[tile];
-        g.x0 = box.x; g.y0 = box.y; g.BW4 = box.z; g.BH = box.w;
-    } else {
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const int t0 = ty * tiles_x64 + 2 * tx;
-        const int4 a = boxes[t0];
-        int4 b = boxes[2 * tx + 1 < tiles_x64 ? t0 + 1 : t0];
-        const int4 l = a.z > 0 ? a : b, r = b.z > 0 ? b : a;           // an empty half takes the other half's box
-        const int x0 = l.x < r.x ? l.x : r.x, y0 = l.y < r.y ? l.y : r.y;
-        const int x1l = l.x + 4 * l.z, x1r = r.x + 4 * r.z, y1l = l.y + l.w, y1r = r.y + r.w;
-        g.x0 = x0; g.y0 = y0;
-        g.BW4 = ((x1l > x1r ? x1l : x1r) - x0) >> 2;
-        g.BH = (y1l > y1r ? y1l : y1r) - y0;
-    }
+    g.x0 = box.x; g.y0 = box.y; g.BW4 = box.z; g.BH = box.w;
     g.any = g.BW4 > 0;
-    // the LDS budget, and the prefetch registers: at most ROUNDS x 256 dwords per plane
-    g.fits = g.any && g.BW4 * g.BH <= 256 * ROUNDS && g.BW4 * g.BH * (NP * 4) <= budget;
+    // the LDS budget, and the prefetch registers: at most ROUNDS x NT dwords per plane
+    g.fits = g.any && g.BW4 * g.BH <= NT * ROUNDS && g.BW4 * g.BH * (NP * 4) <= budget;
     return g;
 }
 
@@ -751,8 +803,11 @@ struct RectJobs { RectJob j[2]; };
 // batch entry point).  The box is then fetched with raw buffer loads: one descriptor per job, the plane as the scalar
 // offset -- no per-plane 64-bit address arithmetic -- and everything outside the image is given an out-of-range offset,
 // for which the hardware returns 0 (= BORDER_CONSTANT): no select on the way into LDS either.
-template <int TH, int ROUNDS, bool STRIDED, int TWV = 1, bool PACKED = false>
-__global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
+// NT == 512 (with TWV == 2): eight waves, waves 0-3 decode the left 64 columns of a 128 x 8 tile and waves 4-7 the right
+// ones out of ONE box that all 512 threads fetch in one round -- the source row segments are twice as long (fewer,
+// fuller cache lines per byte, see profiles/exp/boxread.hip) at the register cost of the 64 x 8 form.
+template <int TH, int ROUNDS, bool STRIDED, int TWV = 1, bool PACKED = false, int NT = 256>
+__global__ __launch_bounds__(NT, (NT == 512 ? 6 : ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect_decode_lds_kernel(RectJobs jobs, int njobs, int pitch, int W, int H,
                                                                  int black_thr, const float *__restrict__ lut_g,
                                                                  int tiles_x, int tiles_y, int budget)
 {
@@ -780,7 +835,8 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
     uint8_t *__restrict__ valid = jobs.j[ji].valid;
     const unsigned *__restrict__ pk_t = jobs.j[ji].pk_t;
     constexpr bool packed = PACKED;                         // the launcher passes pk_t != null with PACKED only
-    static_assert(!PACKED || (TH == kMidTileH && TWV == 1 && ROUNDS == 1), "the pre-digested map serves 64 x 8 tiles");
+    static_assert(!PACKED || (TH == kMidTileH && ROUNDS == 1 && NT == 256 * TWV), "the pre-digested maps serve 64 x 8 / 128 x 8 tiles");
+    static_assert(NT == 256 || (NT == 512 && TWV == 2), "eight waves <=> 128-wide tiles");
     // Tile schedule.  Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x owns the band of `per` consecutive
     // tiles (row-major) [x*per, (x+1)*per), and its nbx workgroups walk the band together: in step i they decode the
     // nbx consecutive tiles starting at x*per + i*nbx, so tiles that share source rows meet in one L2.
@@ -796,7 +852,7 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
         const float inv = __builtin_amdgcn_rcpf((float)(g.BW4 > 0 ? g.BW4 : 1));   // v_rcp_f32: 1 ulp, see the margin below
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            const int e = (int)threadIdx.x + 256 * r;
+            const int e = (int)threadIdx.x + NT * r;
             const int rr = (int)(((float)e + 0.5f) * inv);  // e / BW4 (exact: e < 2^20, remainder margin 0.5/BW4)
             const int cc = e - rr * g.BW4;
             const int gx = g.x0 + 4 * cc, gy = g.y0 + rr;
@@ -820,7 +876,7 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
         const float inv = __builtin_amdgcn_rcpf((float)g.BW4);
 #pragma unroll
         for (int r = 0; r < ROUNDS; r++) {
-            const int e = (int)threadIdx.x + 256 * r;
+            const int e = (int)threadIdx.x + NT * r;
             if (e < E) {
                 const int rr = (int)(((float)e + 0.5f) * inv);
                 const int cc = e - rr * g.BW4;
@@ -840,8 +896,9 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
     if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
     int cur = xcd * per + lb;
     const int tiles_x64 = (W + kTileW - 1) / kTileW;
-    constexpr int QH = TH / 4, NPASS = QH * TWV;            // passes per 64-wide half, passes per tile
-    BoxGeom gc = box_geom<NP, ROUNDS, TWV>(boxes, cur, budget, tiles_x, tiles_x64);
+    constexpr int QH = TH / 4, NPASS = NT == 512 ? QH : QH * TWV;   // passes per 64-wide half, passes of a wave per tile
+    const int wrow = NT == 512 ? (wv & 3) : wv;             // the wave's row inside a pass
+    BoxGeom gc = box_geom<NP, ROUNDS, TWV, NT>(boxes, cur, budget, tiles_x, tiles_x64);
     issue(gc, true);
     for (int it = 1;; it++) {
         if (gc.fits) commit(gc);
@@ -849,21 +906,21 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
         const int nl = lb + it * nbx;
         const bool has_next = nl < per && xcd * per + nl < T;
         const int nxt = has_next ? xcd * per + nl : cur;
-        const BoxGeom gn = box_geom<NP, ROUNDS, TWV>(boxes, nxt, budget, tiles_x, tiles_x64);
+        const BoxGeom gn = box_geom<NP, ROUNDS, TWV, NT>(boxes, nxt, budget, tiles_x, tiles_x64);
 
         const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
         // map entries of all passes first (see the header: they must be older than the prefetch)
         unsigned xy[NPASS], fr[NPASS];
 #pragma unroll
         for (int qq = 0; qq < NPASS; qq++) {
-            const int hx = qq / QH, q = qq - hx * QH;
+            const int hx = NT == 512 ? (wv >> 2) : qq / QH, q = NT == 512 ? qq : qq - hx * QH;
             const int col = (tx * TWV + hx) * kTileW + lane;
             if constexpr (packed) {                         // tiled map: contiguous per 64 x 8 tile, padded -> no bounds
-                const unsigned d = (unsigned)cur * 512u + (unsigned)(q * 256) + threadIdx.x;
+                const unsigned d = (unsigned)cur * (unsigned)(2 * NT) + (unsigned)(q * NT) + threadIdx.x;
                 xy[qq] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(pk_t) + d * 4u);
                 fr[qq] = 0;
             } else {
-                const int row = ty * TH + 4 * q + wv;
+                const int row = ty * TH + 4 * q + wrow;
                 const bool inb = row < H && col < W;
                 const unsigned m = inb ? (unsigned)row * (unsigned)W + (unsigned)col : 0u;
                 xy[qq] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(map_xy) + m * 4u);
@@ -873,9 +930,9 @@ __global__ __launch_bounds__(256, (ROUNDS == 1 && STRIDED ? 5 : 4)) void mf_rect
         issue(gn, has_next);
 #pragma unroll
         for (int qq = 0; qq < NPASS; qq++) {
-            const int hx = qq / QH, q = qq - hx * QH;
+            const int hx = NT == 512 ? (wv >> 2) : qq / QH, q = NT == 512 ? qq : qq - hx * QH;
             const int col = (tx * TWV + hx) * kTileW + lane;
-            const int row = ty * TH + 4 * q + wv;
+            const int row = ty * TH + 4 * q + wrow;
             const bool inb = row < H && col < W;
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             int v;
@@ -1197,17 +1254,19 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
     // than one per tile
     const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
-    const bool wide = rect_algo == 4;                    // 4: 128 x 8 tiles (pairs of 64 x 8 table entries), two rounds
+    const bool wide8 = rect_algo == 5;                   // 5: 128 x 8 tiles, 512 threads, one round, pre-digested map
+    const bool wide = rect_algo == 4 || wide8;           // 4: 128 x 8 tiles (pairs of 64 x 8 table entries), two rounds
     const int th = mid ? kMidTileH : kTileH;
     const int tiles_yy = (H + th - 1) / th;
     if (wide) tiles_x = (W + 2 * kTileW - 1) / (2 * kTileW);
-    const int budget = wide ? 27 * 1024 : mid ? kMidBudget : 24 * 1024;   // 14 planes x ~(tile width + 8) x (th + 7) source bytes
+    const int budget = wide8 ? kWideBudget : wide ? 27 * 1024 : mid ? kMidBudget : 24 * 1024;   // 14 planes x ~(tile width + 8) x (th + 7) source bytes
     const size_t box_off = mid ? tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH) : 0;
     RectJobs j;
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
     for (int jq = 0; jq < 2; jq++) {                      // the tiled map copy lives behind the box tables (launch_tile_boxes)
         const char *basep = reinterpret_cast<const char *>(j.j[jq].boxes);
         j.j[jq].pk_t = mid && !wide && !getenv("SLR_DEBUG_RECT_NO_TILED_MAP") ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
+        if (wide8) j.j[jq].pk_t = reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) + tile_count(W, H, kMidTileH) * 512;
     }
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
     // resident workgroups of this kernel on the CURRENT device (cached per device and kernel variant)
@@ -1222,14 +1281,16 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         strided = strided && ok;
     }
     if (getenv("SLR_DEBUG_RECT_NO_BUFFER")) strided = false;   // tests: force the pointer form
-    static int resident_cache[64][3][2] = {};
+    static int resident_cache[64][4][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &resident_slot = resident_cache[dev & 63][wide ? 2 : mid][strided];
+    int &resident_slot = resident_cache[dev & 63][wide8 ? 3 : wide ? 2 : mid][strided];
     if (!resident_slot) {
         int per_cu = 0, cus = 0;
         const size_t dyn = (size_t)budget + 16;
         const hipError_t e =
+            wide8 ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 2, true, 512>, 512, dyn)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>, 512, dyn)) :
             wide ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>, 256, dyn)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>, 256, dyn)) :
             mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>, 256, dyn)
@@ -1250,7 +1311,13 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
 #define SLR_RECT_LAUNCH(TH_, R_, S_)                                                                                  \
     hipLaunchKernelGGL((mf_rect_decode_lds_kernel<TH_, R_, S_>), grid, dim3(256), (size_t)budget + 16, s, j, njobs, pitch, W, \
                        H, black_thr, atan_lut, tiles_x, tiles_yy, budget)
-    if (wide) {
+    if (wide8) {
+        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
+                                        pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
+    }
+    else if (wide) {
         if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
         else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,

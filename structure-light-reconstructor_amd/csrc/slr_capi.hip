@@ -49,6 +49,7 @@ struct slr_ctx {
     int16_t *d_map_xy[2] = {nullptr, nullptr};
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
+    unsigned tile_nofit[2][2] = {};             // per camera: tiles that do not fit the 64x8 / the 128x8 fused-decode form
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
@@ -80,6 +81,16 @@ int fail(slr_ctx *c, int code, const char *what, const char *detail = nullptr)
         if (detail) { c->err += ": "; c->err += detail; }
     }
     return code;
+}
+
+// SLR_OPT_RECT_DECODE_ALGO resolved for the multi-frequency decode of cameras a..b: 0 (auto) takes the 128x8 / 512-thread
+// form (5) unless more of these maps' pixels would fall back to the per-pixel gather there than in the 64x8 form (6)
+int mf_rect_algo(const slr_ctx *c, int a, int b)
+{
+    if (c->opt_rect_algo != 0) return c->opt_rect_algo;
+    unsigned mid = 0, wide = 0;
+    for (int cam = a; cam <= b; cam++) { mid += c->tile_nofit[cam][0]; wide += c->tile_nofit[cam][1]; }
+    return 2u * wide <= mid ? 5 : 6;
 }
 
 #define SLR_HIP(c, expr)                                                                       \
@@ -246,7 +257,7 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
     ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
-                                rectify ? c->d_tile_box[cam] : nullptr, c->opt_mf_decode_vec, c->opt_rect_algo, c->stream));
+                                rectify ? c->d_tile_box[cam] : nullptr, c->opt_mf_decode_vec, mf_rect_algo(c, cam, cam), c->stream));
     return SLR_OK;
 }
 
@@ -512,7 +523,7 @@ int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint1
     const hipMemcpyKind kind = mem == SLR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
     SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
-    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->tile_nofit[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }
@@ -523,7 +534,7 @@ int slr_init_rectify_maps(slr_ctx *c, int cam, const double M[9], const double D
     if (!c || !M || !D || !R || !P) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
     SLR_TRY(map_storage(c, cam, W, H));
     SLR_HIP(c, launch_init_rectify_map(M, D, R, P, W, H, c->d_map_xy[cam], c->d_map_frac[cam], c->stream));
-    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->stream));
+    SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->tile_nofit[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }
@@ -802,7 +813,7 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
         const uint16_t *const mfr[2] = {c->d_map_frac[0], c->d_map_frac[1]};
         const void *const box[2] = {c->d_tile_box[0], c->d_tile_box[1]};
         ProfScope ps(c, K_MF_RECT_DECODE_PAIR);
-        SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, c->opt_rect_algo,
+        SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, mf_rect_algo(c, 0, 1),
                                               &paired, c->stream));
         if (!paired && ps.on) { ps.on = false; c->free_events.push_back(ps.r.a); c->free_events.push_back(ps.r.b); }
     }
@@ -952,7 +963,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->opt_mf_decode_vec = value;
             return SLR_OK;
         case SLR_OPT_RECT_DECODE_ALGO:
-            if (value < 0 || value > 4) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..4");
+            if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..6");
             c->opt_rect_algo = value;
             return SLR_OK;
         case SLR_OPT_PROFILE_STRIDE:

@@ -48,7 +48,7 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
                             const int16_t *map_xy, const uint16_t *map_frac /* null -> no rectify */,
                             const void *tile_boxes /* launch_tile_boxes output for this map, or null */,
                             int vec_hint /* 0 auto, 4/8/16 pixels per thread (tuning) */,
-                            int rect_algo /* fused form: 0 = LDS-tiled, 1 = direct gather */, hipStream_t s);
+                            int rect_algo /* SLR_OPT_RECT_DECODE_ALGO, already resolved (0 is treated as 6) */, hipStream_t s);
 
 // both cameras of a stereo frame in one launch (LDS-tiled fused form only; *done = false -> not applicable, nothing
 // was launched)
@@ -61,9 +61,12 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
 hipError_t launch_init_rectify_map(const double M[9], const double D[5], const double R[9], const double P[12], int W, int H,
                                    int16_t *map_xy, uint16_t *map_frac, hipStream_t s);
 
-// per-tile source bounding boxes of a rectification map (64x16 destination tiles), int4 per tile
+// per-tile source bounding boxes of a rectification map (64x16, 64x4, 64x8 destination tiles; int4 per tile), the
+// pre-digested tiled copies of the map for the 64x8 and 128x8 fused decode, and (nofit_host, valid after the stream is
+// synchronised) the number of tiles whose box does not fit the 64x8 / the 128x8 form
 size_t     tile_boxes_bytes(int W, int H);
-hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, hipStream_t s);
+hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, unsigned nofit_host[2],
+                             hipStream_t s);
 
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,

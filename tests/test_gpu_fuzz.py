@@ -48,7 +48,7 @@ def test_fuzz_decode_and_fused_rectify(ctx, oracle, synth, slr, seed):
     ctx.set_rectify_maps(0, np.ascontiguousarray(mx), np.ascontiguousarray(mf))
     rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
     eph, ev = oracle.mf_decode(rect, BLACK)
-    for algo in (0, 1, 2, 3, 4):
+    for algo in (0, 1, 2, 3, 4, 5, 6):
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
         ph, v = ctx.mf_decode(planes, BLACK, W=W, rectify_cam=0)
         ctx.synchronize()

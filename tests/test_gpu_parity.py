@@ -159,7 +159,7 @@ def test_remap_and_fused_rectify_decode(ctx, oracle, synth, slr, W, H):
         ctx.synchronize()
         assert np.array_equal(np_of(gdev), rect[5])
         exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
-        for algo in (0, 1, 2, 3, 4):                                    # LDS tiles 64x8, gather, LDS tiles 64x16, LDS ring, LDS tiles 128x8
+        for algo in (0, 1, 2, 3, 4, 5, 6):                                    # LDS tiles 64x8, gather, LDS tiles 64x16, LDS ring, LDS tiles 128x8
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
@@ -185,7 +185,7 @@ def test_fused_rectify_decode_wild_maps(ctx, oracle, synth, slr):
         ctx.set_rectify_maps(0, np.ascontiguousarray(mx), mf)
         rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
         exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
-        for algo in (0, 1, 2, 3, 4):
+        for algo in (0, 1, 2, 3, 4, 5, 6):
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
@@ -210,7 +210,7 @@ def test_fused_rectify_decode_pipeline_many_tiles_per_workgroup(ctx, oracle, syn
     exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
     for res in ("8", "16", "40"):
         monkeypatch.setenv("SLR_DEBUG_RECT_RESIDENT", res)
-        for algo in (0, 2, 3, 4):
+        for algo in (0, 2, 3, 4, 5, 6):
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), (res, algo)
