@@ -75,6 +75,16 @@ def parse_args():
     return ap.parse_args()
 
 
+def _device_info(torch, index):
+    """what the step ran on (box-to-box variation in the pool is +-5 %, one box was 25 % slower on every LDS-tiled kernel)"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return {"name": p.name, "compute_units": p.multi_processor_count, "hbm_gib": round(p.total_memory / 2 ** 30, 1),
+                "gcn_arch": getattr(p, "gcnArchName", None), "clock_mhz": round(getattr(p, "clock_rate", 0) / 1000)}
+    except Exception as e:                                   # pragma: no cover
+        return {"error": str(e)}
+
+
 def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
     """The CPU oracle (a port of the reference loops, 1 thread like the reference) on a bounded sample of the same
     workload: full-frame remap + decode for both cameras, triangulation on `rows` image rows (it is O(W^2) per
@@ -418,6 +428,7 @@ def main():
                            (", one RCCL all-gather of the final XYZ+mask inside the timed region" if final_gather else
                             (", one RCCL all-gather of the final XYZ+mask right after the timed steps (final_allgather_ms)"
                              if after_gather else "")))},
+            "device": _device_info(torch, local),
             "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * npix * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
