@@ -2,8 +2,17 @@
 // K3/K3' (Gray-code decode) and the fused rectify+decode variants.  gfx950 (MI355X) only.
 //
 // Streaming kernels over N separate u8 planes: no MFMA, plain integer/f32 ALU, wide coalesced loads.  PMC shows they
-// move exactly the algorithmic HBM bytes and are bound by VALU issue, so the per-pixel branch chains live in small
-// LDS tables (the reference's quotient is an integer) and the bilinear blend uses v_perm / v_dot2.
+// move the algorithmic HBM bytes (1.00-1.13x); the per-pixel branch chains live in small LDS tables (the reference's
+// quotient is an integer) and the bilinear blend uses v_perm / v_dot2, which took K2 to the box's copy
+// ceiling.  The fused rectify+decode forms (SLR_OPT_RECT_DECODE_ALGO, include/slr.h) are bound by how the memory
+// system serves the short source row segments of a tile (profiles/exp/boxread.hip):
+//   mf_rect_decode_lds_kernel<TH, ROUNDS, STRIDED, TWV, PACKED, NT>   persistent workgroups, register prefetch pipeline
+//       <8,1,*,2,true,512>  128x8 tiles, 512 threads, map digest   (5, what "auto" picks when the maps fit it)
+//       <8,1,*,1,true,256>  64x8 tiles, map digest                 (6)
+//       <16,2,*>            64x16 tiles, two prefetch rounds       (2)
+//       <8,2,*,2>           128x8 tiles, 256 threads, two rounds   (4)
+//   mf_rect_decode_ring_kernel                                      16-row sliding LDS window down tile columns (3)
+//   mf_rect_decode_kernel<V>                                        direct gather (1, and the per-tile fallback)
 //
 // Reference behaviour restated (never copied):
 //   K1  stereoRect::doStereoRectify -> cv::remap(CV_16SC2,CV_16UC1,INTER_LINEAR)   Duke/stereorect.cpp:26-34
