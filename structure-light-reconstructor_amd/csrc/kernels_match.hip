@@ -225,8 +225,10 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
                                         /* base: band-local pixel offset of the row; the tables use the absolute row */
                                         const DevCalib &cal, const float2 *__restrict__ undL,
                                         const float *__restrict__ undRx, float *__restrict__ xyz,
-                                        uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+                                        uint8_t *__restrict__ has, int32_t *__restrict__ match_k,
+                                        const float *Tm = nullptr /* T to use instead of cal.T (see the chunked kernel) */)
 {
+    const float *T = Tm ? Tm : cal.T;
     // triangulate: gather the table values for all IPT pixels first (independent loads), then the f64 math
     float ulx[IPT], uly[IPT], urx[IPT];
     if (undL) {
@@ -262,7 +264,7 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
             float X[3] = {0.0f, 0.0f, 0.0f};
             if (best[i] >= 0) {
                 reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
-                if (cal.has_T) apply_T(cal.T, X);
+                if (cal.has_T) apply_T(T, X);
             }
             out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
             hw |= (best[i] >= 0 ? 1u : 0u) << (8 * q);
@@ -428,6 +430,169 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     }
     if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
     k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
+}
+
+// K4 for rows wider than 4096 pixels.  The hash table of a whole 8192-pixel right row needs 128 KB of LDS (one 1024-thread
+// workgroup per CU, 8 pixels and too many registers per thread: 2.3x the time per pixel of a 4096-wide row).  "Smallest
+// column k with |phiL - phiR[k]| < 0.1" decomposes over CHUNKS of the right row: the answer lies in the first chunk
+// (ascending columns) that holds any candidate.  So the workgroup keeps the 4096-pixel geometry (64 KB table, two
+// workgroups per CU, 4 pixels per thread): for every right chunk, in ascending order, it builds the binned index exactly
+// as mf_match_binned_kernel does, and every left chunk queries it for the pixels that have no match yet.  Between right
+// chunks a thread parks the state of its 4 pixels of a left chunk (u16 each: the match column, 0xFFFF = still open,
+// 0xFFFE = can never match) in the first 8 bytes of its own 48-byte span of the XYZ output row, which it overwrites with
+// the result after the last right chunk -- nothing but best[] would otherwise have to live across the index builds, and
+// the kernel sits at the 64-VGPR limit of two 1024-thread workgroups per CU.  W <= 32768 (columns fit 15 bits).
+__global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                                   const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                                   int W, int H, int row0, DevCalib cal, int vec_ok,
+                                                                   const float2 *__restrict__ undL, const float *__restrict__ undRx,
+                                                                   float *__restrict__ xyz,
+                                                                   uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT;
+    constexpr int TS = 2 * N;
+    constexpr int kPer = kBins / BLOCK;
+    constexpr unsigned kEmpty = 0xFFFFFFFFu;
+    constexpr unsigned kOpen = 0xFFFFu, kNever = 0xFFFEu;
+    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
+    __shared__ union {
+        struct { unsigned key[TS]; unsigned mink[TS]; } t;
+        struct { float2 pk[N]; unsigned binstart[kBins + 1]; } b;
+    } sh;
+    __shared__ typename ScanU::TempStorage scan_tmp;
+
+    const int row = blockIdx.x + row0, tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * W;
+    const bool vec = (vec_ok & 1) != 0;
+    const int nch = (W + N - 1) / N;
+
+#pragma unroll 1
+    for (int rc = 0; rc < nch; rc++) {
+        const int k0 = rc * N + tid * IPT;               // right columns of this thread in this chunk
+        {
+            float pr[IPT];
+            unsigned vr[IPT];
+            load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
+            load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+#pragma unroll
+            for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
+            __syncthreads();
+            // A. distinct values of the chunk and their smallest column
+            unsigned slot[IPT];
+            bool prev_ok = false;
+            unsigned prev_bits = 0;
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                const bool ok = (k0 + i < W) && vr[i] && (pr[i] == pr[i]);
+                const unsigned bits = __float_as_uint(pr[i]);
+                const bool dup = prev_ok && ok && bits == prev_bits;
+                slot[i] = kEmpty;
+                if (ok && !dup) {
+                    unsigned h = (bits * 2654435761u) >> (32 - __builtin_ctz(TS));
+                    for (;;) {
+                        const unsigned old = atomicCAS(&sh.t.key[h], kEmpty, bits);
+                        if (old == kEmpty || old == bits) break;
+                        h = (h + 1) & (TS - 1);
+                    }
+                    atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
+                    slot[i] = h;
+                }
+                prev_ok = ok; prev_bits = bits;
+            }
+            __syncthreads();
+            unsigned repmask = 0;
+#pragma unroll
+            for (int i = 0; i < IPT; i++)
+                if (slot[i] != kEmpty && sh.t.mink[slot[i]] == (unsigned)(k0 + i)) repmask |= 1u << i;
+            __syncthreads();
+            // B. counting sort of the representatives by phase bin
+#pragma unroll
+            for (int q = 0; q < kPer; q++) sh.b.binstart[tid + q * BLOCK] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                if (repmask & (1u << i)) {
+                    const unsigned b = (unsigned)phase_bin(pr[i]);
+                    slot[i] = (b << 16) | atomicAdd(&sh.b.binstart[b], 1u);
+                }
+            }
+            __syncthreads();
+            {
+                unsigned c[kPer], sum = 0;
+#pragma unroll
+                for (int q = 0; q < kPer; q++) { c[q] = sh.b.binstart[tid * kPer + q]; sum += c[q]; }
+                unsigned excl, total;
+                ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+#pragma unroll
+                for (int q = 0; q < kPer; q++) { sh.b.binstart[tid * kPer + q] = excl; excl += c[q]; }
+                if (tid == 0) sh.b.binstart[kBins] = total;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < IPT; i++)
+                if (repmask & (1u << i))
+                    sh.b.pk[sh.b.binstart[slot[i] >> 16] + (slot[i] & 0xFFFFu)] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+            __syncthreads();
+        }
+        // every left chunk queries this index for its still open pixels
+#pragma unroll 1
+        for (int lc = 0; lc < nch; lc++) {
+            const int j0 = lc * N + tid * IPT;
+            if (j0 >= W) continue;                       // (per thread; no barrier inside this loop)
+            unsigned *park = reinterpret_cast<unsigned *>(xyz + 3 * (base + j0));   // 2 dwords of this thread's own span
+            float pl[IPT];
+            load_f32_blocked<IPT>(phaseL + base, j0, W, vec, pl);
+            unsigned st[IPT];
+            if (rc == 0) {
+                unsigned vl[IPT];
+                load_u8_blocked<IPT>(validL + base, j0, W, vec, vl);
+#pragma unroll
+                for (int i = 0; i < IPT; i++) st[i] = (j0 + i < W && vl[i] && pl[i] == pl[i]) ? kOpen : kNever;
+            } else {
+                const unsigned a = park[0], b = park[1];
+                st[0] = a & 0xFFFFu; st[1] = a >> 16; st[2] = b & 0xFFFFu; st[3] = b >> 16;
+            }
+            int qi0[IPT], qi1[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                const bool act = st[i] == kOpen;
+                const int b = act ? phase_bin(pl[i]) : 0;
+                qi0[i] = (int)sh.b.binstart[b > 0 ? b - 1 : 0];
+                qi1[i] = act ? (int)sh.b.binstart[b + 2 < kBins ? b + 2 : kBins] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                unsigned bk = 0xFFFFFFFFu;
+                for (int idx = qi0[i]; idx < qi1[i]; idx += 4) {
+                    float2 c[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) c[q] = sh.b.pk[idx + q < N ? idx + q : N - 1];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                        const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
+                        bk = kk < bk ? kk : bk;
+                    }
+                }
+                if (bk != 0xFFFFFFFFu) st[i] = bk;
+            }
+            if (rc + 1 < nch) {
+                park[0] = st[0] | st[1] << 16;
+                park[1] = st[2] | st[3] << 16;
+            } else {
+                int best[IPT];
+#pragma unroll
+                for (int i = 0; i < IPT; i++) best[i] = st[i] < kNever ? (int)st[i] : -1;
+                // (an empty asm makes T opaque per chunk: without it the compiler hoists the twelve f32->f64 conversions
+                // of apply_T out of the loops and then spills them)
+                float Tl[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) { Tl[i] = cal.T[i]; asm volatile("" : "+s"(Tl[i])); }
+                k4_emit<IPT>(best, base, j0, row, W, vec, cal, undL, undRx, xyz, has, match_k, Tl);
+            }
+        }
+        __syncthreads();                                 // the index is rebuilt for the next right chunk
+    }
 }
 
 template <int BLOCK, int IPT>
@@ -629,8 +794,19 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         else if (W <= 1024) SLR_SORTED(256, 4);
         else if (W <= 2048) SLR_SORTED(1024, 2);
         else if (W <= 4096) SLR_SORTED(1024, 4);
-        else SLR_SORTED(1024, 8);
+        else if (algo == 2) SLR_SORTED(1024, 8);
+        else                                                 // wider rows: the right row in chunks of 4096 columns
+            hipLaunchKernelGGL(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
+                               cal, vec_ok, undL, undRx, xyz, has, match_k);
 #undef SLR_SORTED
+        return hipGetLastError();
+    }
+    if (algo != 1 && W <= 4096 * 8) {                       // up to 32768 columns: up to 8 chunks
+        const int vec_ok = (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
+                           ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
+                           ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
+        hipLaunchKernelGGL(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
+                           cal, vec_ok, undL, undRx, xyz, has, match_k);
         return hipGetLastError();
     }
     const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);

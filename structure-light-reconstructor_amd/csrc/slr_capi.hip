@@ -269,7 +269,7 @@ int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *
     if (rows < 0) rows = H;
     const size_t n = (size_t)W * H;
     const float *undL = nullptr, *undR = nullptr;
-    if (c->opt_mf_match_algo != 1 && W <= 256 * 32) {
+    if (c->opt_mf_match_algo != 1 && W <= 4096 * 8) {     // the indexed forms (launch_mf_match) read the tables
         void *a, *b;
         if (c->scratch_cap[S_UND_L] < n * 8 || c->scratch_cap[S_UND_R] < n * 4) c->und_valid = false;   // will realloc
         SLR_TRY(get_scratch(c, S_UND_L, n * 8, &a));

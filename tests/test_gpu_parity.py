@@ -367,7 +367,7 @@ def test_mf_triangulate_threshold_edges(ctx, oracle, synth):
     assert emk[1, 0] == 9 and emk[1, 4] == -1
 
 
-@pytest.mark.parametrize("W", [16, 255, 256, 300, 700, 1500, 2100, 4096, 5000])
+@pytest.mark.parametrize("W", [16, 255, 256, 300, 700, 1500, 2100, 4096, 5000, 8192, 9001, 16390])
 def test_mf_match_sweep_and_indexed_forms_agree(ctx, oracle, synth, slr, W):
     """the O(log W) indexed K4 must return exactly what the literal linear sweep returns (and the oracle):
     adversarial rows -- few distinct values, dense clusters inside one 0.2 window, +-0, NaN, huge magnitudes"""
