@@ -80,7 +80,7 @@ def test_fuzz_gray_decode_and_fused_rectify(ctx, oracle, synth, slr, seed):
     ctx.set_rectify_maps(1, mxt.numpy(), mft.numpy())
     rect = np.stack([oracle.remap_u8(raw[p], mxt.numpy(), mft.numpy()) for p in range(n)])
     ex, ey, ev = oracle.gray_decode(rect, ncol, nrow, BLACK, wt, scan_w, scan_h)
-    for algo in (0, 1, 2):
+    for algo in (0, 1, 2, 5, 6):
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
         cx, cy, v = ctx.gray_decode(planes, ncol, nrow, BLACK, wt, scan_w, scan_h, W=W, rectify_cam=1)
         ctx.synchronize()

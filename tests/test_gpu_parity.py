@@ -299,7 +299,7 @@ def test_gray_rectify_decode(ctx, oracle, synth, slr):
         raw = st[cam].numpy()
         rect = np.stack([oracle.remap_u8(raw[p], mx.numpy(), mf.numpy()) for p in range(raw.shape[0])])
         ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 4, scan_w, 0)
-        for algo in (0, 1, 2):                                       # LDS tiles 64x8, direct gather, LDS tiles 64x4
+        for algo in (0, 1, 2, 5, 6):                                 # auto, direct gather, LDS tiles 64x4, 128x8, 64x8
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             cx, _, v = ctx.gray_decode(raw, ncol, 0, BLACK, 4, scan_w, 0, rectify_cam=cam)
             assert bits_equal(cx, ex) and bits_equal(v, ev), algo
