@@ -36,9 +36,10 @@ BLACK_THR = 40                 # Duke/Set.ui:429-431 default
 # algorithmic bytes per camera-pixel (or stereo-pixel for the match kernel) -- SURVEY.md 8(d), DESIGN.md
 ALG_BYTES = {
     "slr_mf_rectify_decode": 25.0,     # 14 src + 6 map + 4 phase + 1 valid
-    "slr_mf_rectify_decode_pair": 50.0,  # the same kernel serving both cameras of the frame in one launch (per st-px)
+    # inside slr_reconstruct_mf* the valid flag travels in the phase (NaN): no separate valid bytes on either side
+    "slr_mf_rectify_decode_pair": 48.0,  # both cameras of the frame in one launch, per st-px: 2 x (14 src + 6 map + 4 phase)
     "slr_mf_decode": 19.0,             # 12 fringe + 2 white/black + 4 phase + 1 valid
-    "slr_mf_match_triangulate": 23.0,  # 2x(4+1) read + 12 + 1 write
+    "slr_mf_match_triangulate": 21.0,  # 2 x 4 phase read + 12 xyz + 1 mask write (23 with separate valid bytes)
     "slr_remap_u8": 8.0,
 }
 

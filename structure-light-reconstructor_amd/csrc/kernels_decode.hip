@@ -51,6 +51,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 //                   three signs of d do not overlap.  Every P is 0 or at least 0.5 in magnitude and below 8, i.e. a
 //                   multiple of 2^-24 below 2^27: the integer holds it exactly.
 constexpr int kLutR = 0, kLutP = 512, kLutWords = kDecodeLutWords;
+// valid == null in a decode launch: the flag is folded into the phase -- invalid pixels get this NaN, which K4 never matches
+#define kInvalidPhase __uint_as_float(0x7FC00000u)
 constexpr int kQ24TwoPI = (int)(kTwoPI * 16777216.0f);      // 2*PI as the reference's float, times 2^24: an integer
 
 __device__ __forceinline__ int wrapped_phase_q24(int G1, int G2, int G3, int G4, const float *lut, int &nz)
@@ -253,17 +255,20 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
                 for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (word_of(w[p], k) >> (8 * b)) & 0xFFu;
                 int v;
                 ph[b] = mf_pixel(gpx, black_thr, lut, v);
+                if (!valid) ph[b] = v ? ph[b] : kInvalidPhase;
                 vw |= (unsigned)v << (8 * b);
             }
             f32x4 o; o.x = ph[0]; o.y = ph[1]; o.z = ph[2]; o.w = ph[3];
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(phase + oo + 4 * k));
             vout[k] = vw;
         }
-        vec_t vv;
-        if constexpr (NW == 1) vv = vout[0];
-        else if constexpr (NW == 2) { vv.x = vout[0]; vv.y = vout[1]; }
-        else { vv.x = vout[0]; vv.y = vout[1]; vv.z = vout[2]; vv.w = vout[3]; }
-        __builtin_nontemporal_store(vv, reinterpret_cast<vec_t *>(valid + oo));
+        if (valid) {
+            vec_t vv;
+            if constexpr (NW == 1) vv = vout[0];
+            else if constexpr (NW == 2) { vv.x = vout[0]; vv.y = vout[1]; }
+            else { vv.x = vout[0]; vv.y = vout[1]; vv.z = vout[2]; vv.w = vout[3]; }
+            __builtin_nontemporal_store(vv, reinterpret_cast<vec_t *>(valid + oo));
+        }
     };
     if (gridDim.y > 1) {                                    // padded rows: image rows blockIdx.y + k gridDim.y, no division
         const unsigned c = blockIdx.x * 256u + threadIdx.x;
@@ -292,8 +297,9 @@ __global__ __launch_bounds__(256) void mf_decode_scalar_kernel(MfPlanes pl, int 
 #pragma unroll
         for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = pl.p[p][so];
         int v;
-        phase[g] = mf_pixel(gpx, black_thr, lut, v);
-        valid[g] = (uint8_t)v;
+        const float ph = mf_pixel(gpx, black_thr, lut, v);
+        phase[g] = valid || v ? ph : kInvalidPhase;
+        if (valid) valid[g] = (uint8_t)v;
     }
 }
 
@@ -407,15 +413,16 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
             for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (packed[p] >> (8 * i)) & 0xFFu;
             int v;
             ph[i] = mf_pixel(gpx, black_thr, lut, v);
+            if (!valid) ph[i] = v ? ph[i] : kInvalidPhase;
             vw |= (unsigned)v << (8 * i);
         }
         if constexpr (V == 4) {
             f32x4 o; o.x = ph[0]; o.y = ph[1]; o.z = ph[2]; o.w = ph[3];
             __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(phase + m));
-            __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            if (valid) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
         } else {
             phase[m] = ph[0];
-            valid[m] = (uint8_t)vw;
+            if (valid) valid[m] = (uint8_t)vw;
         }
     }
 }
@@ -971,13 +978,15 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 6 : ROUNDS == 1 && STRIDED ? 5 : 4
             // valid bytes of 4 neighbouring lanes -> one dword store by every 4th lane: the wave's ballot, this lane's
             // nibble of it, and a multiply that spreads 4 bits into 4 bytes (bit i -> bit 8i; the partial products of
             // 1 + 2^7 + 2^14 + 2^21 do not overlap)
-            const unsigned long long bal = __ballot(v != 0);
-            const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
-            const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
-            if (inb) {
-                __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
-                if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            if (valid) {
+                const unsigned long long bal = __ballot(v != 0);
+                const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+                const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+                if (inb && (lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            } else {
+                ph = v ? ph : kInvalidPhase;                // folded flag (see launch_mf_decode)
             }
+            if (inb) __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
         }
         if (!has_next) break;
         __syncthreads();                                    // everybody is done reading this tile's LDS
@@ -1178,13 +1187,15 @@ __global__ __launch_bounds__(256, 5) void mf_rect_decode_ring_kernel(RectJobs jo
                 for (int p = 0; p < NP; p++) gpx[p] = cur.any ? sample(plane(p), pitch, W, H, t) : 0;
                 ph = mf_pixel(gpx, black_thr, lut, v);
             }
-            const unsigned long long bal = __ballot(v != 0);
-            const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
-            const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
-            if (inb) {
-                __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
-                if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            if (valid) {
+                const unsigned long long bal = __ballot(v != 0);
+                const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+                const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+                if (inb && (lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            } else {
+                ph = v ? ph : kInvalidPhase;                // folded flag (see launch_mf_decode)
             }
+            if (inb) __builtin_nontemporal_store(ph, reinterpret_cast<float *>(reinterpret_cast<char *>(phase) + m * 4u));
         }
         if (!nxt.valid) break;
         __syncthreads();

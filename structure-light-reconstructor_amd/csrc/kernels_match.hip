@@ -117,13 +117,13 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
     const size_t base = (size_t)blockIdx.x * W;
     const int Wp = (W + 3) & ~3;
     for (int k = threadIdx.x; k < Wp; k += 256)
-        phR[k] = (k < W && validR[base + k]) ? phaseR[base + k] : __builtin_nanf("");
+        phR[k] = (k < W && (!validR || validR[base + k])) ? phaseR[base + k] : __builtin_nanf("");
     __syncthreads();
 
     for (int j0 = 0; j0 < W; j0 += 256) {
         const int j = j0 + threadIdx.x;
         const bool inb = j < W;
-        const bool act = inb && validL[base + j];
+        const bool act = inb && (!validL || validL[base + j]);   // (null: invalid pixels carry a NaN phase and never match)
         const float pl = act ? phaseL[base + j] : 0.0f;
         int best = -1;
         bool searching = act;
@@ -215,6 +215,18 @@ __device__ __forceinline__ void load_u8_blocked(const uint8_t *__restrict__ p, i
     } else {
 #pragma unroll
         for (int i = 0; i < IPT; i++) out[i] = (k0 + i < W) ? p[k0 + i] : 0u;
+    }
+}
+// valid bytes of a row, or "all valid" when the caller folded the flags into the phases as NaNs (valid == null: the
+// internal phase format of slr_reconstruct_mf*, see launch_mf_decode)
+template <int IPT>
+__device__ __forceinline__ void load_valid_blocked(const uint8_t *__restrict__ valid, size_t base, int k0, int W, bool vec,
+                                                   unsigned out[IPT])
+{
+    if (valid) load_u8_blocked<IPT>(valid + base, k0, W, vec, out);
+    else {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) out[i] = 1u;
     }
 }
 
@@ -334,9 +346,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     float pr[IPT], pl[IPT];
     unsigned vr[IPT], vl[IPT];
     load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
-    load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+    load_valid_blocked<IPT>(validR, base, k0, W, vec, vr);
     load_f32_blocked<IPT>(phaseL + base, k0, W, vec, pl);
-    load_u8_blocked<IPT>(validL + base, k0, W, vec, vl);
+    load_valid_blocked<IPT>(validL, base, k0, W, vec, vl);
 #pragma unroll
     for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
     __syncthreads();
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
             float pr[IPT];
             unsigned vr[IPT];
             load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
-            load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+            load_valid_blocked<IPT>(validR, base, k0, W, vec, vr);
 #pragma unroll
             for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
             __syncthreads();
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
             unsigned st[IPT];
             if (rc == 0) {
                 unsigned vl[IPT];
-                load_u8_blocked<IPT>(validL + base, j0, W, vec, vl);
+                load_valid_blocked<IPT>(validL, base, j0, W, vec, vl);
 #pragma unroll
                 for (int i = 0; i < IPT; i++) st[i] = (j0 + i < W && vl[i] && pl[i] == pl[i]) ? kOpen : kNever;
             } else {
@@ -629,9 +641,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     float pr[IPT], pl[IPT];
     unsigned vr[IPT], vl[IPT];
     load_f32_blocked<IPT>(phaseR + base, k0, W, vec, pr);
-    load_u8_blocked<IPT>(validR + base, k0, W, vec, vr);
+    load_valid_blocked<IPT>(validR, base, k0, W, vec, vr);
     load_f32_blocked<IPT>(phaseL + base, k0, W, vec, pl);
-    load_u8_blocked<IPT>(validL + base, k0, W, vec, vl);
+    load_valid_blocked<IPT>(validL, base, k0, W, vec, vl);
 
     // Sort key: any function of phi works for correctness (equal phases share a key, and the stable order keeps
     // ascending k inside a key).  16 bits = 12-bit bin + 4-bit hash of the value: two 8-bit radix passes instead

@@ -800,9 +800,12 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
                               int black_thr, int rectify, float *xyz, uint8_t *has)
 {
     const size_t n = (size_t)W * H;
-    void *phL, *vL, *phR, *vR;
-    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL)); SLR_TRY(get_scratch(c, S_VALID_L, n, &vL));
-    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vR));
+    // the phase images between the decode and K4 are internal: the valid flag travels INSIDE the phase (invalid pixels
+    // carry a NaN, which K4 never matches -- the decode kernels do that when their valid pointer is null), so neither
+    // side touches separate valid bytes (the decode's 64-byte partial-line stores, 2 B per stereo pixel each way)
+    void *phL, *phR, *vL = nullptr, *vR = nullptr;
+    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL));
+    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR));
     bool paired = false;
     if (rectify) {                                       // both cameras in one launch when the LDS-tiled form applies
         MfPlanes mp[2];
