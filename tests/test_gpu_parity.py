@@ -562,6 +562,40 @@ def test_reconstruct_mf_whole_path(ctx, oracle, synth):
     assert not bits_equal(np_of(bx[1]), exyz)
 
 
+def test_reconstruct_mf_under_every_decode_and_match_form(ctx, oracle, synth, slr):
+    """inside slr_reconstruct_mf* the valid flag travels in the phase (NaN for invalid pixels, no separate valid bytes):
+    every fused-decode form and every K4 form must give the oracle's cloud, also on pixels whose phase is undefined (Q5:
+    flat fringes), shadowed (mask) or outside the rectified image"""
+    W, H = 384, 96
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    st = synth.render_mf_stack(W, H, seed=91, noise=2).numpy().copy()
+    st[0, 2:, 10:30, 40:90] = 77                      # flat fringes under full light: n = d = 0 for all frequencies (Q5)
+    st[1, 2:, 50:60, 200:260] = 120
+    st[0, 0, 60:80, 300:340] = st[0, 1, 60:80, 300:340]   # white == black: shadow mask
+    maps = [synth.make_rectify_maps(W, H, cam, strength=3.0) for cam in range(2)]
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    for rectify in (True, False):
+        dec = []
+        for cam in range(2):
+            pl = st[cam]
+            if rectify:
+                pl = np.stack([oracle.remap_u8(pl[p], maps[cam][0].numpy(), maps[cam][1].numpy()) for p in range(14)])
+            dec.append(oracle.mf_decode(pl, BLACK))
+        assert (dec[0][1] == 0).sum() > 500 and (dec[0][1] == 1).sum() > 500
+        exyz, ehas, _ = oracle.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q, T)
+        for ralgo in ((0, 1, 2, 3, 4, 5, 6) if rectify else (0,)):
+            for malgo in (0, 1, 2, 3):
+                ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, ralgo)
+                ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, malgo)
+                xyz, has = ctx.reconstruct_mf(st[0], st[1], BLACK, rectify)
+                assert bits_equal(has, ehas) and bits_equal(xyz, exyz), (rectify, ralgo, malgo)
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+    ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
+
+
 def test_reconstruct_ge_and_gray_whole_path(ctx, oracle, synth):
     W, H, scan_w, scan_h = 256, 160, 256, 160
     calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
