@@ -1507,11 +1507,11 @@ __global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_c
             __builtin_nontemporal_store(o, reinterpret_cast<i32x4 *>(code_x + m));
             if (code_y) { i32x4 q; q.x = cy[0]; q.y = cy[1]; q.z = cy[2]; q.w = cy[3];
                           __builtin_nontemporal_store(q, reinterpret_cast<i32x4 *>(code_y + m)); }
-            __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+            if (valid) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));   // (null: code -1 says it all)
         } else {
             code_x[m] = cx[0];
             if (code_y) code_y[m] = cy[0];
-            valid[m] = (uint8_t)vw;
+            if (valid) valid[m] = (uint8_t)vw;
         }
     }
 }
@@ -1658,13 +1658,15 @@ __global__ __launch_bounds__(256) void gray_rect_decode_lds_kernel(GrayPlanes pl
         if (n_row_bits > 0) err |= (y > scan_h || x > scan_w) ? 1 : 0;   // reconstruct.cpp:364 (Q9 '>')
         else err |= (x > scan_w) ? 1 : 0;                                // reconstruct.cpp:403
         const int ok = mask & (err ^ 1);
-        const unsigned long long bal = __ballot(ok != 0);    // valid bytes of 4 lanes -> one dword (see the MF kernel)
-        const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
-        const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+        if (valid) {                                        // (null: the consumer reads validity off code_x == -1)
+            const unsigned long long bal = __ballot(ok != 0);    // valid bytes of 4 lanes -> one dword (see the MF kernel)
+            const unsigned half = (lane & 32) ? (unsigned)(bal >> 32) : (unsigned)bal;
+            const unsigned vw = __umul24((half >> lane31) & 0xFu, 0x204081u) & 0x01010101u;
+            if (inb && (lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
+        }
         if (inb) {
             __builtin_nontemporal_store(ok ? x : -1, code_x + m);
             if (code_y) __builtin_nontemporal_store((ok && n_row_bits > 0) ? y : -1, code_y + m);
-            if ((lane & 3) == 0) __builtin_nontemporal_store(vw, reinterpret_cast<unsigned *>(valid + m));
         }
     }
 }

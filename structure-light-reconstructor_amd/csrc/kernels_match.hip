@@ -864,7 +864,9 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         const int k = threadIdx.x * IPT + i;
-        keys[i] = (k < W && validR[base + k]) ? (((unsigned)codeR[base + k] << 16) | (unsigned)k) : 0xFFFFFFFFu;
+        // (validR == null: the Gray decode was launched without a valid plane, code -1 marks the invalid pixels)
+        const int cr = k < W ? codeR[base + k] : -1;
+        keys[i] = (k < W && (validR ? validR[base + k] != 0 : cr >= 0)) ? (((unsigned)cr << 16) | (unsigned)k) : 0xFFFFFFFFu;
     }
     for (int t = threadIdx.x; t < TC; t += 256) first[t] = 0xFFFFu;
     Sort(sh.sort).Sort(keys, 16, 32);
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         const int j = j0 + i;
-        cl[i] = (j < W && validL[base + j]) ? codeL[base + j] : -1;
+        cl[i] = (j < W && (!validL || validL[base + j])) ? codeL[base + j] : -1;   // (null validL: invalid pixels hold -1)
     }
     int ks_in = 0, lm = -1, fm = 0x7FFFFFFF;       // incoming kstart, last and first match of this thread
     bool dirty = true;

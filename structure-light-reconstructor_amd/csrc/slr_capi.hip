@@ -885,13 +885,14 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
     Stage st(c, mem);
     const size_t n = (size_t)W * H;
     const uint8_t *dl[SLR_MAX_GRAY_PLANES], *dr[SLR_MAX_GRAY_PLANES];
-    void *dx, *dh, *dc, *cxl, *vl, *cxr, *vr;
+    // the code images between the decode and K5 are internal: an invalid pixel holds code -1, no separate valid bytes
+    void *dx, *dh, *dc, *cxl, *vl = nullptr, *cxr, *vr = nullptr;
     SLR_TRY(st.planes(planesL, np, pitch, H, dl));
     SLR_TRY(st.planes(planesR, np, pitch, H, dr));
     SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh));
     SLR_TRY(st.out(have_color ? color : nullptr, n, &dc));
-    SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl)); SLR_TRY(get_scratch(c, S_VALID_L, n, &vl));
-    SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr)); SLR_TRY(get_scratch(c, S_VALID_R, n, &vr));
+    SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl));
+    SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr));
     SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
                              (int32_t *)cxl, nullptr, (uint8_t *)vl));
     SLR_TRY(core_gray_decode(c, 1, rectify != 0, dr, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
