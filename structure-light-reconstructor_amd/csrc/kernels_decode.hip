@@ -201,8 +201,8 @@ hipError_t launch_remap_u8(const uint8_t *src, int src_pitch, uint8_t *dst, int 
     const bool vec = (W % 4 == 0) && (dst_pitch % 4 == 0) && ((uintptr_t)dst % 4 == 0);
     const size_t groups = vec ? (size_t)(W / 4) * H : (size_t)W * H;
     const unsigned blocks = (unsigned)((groups + 255) / 256 < 8192 ? (groups + 255) / 256 : 8192);
-    if (vec) hipLaunchKernelGGL(remap_kernel<4>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
-    else     hipLaunchKernelGGL(remap_kernel<1>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
+    if (vec) SLR_LAUNCH(remap_kernel<4>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
+    else     SLR_LAUNCH(remap_kernel<1>, dim3(blocks), dim3(256), 0, s, src, src_pitch, dst, dst_pitch, W, H, map_xy, map_frac);
     return hipGetLastError();
 }
 
@@ -490,7 +490,7 @@ hipError_t launch_init_rectify_map(const double M[9], const double D[5], const d
     g.ir[8] = (A[0] * A[4] - A[1] * A[3]) * d;
     g.fx = M[0]; g.fy = M[4]; g.u0 = M[2]; g.v0 = M[5];
     g.k1 = D[0]; g.k2 = D[1]; g.p1 = D[2]; g.p2 = D[3]; g.k3 = D[4];
-    hipLaunchKernelGGL(init_rectify_map_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, s, g, W, H, map_xy, map_frac);
+    SLR_LAUNCH(init_rectify_map_kernel, dim3((unsigned)((H + 63) / 64)), dim3(64), 0, s, g, W, H, map_xy, map_frac);
     return hipGetLastError();
 }
 
@@ -677,16 +677,16 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, in
     hipError_t me = hipMemsetAsync(nofit, 0, 16, s);
     if (me != hipSuccess) return me;
     const int tiles_x = (W + kTileW - 1) / kTileW;
-    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+    SLR_LAUNCH(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kTileH, boxes);
-    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kGrayTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+    SLR_LAUNCH(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kGrayTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kGrayTileH, boxes + tile_count(W, H, kTileH));
-    hipLaunchKernelGGL(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
+    SLR_LAUNCH(tile_boxes_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, W, H, tiles_x,
                        kMidTileH, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH));
     unsigned *pk_t = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(boxes) + tiled_map_offset(W, H));
-    hipLaunchKernelGGL(tile_maps_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, map_frac, W, H,
+    SLR_LAUNCH(tile_maps_kernel, dim3((unsigned)tile_count(W, H, kMidTileH)), dim3(256), 0, s, map_xy, map_frac, W, H,
                        tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH), pk_t, nofit);
-    hipLaunchKernelGGL(tile_maps_wide_kernel, dim3((unsigned)wide_tile_count(W, H)), dim3(512), 0, s, map_xy, map_frac, W, H,
+    SLR_LAUNCH(tile_maps_wide_kernel, dim3((unsigned)wide_tile_count(W, H)), dim3(512), 0, s, map_xy, map_frac, W, H,
                        (W + 2 * kTileW - 1) / (2 * kTileW), tiles_x, boxes + tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH),
                        pk_t + tile_count(W, H, kMidTileH) * 512, nofit + 1);
     me = hipGetLastError();
@@ -1267,7 +1267,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         int seg_len = (R * tiles_x + 4 * nbx - 1) / (4 * nbx);   // ~4 items per workgroup
         if (seg_len < 4) seg_len = 4;
         if (seg_len > R) seg_len = R > 0 ? R : 1;
-        hipLaunchKernelGGL(mf_rect_decode_ring_kernel, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(256), lds, s, jr, njobs,
+        SLR_LAUNCH(mf_rect_decode_ring_kernel, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(256), lds, s, jr, njobs,
                            pitch, W, H, black_thr, atan_lut, tiles_x, tiles_y8, seg_len);
         return hipGetLastError();
     }
@@ -1329,24 +1329,24 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     if (nbx < 1) nbx = 1;
     const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);
 #define SLR_RECT_LAUNCH(TH_, R_, S_)                                                                                  \
-    hipLaunchKernelGGL((mf_rect_decode_lds_kernel<TH_, R_, S_>), grid, dim3(256), (size_t)budget + 16, s, j, njobs, pitch, W, \
+    SLR_LAUNCH((mf_rect_decode_lds_kernel<TH_, R_, S_>), grid, dim3(256), (size_t)budget + 16, s, j, njobs, pitch, W, \
                        H, black_thr, atan_lut, tiles_x, tiles_yy, budget)
     if (wide8) {
-        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
+        if (strided) SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
-        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
+        else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
     else if (wide) {
-        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+        if (strided) SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
-        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+        else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
     else if (mid && j.j[0].pk_t) {
-        if (strided) hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+        if (strided) SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
-        else         hipLaunchKernelGGL((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
+        else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
     else if (mid) { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
@@ -1381,9 +1381,9 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
     }
     if (map_xy) {
         const bool vec = (W % 4 == 0);
-        if (vec) hipLaunchKernelGGL(mf_rect_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
+        if (vec) SLR_LAUNCH(mf_rect_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
                                     pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
-        else     hipLaunchKernelGGL(mf_rect_decode_kernel<1>, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
+        else     SLR_LAUNCH(mf_rect_decode_kernel<1>, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
                                     pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
         return hipGetLastError();
     }
@@ -1400,10 +1400,10 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
     // measured on MI355X at 4096x3000: 4 px/thread 56.8 us, 8 px 58.5 us, 16 px 69.4 us (the 16-px form stores 64-byte
     // strided fragments per lane; the 4-px form writes one contiguous KiB per wave instruction) -> default 4
     if (a16 && vec_hint == 16)
-                  hipLaunchKernelGGL(mf_decode_kernel<4>, dim3(pick_blocks_k2((size_t)(W / 16) * H)), dim3(256), 0, s,
+                  SLR_LAUNCH(mf_decode_kernel<4>, dim3(pick_blocks_k2((size_t)(W / 16) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a8 && vec_hint == 8)
-                  hipLaunchKernelGGL(mf_decode_kernel<2>, dim3(pick_blocks_k2((size_t)(W / 8) * H)), dim3(256), 0, s,
+                  SLR_LAUNCH(mf_decode_kernel<2>, dim3(pick_blocks_k2((size_t)(W / 8) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     else if (a4 && pitch != W && H > 1) {                   // padded rows: (column group, row) grid, rows strided
         const unsigned gx = (unsigned)((W / 4 + 255) / 256), cap = pick_blocks_k2((size_t)(W / 4) * H);
@@ -1411,12 +1411,12 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
         if (gy > (unsigned)H) gy = (unsigned)H;
         if (gy > 65535u) gy = 65535u;
         if (gy < 2u) gy = 2u;                               // gridDim.y > 1 selects this form in the kernel
-                  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(gx, gy), dim3(256), 0, s,
+                  SLR_LAUNCH(mf_decode_kernel<1>, dim3(gx, gy), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     }
-    else if (a4)  hipLaunchKernelGGL(mf_decode_kernel<1>, dim3(pick_blocks_k2((size_t)(W / 4) * H)), dim3(256), 0, s,
+    else if (a4)  SLR_LAUNCH(mf_decode_kernel<1>, dim3(pick_blocks_k2((size_t)(W / 4) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
-    else          hipLaunchKernelGGL(mf_decode_scalar_kernel, dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
+    else          SLR_LAUNCH(mf_decode_scalar_kernel, dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     return hipGetLastError();
 }
@@ -1696,7 +1696,7 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
         bool strided = st >= (long long)H * pitch && st * nplanes < (1ll << 31) && !getenv("SLR_DEBUG_RECT_NO_BUFFER");
         for (int i = 2; i < nplanes && strided; i++) strided = (long long)(pl.p[i] - pl.p[0]) == st * i;
 #define SLR_GRAY_LDS(TH_, S_)                                                                                          \
-        hipLaunchKernelGGL((gray_rect_decode_lds_kernel<TH_, S_>), dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,     \
+        SLR_LAUNCH((gray_rect_decode_lds_kernel<TH_, S_>), dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,     \
                            (unsigned)st, n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy, \
                            map_frac, boxes, code_x, code_y, valid, tiles_x, tiles_y, budget)
         if (mid) { if (strided) SLR_GRAY_LDS(kMidTileH, true); else SLR_GRAY_LDS(kMidTileH, false); }
@@ -1711,7 +1711,7 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
         for (int p = 0; p < nplanes; p++) a4 = a4 && ((uintptr_t)pl.p[p] % 4 == 0);
     }
 #define SLR_GRAY_LAUNCH(V, RECT)                                                                              \
-    hipLaunchKernelGGL((gray_decode_kernel<V, RECT>), dim3(pick_blocks((size_t)(W / V) * H)), dim3(256), 0, s, \
+    SLR_LAUNCH((gray_decode_kernel<V, RECT>), dim3(pick_blocks((size_t)(W / V) * H)), dim3(256), 0, s, \
                        pl, n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr, scan_w, scan_h, map_xy,  \
                        map_frac, code_x, code_y, valid)
     if (map_xy) { if (a4) SLR_GRAY_LAUNCH(4, true); else SLR_GRAY_LAUNCH(1, true); }

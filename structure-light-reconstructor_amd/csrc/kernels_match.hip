@@ -775,7 +775,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 {
     const size_t n = (size_t)W * H;
     const unsigned blocks = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(undistort_table_kernel, dim3(blocks), dim3(256), 0, s, cal, W, H, (float2 *)undL_xy, undRx);
+    SLR_LAUNCH(undistort_table_kernel, dim3(blocks), dim3(256), 0, s, cal, W, H, (float2 *)undL_xy, undRx);
     return hipGetLastError();
 }
 
@@ -794,10 +794,10 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 #define SLR_SORTED(BLOCK, IPT)                                                                                     \
     do {                                                                                                           \
         if (algo == 2)                                                                                             \
-            hipLaunchKernelGGL((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
+            SLR_LAUNCH((mf_match_sorted_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
                                phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
         else                                                                                                       \
-            hipLaunchKernelGGL((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
+            SLR_LAUNCH((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
                                phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
     } while (0)
         // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
@@ -808,7 +808,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         else if (W <= 4096) SLR_SORTED(1024, 4);
         else if (algo == 2) SLR_SORTED(1024, 8);
         else                                                 // wider rows: the right row in chunks of 4096 columns
-            hipLaunchKernelGGL(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
+            SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
                                cal, vec_ok, undL, undRx, xyz, has, match_k);
 #undef SLR_SORTED
         return hipGetLastError();
@@ -817,12 +817,12 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         const int vec_ok = (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
                            ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
-        hipLaunchKernelGGL(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
+        SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
                            cal, vec_ok, undL, undRx, xyz, has, match_k);
         return hipGetLastError();
     }
     const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);
-    hipLaunchKernelGGL(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, row0, cal,
+    SLR_LAUNCH(mf_match_kernel, dim3(H), dim3(256), lds, s, phaseL, validL, phaseR, validR, W, H, row0, cal,
                        xyz, has, match_k);
     return hipGetLastError();
 }
@@ -960,7 +960,7 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
 {
     const int TC = 8192;                           // codes below this use the direct list-head table (16 KB LDS)
 #define SLR_GE(IPT)                                                                                                    \
-    hipLaunchKernelGGL(ge_match_kernel<IPT>, dim3(H), dim3(256), (size_t)TC * 2, s, codeL, validL, codeR, validR, W, H, TC, \
+    SLR_LAUNCH(ge_match_kernel<IPT>, dim3(H), dim3(256), (size_t)TC * 2, s, codeL, validL, codeR, validR, W, H, TC, \
                        cal, whiteL, whiteR, xyz, has, color, match_k)
     if (W <= 256) SLR_GE(1);
     else if (W <= 512) SLR_GE(2);

@@ -132,7 +132,7 @@ hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_st
     const size_t groups = a4 ? (size_t)(W / 4) * H : (size_t)W * H;
     const unsigned blocks = (unsigned)((groups + 255) / 256 < 65536 ? (groups + 255) / 256 : 65536);
 #define SLR_MFN(V, FS, NS)                                                                                       \
-    hipLaunchKernelGGL((mfn_decode_kernel<V, FS, NS>), dim3(blocks ? blocks : 1), dim3(256), 0, s, pl, tr, n_freq, n_step, \
+    SLR_LAUNCH((mfn_decode_kernel<V, FS, NS>), dim3(blocks ? blocks : 1), dim3(256), 0, s, pl, tr, n_freq, n_step, \
                        pitch, W, H, black_thr, phase, valid)
     if (a4 && n_freq == 4 && n_step == 8) SLR_MFN(4, 4, 8);          // BASELINE config 5
     else if (a4 && n_freq == 3 && n_step == 4) SLR_MFN(4, 3, 4);     // the reference's own pattern count

@@ -64,7 +64,7 @@ hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const 
 {
     const size_t n = (size_t)W * H;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
-    hipLaunchKernelGGL(ray_count_kernel, dim3(blocks), dim3(256), 0, s, code_x, code_y, valid, (unsigned)n, scan_w,
+    SLR_LAUNCH(ray_count_kernel, dim3(blocks), dim3(256), 0, s, code_x, code_y, valid, (unsigned)n, scan_w,
                        scan_h, cnt, cell_of, rank_of);
     return hipGetLastError();
 }
@@ -72,7 +72,7 @@ hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const 
 hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, int W, int H, const uint32_t *offs,
                               uint32_t *items, hipStream_t s)
 {
-    hipLaunchKernelGGL(ray_scatter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cell_of, rank_of, W, offs, items);
+    SLR_LAUNCH(ray_scatter_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cell_of, rank_of, W, offs, items);
     return hipGetLastError();
 }
 
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void ray_table_kernel(DevCalib cal, int W, int
 
 hipError_t launch_ray_tables(const DevCalib &cal, int W, int H, float *raysL, float *raysR, hipStream_t s)
 {
-    hipLaunchKernelGGL(ray_table_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cal, W, H, raysL, raysR);
+    SLR_LAUNCH(ray_table_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, cal, W, H, raysL, raysR);
     return hipGetLastError();
 }
 
@@ -265,7 +265,7 @@ hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const D
 {
     const size_t nb = (size_t)scan_w * scan_h;
     const unsigned blocks = (unsigned)((nb + 255) / 256 < 16384 ? (nb + 255) / 256 : 16384);
-    hipLaunchKernelGGL(ray_triangulate_kernel, dim3(blocks), dim3(256), 0, s, offs, items, cal, (unsigned)nb, W, raysL,
+    SLR_LAUNCH(ray_triangulate_kernel, dim3(blocks), dim3(256), 0, s, offs, items, cal, (unsigned)nb, W, raysL,
                        raysR, xyz_sum, count);
     return hipGetLastError();
 }
@@ -302,7 +302,7 @@ hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8
 {
     const size_t n = (size_t)scan_w * scan_h;
     const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pc_from_grid_kernel, dim3(blocks), dim3(256), 0, s, xyz, has, color, W, H, scan_w, scan_h,
+    SLR_LAUNCH(pc_from_grid_kernel, dim3(blocks), dim3(256), 0, s, xyz, has, color, W, H, scan_w, scan_h,
                        pc_sum, pc_count, pc_color);
     return hipGetLastError();
 }
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void pc_get_kernel(const float *__restrict__ p
 hipError_t launch_pc_get(const float *pc_sum, const uint8_t *pc_count, size_t n, float *out, hipStream_t s)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? ((n + 255) / 256 ? (n + 255) / 256 : 1) : 8192);
-    hipLaunchKernelGGL(pc_get_kernel, dim3(blocks), dim3(256), 0, s, pc_sum, pc_count, n, out);
+    SLR_LAUNCH(pc_get_kernel, dim3(blocks), dim3(256), 0, s, pc_sum, pc_count, n, out);
     return hipGetLastError();
 }
 

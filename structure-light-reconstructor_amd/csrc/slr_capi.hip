@@ -38,6 +38,8 @@ struct ProfRec { hipEvent_t a, b; int id; };
 
 }  // namespace
 
+namespace slr { thread_local hipEvent_t tl_prof_start = nullptr, tl_prof_stop = nullptr; }
+
 struct slr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -190,9 +192,11 @@ int prof_event(slr_ctx *c, hipEvent_t *e)
     return SLR_OK;
 }
 
+// exact == true (scopes around ONE kernel launch): the events are armed for SLR_LAUNCH, which stamps them at the kernel's
+// own start and end; otherwise (several launches, or a library call such as the hipcub scan) they bracket the scope
 struct ProfScope {
-    slr_ctx *c; int id; ProfRec r{}; bool on;
-    ProfScope(slr_ctx *ctx, int kid) : c(ctx), id(kid), on(ctx->profiling)
+    slr_ctx *c; int id; ProfRec r{}; bool on, exact;
+    ProfScope(slr_ctx *ctx, int kid, bool exact_ = false) : c(ctx), id(kid), on(ctx->profiling), exact(exact_)
     {
         if (!on) return;
         // sampling: bracket only every opt_profile_stride-th launch of this kernel (two event records per launch cost
@@ -200,12 +204,21 @@ struct ProfScope {
         if (c->opt_profile_stride > 1 && (c->prof_seen[kid]++ % c->opt_profile_stride) != 0) { on = false; return; }
         if (prof_event(c, &r.a) != SLR_OK || prof_event(c, &r.b) != SLR_OK) { on = false; return; }
         r.id = id;
-        (void)hipEventRecord(r.a, c->stream);
+        if (exact) { tl_prof_start = r.a; tl_prof_stop = r.b; }
+        else (void)hipEventRecord(r.a, c->stream);
     }
     ~ProfScope()
     {
         if (!on) return;
-        (void)hipEventRecord(r.b, c->stream);
+        if (exact) {
+            if (tl_prof_start == r.a) {                  // no kernel was launched in this scope: no sample
+                tl_prof_start = tl_prof_stop = nullptr;
+                c->free_events.push_back(r.a); c->free_events.push_back(r.b);
+                return;
+            }
+        } else {
+            (void)hipEventRecord(r.b, c->stream);
+        }
         c->pending.push_back(r);
     }
 };
@@ -254,7 +267,7 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
 {
     MfPlanes mp;
     for (int i = 0; i < SLR_MF_PLANES; i++) mp.p[i] = pl[i];
-    ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE);
+    ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE, true);
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
                                 rectify ? c->d_tile_box[cam] : nullptr, c->opt_mf_decode_vec, mf_rect_algo(c, cam, cam), c->stream));
@@ -281,7 +294,7 @@ int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *
         }
         undL = (const float *)a; undR = (const float *)b;
     }
-    ProfScope ps(c, K_MF_MATCH);
+    ProfScope ps(c, K_MF_MATCH, true);
     SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, rows, row0, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
                                c->stream));
     return SLR_OK;
@@ -294,7 +307,7 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
     GrayPlanes gp;
     const int n = 2 + 2 * ncol + 2 * nrow;
     for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) gp.p[i] = i < n ? pl[i] : nullptr;
-    ProfScope ps(c, rectify ? K_GRAY_RECT_DECODE : K_GRAY_DECODE);
+    ProfScope ps(c, rectify ? K_GRAY_RECT_DECODE : K_GRAY_DECODE, true);
     SLR_HIP(c, launch_gray_decode(gp, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx, cy, valid,
                                   rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
                                   rectify ? c->d_tile_box[cam] : nullptr, c->opt_rect_algo, c->stream));
@@ -564,7 +577,7 @@ int slr_remap_u8(slr_ctx *c, int cam, const uint8_t *src, int src_pitch, uint8_t
     const void *ds; void *dd;
     SLR_TRY(st.in(src, (size_t)src_pitch * H, &ds));
     SLR_TRY(st.out(dst, (size_t)dst_pitch * H, &dd));
-    { ProfScope ps(c, K_REMAP);
+    { ProfScope ps(c, K_REMAP, true);
       SLR_HIP(c, launch_remap_u8((const uint8_t *)ds, src_pitch, (uint8_t *)dd, dst_pitch, W, H, c->d_map_xy[cam],
                                  c->d_map_frac[cam], c->stream)); }
     return st.finish();
@@ -651,7 +664,7 @@ int slr_mfn_decode(slr_ctx *c, const uint16_t *const *planes, int n_freq, int n_
         SLR_TRY(get_scratch(c, S_STAGE0 + 1, n * 4, &dph));
         SLR_TRY(get_scratch(c, S_STAGE0 + 2, n, &dv));
     }
-    { ProfScope ps(c, K_MFN_DECODE);
+    { ProfScope ps(c, K_MFN_DECODE, true);
       SLR_HIP(c, launch_mfn_decode(dp, n_freq, n_step, pitch, W, H, black_thr, (float *)dph, (uint8_t *)dv, c->stream)); }
     if (mem != SLR_MEM_DEVICE) {
         const size_t n = (size_t)W * H;
@@ -737,7 +750,7 @@ int slr_ge_triangulate(slr_ctx *c, const int32_t *codeL, const uint8_t *validL, 
     SLR_TRY(st.in(whiteL, n, &wl)); SLR_TRY(st.in(whiteR, n, &wr));
     SLR_TRY(st.out(xyz, n * 12, &dx)); SLR_TRY(st.out(has, n, &dh));
     SLR_TRY(st.out(color, n, &dc)); SLR_TRY(st.out(match_k, n * 4, &dk));
-    { ProfScope ps(c, K_GE_MATCH);
+    { ProfScope ps(c, K_GE_MATCH, true);
       SLR_HIP(c, launch_ge_match((const int32_t *)cl, (const uint8_t *)vl, (const int32_t *)cr, (const uint8_t *)vr, W, H,
                                  c->cal, (const uint8_t *)wl, (const uint8_t *)wr, (float *)dx, (uint8_t *)dh,
                                  (uint8_t *)dc, (int32_t *)dk, c->stream)); }
@@ -815,10 +828,9 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
         const int16_t *const mxy[2] = {c->d_map_xy[0], c->d_map_xy[1]};
         const uint16_t *const mfr[2] = {c->d_map_frac[0], c->d_map_frac[1]};
         const void *const box[2] = {c->d_tile_box[0], c->d_tile_box[1]};
-        ProfScope ps(c, K_MF_RECT_DECODE_PAIR);
+        ProfScope ps(c, K_MF_RECT_DECODE_PAIR, true);
         SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, mf_rect_algo(c, 0, 1),
                                               &paired, c->stream));
-        if (!paired && ps.on) { ps.on = false; c->free_events.push_back(ps.r.a); c->free_events.push_back(ps.r.b); }
     }
     if (!paired) {
         SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
@@ -904,9 +916,9 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
             void *a, *b;
             SLR_TRY(get_scratch(c, S_COLOR, n * 2, &a));
             b = (uint8_t *)a + n;
-            { ProfScope ps(c, K_REMAP);
+            { ProfScope ps(c, K_REMAP, true);
               SLR_HIP(c, launch_remap_u8(dl[0], pitch, (uint8_t *)a, W, W, H, c->d_map_xy[0], c->d_map_frac[0], c->stream)); }
-            { ProfScope ps(c, K_REMAP);
+            { ProfScope ps(c, K_REMAP, true);
               SLR_HIP(c, launch_remap_u8(dr[0], pitch, (uint8_t *)b, W, W, H, c->d_map_xy[1], c->d_map_frac[1], c->stream)); }
             wl = (const uint8_t *)a; wr = (const uint8_t *)b;
         } else {
@@ -914,7 +926,7 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
             wl = dl[0]; wr = dr[0];
         }
     }
-    { ProfScope ps(c, K_GE_MATCH);
+    { ProfScope ps(c, K_GE_MATCH, true);
       SLR_HIP(c, launch_ge_match((const int32_t *)cxl, (const uint8_t *)vl, (const int32_t *)cxr, (const uint8_t *)vr, W, H,
                                  c->cal, wl, wr, (float *)dx, (uint8_t *)dh, (uint8_t *)dc, nullptr, c->stream)); }
     return st.finish();
