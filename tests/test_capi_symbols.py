@@ -32,6 +32,21 @@ def test_library_exports_every_declared_symbol(slr):
     assert "slr_mf_decode" in names and "slr_mf_match_triangulate" in names and all(names)
 
 
+def test_header_constants_match_the_binding(slr):
+    """option ids, status codes and memory kinds of include/slr.h == the ctypes mirror's"""
+    text = open(os.path.join(ROOT, "include", "slr.h")).read()
+    defines = {k: int(v) for k, v in re.findall(r"#define\s+(SLR_[A-Z0-9_]+)\s+(-?\d+)\b", text)}
+    enums = {k: int(v) for k, v in re.findall(r"\b(SLR_[A-Z_]+)\s*=\s*(-?\d+)", text)}
+    cap = slr.capi
+    for name in ("MF_MATCH_ALGO", "MF_DECODE_VEC", "RECT_DECODE_ALGO", "ASYNC_HOST", "PROFILE_STRIDE"):
+        assert defines["SLR_OPT_" + name] == getattr(cap, "OPT_" + name), name
+    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 6))   # no duplicate ids
+    for name in ("OK", "ERR_INVALID_ARG", "ERR_NO_DEVICE", "ERR_HIP", "ERR_NOT_CONFIGURED", "ERR_UNSUPPORTED", "ERR_OOM"):
+        assert enums["SLR_" + name] == getattr(cap, name), name
+    assert (enums["SLR_MEM_HOST"], enums["SLR_MEM_DEVICE"]) == (cap.MEM_HOST, cap.MEM_DEVICE)
+    assert defines["SLR_MF_PLANES"] == 14
+
+
 def test_product_never_touches_the_oracle():
     """the oracle is test infrastructure: nothing under the product package may import/link/execute it"""
     pkg = os.path.join(ROOT, "structure-light-reconstructor_amd")
