@@ -191,6 +191,12 @@ class Context:
         if mem == MEM_DEVICE and self.stream is not None:
             import torch
             self.stream.wait_stream(torch.cuda.current_stream(self.stream.device))
+            # the kernels run on the ctx stream, the tensors were allocated on torch's current stream: tell the caching
+            # allocator, or a temporary passed inline (ctx.reconstruct_mf(a.cuda(), ...)) is freed on return and its
+            # block handed to another current-stream allocation while the kernels are still queued
+            for a in arrs:
+                if a is not None and _is_torch(a):
+                    a.record_stream(self.stream)
         return mem
 
     # -- plumbing
@@ -233,7 +239,10 @@ class Context:
         if like_mem == MEM_DEVICE:
             import torch
             tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
-            return torch.empty(shape, dtype=tdt, device=like.device)
+            t = torch.empty(shape, dtype=tdt, device=like.device)
+            if self.stream is not None:
+                t.record_stream(self.stream)            # written on the ctx stream (see _mem)
+            return t
         return np.empty(shape, dtype)
 
     # -- configuration

@@ -1,6 +1,7 @@
 """BASELINE.json's full size (4096x3000) on the GPU: direct comparison with the oracle where the oracle finishes in
-seconds (decode, rectify, Gray, GE), sampled rows + size-independent properties where it does not (the O(W^2) MF
-match: indexed form == literal sweep on the whole frame; oracle on a handful of rows)."""
+seconds (decode, rectify, Gray, GE, GRAY_ONLY, the PointCloudImage adaptor; the O(W^2) MF match on all 3000 rows), plus
+size-independent properties (indexed match forms == literal sweep on the whole frame, depth from disparity) and one
+config-5 sized case (8192x6000, 4 freq x 8 steps fp16) on sampled rows."""
 import numpy as np
 import pytest
 import torch
@@ -61,9 +62,9 @@ def test_fullsize_mf_match_forms_agree_and_oracle_rows(ctx, oracle, scene, slr):
     assert 0.05 < has.mean() < 1.0
     camL, camR, Q, T = calib_parts(oracle, calib)
     phL, vL, phR, vR = [np_of(t) for t in (dec[0][0], dec[0][1], dec[1][0], dec[1][1])]
-    for r in (0, 1, 777, 1500, 2999):
-        exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T, rows=(r, r + 1))
-        assert bits_equal(mk[r], emk[r]) and bits_equal(has[r], ehas[r]) and bits_equal(xyz[r], exyz[r]), r
+    # every one of the 3000 rows against the oracle's O(W^2) first-match search (~7 s single-threaded)
+    exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
+    assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz)
     # whole-path entry point == the three stages
     x2, h2 = ctx.reconstruct_mf(st[0], st[1], BLACK, True)
     ctx.synchronize()
@@ -116,3 +117,106 @@ def test_fullsize_whole_path_pair_launch_equals_step_by_step(ctx, scene):
         ctx.synchronize()
         assert torch.equal(has[f], eh) and torch.equal(xyz[f], ex), f
     assert 0.2 < has[0].float().mean().item() < 1.0
+
+
+def test_fullsize_ge_whole_path_with_rectification_and_colour(ctx, oracle, synth, scene):
+    """config 3's Gray half at size: slr_reconstruct_ge (fused rectify + Gray decode of 26 planes per camera, K5, colour)
+    and the fused decode on its own against remap -> decode -> triangulation_ge of the oracle; then the
+    PointCloudImage adaptor (Q11: transposed + cropped) on the full grid"""
+    _, maps, calib, _ = scene
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    dev = torch.device("cuda", 0)
+    g = synth.render_gray_stack(W, H, W, seed=77, noise=2, device=dev)
+    ncol = synth.gray_num_bits(W)
+    torch.cuda.synchronize()
+    edec, white = [], []
+    for cam in range(2):
+        raw = g[cam].cpu().numpy()
+        mx, mf = maps[cam][0].cpu().numpy(), maps[cam][1].cpu().numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(raw.shape[0])])
+        ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 3, W, 0)
+        cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, W, 0, rectify_cam=cam)      # slr_gray_rectify_decode
+        ctx.synchronize()
+        assert bits_equal(np_of(cx), ex) and bits_equal(np_of(v), ev), cam
+        edec.append((ex, ev))
+        white.append(rect[0])
+    _, _, Q, T = calib_parts(oracle, calib)
+    exyz, ehas, ecol, _ = oracle.ge_triangulate(edec[0][0], edec[0][1], edec[1][0], edec[1][1], Q, T, white[0], white[1])
+    xyz, has, col = ctx.reconstruct_ge(g[0], g[1], ncol, BLACK, 3, W, True, True)
+    ctx.synchronize()
+    assert bits_equal(np_of(has), ehas) and bits_equal(np_of(xyz), exyz) and bits_equal(np_of(col), ecol)
+    assert ehas.mean() > 0.3
+    for scan_w, scan_h in ((1280, 1024), (3000, 4096), (4096, 4096)):
+        es, ec, ek = oracle.pointcloud_from_grid(exyz, ehas, scan_w, scan_h, ecol)
+        s, c, k = ctx.pointcloud_from_grid(xyz, has, scan_w, scan_h, col)
+        ctx.synchronize()
+        assert bits_equal(np_of(c), ec) and bits_equal(np_of(s), es) and bits_equal(np_of(k), ek), (scan_w, scan_h)
+
+
+def test_fullsize_gray_only_whole_path(ctx, oracle, synth):
+    """GRAY_ONLY at size (reconstruct.cpp:230-265): 4096x3000 cameras, 1280x1024 projector, column + row bits (44 planes
+    per camera) -> bucket scatter -> ray-ray triangulation, against the oracle's decode + bucket + Reconstruct::triangulation"""
+    scan_w, scan_h = 1280, 1024
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    dev = torch.device("cuda", 0)
+    st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=52, noise=2, device=dev, rows=True)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    torch.cuda.synchronize()
+    dec = [oracle.gray_decode(st[c].cpu().numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h) for c in range(2)]
+    offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.reconstruct_gray(st[0], st[1], ncol, nrow, BLACK, 0, scan_w, scan_h)
+    ctx.synchronize()
+    assert bits_equal(np_of(cnt), ecnt) and bits_equal(np_of(xyz), exyz)
+    assert (ecnt > 0).mean() > 0.2 and (ecnt > 1).any()
+    got = ctx.pointcloud_get(xyz, cnt)
+    ctx.synchronize()
+    assert bits_equal(np_of(got), oracle.pointcloud_get(exyz, ecnt))
+
+
+def test_config5_size_mfn_decode_and_chunked_match(ctx, oracle, synth):
+    """BASELINE config 5 at its stated size on one GPU: 8192x6000, 4 frequencies x 8 steps, fp16 planes.  The decode
+    (build extension: no reference counterpart) against the fp64 model on sampled rows, the match (rows wider than 4096 run
+    the chunked K4) against the oracle's literal search on sampled rows, and the whole frame against itself cut into
+    the row bands an 8-GPU run would use (dist.shard_rows)"""
+    W5, H5, F, N = 8192, 6000, 4, 8
+    dev = torch.device("cuda", 0)
+    calib, _ = synth.make_calibration(W5, H5)
+    ctx.set_calibration(calib)
+    st = synth.render_mfn_stack(W5, H5, F, N, noise=0.25, seed=5, device=dev)
+    torch.cuda.synchronize()
+    dec = [ctx.mfn_decode(st[cam], F, N, 40.0) for cam in range(2)]
+    xyz, has, mk = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
+    ctx.synchronize()
+    rows = [0, 1, 749, 750, 2999, 3000, 4242, 5999]
+    for cam in range(2):
+        sub = st[cam][:, rows, :].cpu().numpy()
+        exp, ev = oracle.mfn_decode_f64(sub, F, N, 40.0)
+        ph, v = np_of(dec[cam][0])[rows], np_of(dec[cam][1])[rows]
+        assert np.array_equal(v, ev)
+        d = np.abs(ph.astype(np.float64) - exp)
+        tol = 2e-3 + 1e-4 * np.abs(exp)                                  # north_star: 1e-4 relative (+ f32 floor)
+        per = np.abs(d - 255.0 * np.round(d / 255.0))                    # wrap flips at an a > b decided in f32 vs f64
+        assert ((d > tol) & (per > tol)).sum() == 0
+        assert (d > tol).sum() <= 1e-3 * ph.size
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    phL, vL, phR, vR = [np_of(t) for t in (dec[0][0], dec[0][1], dec[1][0], dec[1][1])]
+    hx, hh, hk = np_of(xyz), np_of(has), np_of(mk)
+    for r in rows:
+        exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T, rows=(r, r + 1))
+        assert bits_equal(hk[r], emk[r]) and bits_equal(hh[r], ehas[r]) and bits_equal(hx[r], exyz[r]), r
+    assert hh.mean() > 0.05
+    del hx, hh, hk, phL, phR
+    # 8 row bands (what rank r of an 8-GPU run computes) concatenated == the whole frame
+    band = (H5 + 7) // 8
+    for b in range(8):
+        r0, r1 = b * band, min(H5, (b + 1) * band)
+        bx, bh, bk = ctx.mf_triangulate(dec[0][0][r0:r1], dec[0][1][r0:r1], dec[1][0][r0:r1], dec[1][1][r0:r1],
+                                        row0=r0, image_h=H5)
+        ctx.synchronize()
+        assert torch.equal(bx, xyz[r0:r1]) and torch.equal(bh, has[r0:r1]) and torch.equal(bk, mk[r0:r1]), b
