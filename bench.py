@@ -70,7 +70,9 @@ def parse_args():
                     help="bytes of row padding of the HBM-resident stacks (pitch = width + pad).  A pitch that is a power of two "
                          "(4096) puts the ~10 source rows of every tile of the rectifying decode on the same HBM channels: the "
                          "fused kernel is 3-6 %% faster with 64..1152 bytes of padding (the unfused one 1-3 %% slower)")
-    ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8)")
+    ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
+    ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
+    ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
     return ap.parse_args()
@@ -255,6 +257,10 @@ def main():
         c_.set_calibration(calib)
         if args.rect_algo:
             c_.set_option(slr.capi.OPT_RECT_DECODE_ALGO, args.rect_algo)
+        if args.dma_shape >= 0:
+            c_.set_option(slr.capi.OPT_RECT_DMA_SHAPE, args.dma_shape)
+        if args.dma_depth >= 0:
+            c_.set_option(slr.capi.OPT_RECT_DMA_DEPTH, args.dma_depth)
         if args.rectify:
             for cam in range(2):
                 c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])

@@ -94,7 +94,7 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_RECT_DECODE_ALGO: form of the fused rectify+decode kernel (identical results).  All LDS-tiled forms run
  * persistent workgroups with a register prefetch pipeline and fall back, per tile, to a direct gather when the tile's
  * source box does not fit their LDS budget.
- *   0 = auto (default): 5, or 6 when the maps would make more pixels fall back in 5 than in 6
+ *   0 = auto (default): 7 when it applies, else 5, or 6 when the maps would make more pixels fall back in 5 than in 6
  *   1 = direct gather (no LDS tiles)
  *   2 = 64x16 tiles, two prefetch rounds
  *   3 = 64x8 tiles walking down tile columns with a 16-row sliding LDS window (no halo re-reads: 1.03x instead of
@@ -102,6 +102,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
  *   4 = 128x8 tiles, 256 threads, two prefetch rounds
  *   5 = 128x8 tiles, 512 threads (waves 0-3 left half, 4-7 right half), one round, pre-digested 4-byte map entries
  *   6 = 64x8 tiles, 256 threads, one round, pre-digested 4-byte map entries
+ *   7 = LDS-DMA form (round 2): 256- or 128-pixel-wide tiles (SLR_OPT_RECT_DMA_SHAPE) decoded in 7 phases of two
+ *       planes whose source boxes go HBM -> LDS by buffer_load ... lds into a double / triple buffer.  Needs the 14 planes
+ *       of a camera equally spaced in one allocation, 16-byte aligned rows, W % 16 == 0 and maps whose tile boxes fit;
+ *       auto falls back to 5 / 6 otherwise (also per call); an explicit 7 makes such calls fail with SLR_ERR_UNSUPPORTED.
  * The Gray fused decode only distinguishes 1 (gather), 2 (64x4 tiles) and everything else (64x8 tiles when they fit). */
 #define SLR_OPT_RECT_DECODE_ALGO 3
 /* SLR_OPT_ASYNC_HOST: 1 = calls with SLR_MEM_HOST buffers return once the H2D copies, the kernels and the D2H copies
@@ -112,6 +116,12 @@ const char  *slr_last_error(const slr_ctx *ctx);
 #define SLR_OPT_ASYNC_HOST 4
 /* SLR_OPT_PROFILE_STRIDE: the built-in HIP-event profiler brackets every n-th launch of a kernel (default 1 = all) */
 #define SLR_OPT_PROFILE_STRIDE 5
+/* SLR_OPT_RECT_DMA_SHAPE: destination tile / workgroup size of form 7: 0 = 256x16 / 512 threads, 1 = 256x8 / 512 (default), 2 = 256x8 / 256,
+ * 3 = 128x16 / 512, 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
+ * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
+ * the decode, 1 (double buffer) or 2 (triple buffer). */
+#define SLR_OPT_RECT_DMA_SHAPE 6
+#define SLR_OPT_RECT_DMA_DEPTH 7
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */

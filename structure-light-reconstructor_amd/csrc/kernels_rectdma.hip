@@ -1,0 +1,643 @@
+// kernels_rectdma.hip -- fused rectify + multi-frequency decode, LDS-DMA form (SLR_OPT_RECT_DECODE_ALGO = 7, what "auto"
+// picks when the maps and the stack layout allow it).  gfx950 (MI355X) only.
+//
+// Round 1's fused kernel staged the 14-plane source box of a 128 x 8 tile through VGPRs: box fetch (short row segments,
+// the cost follows the 128-byte lines touched), tap/decode VALU work and LDS traffic ADDED instead of overlapping
+// (VERDICT r01, 0.39 of the HBM roofline).  This form changes the decomposition:
+//   * the box goes HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: 16 bytes per lane, no VGPR staging, no commit pass)
+//     in its NATURAL [plane][row][x] byte layout with a compile-time row stride, every thread owning one 16-byte chunk;
+//     the taps are read back with ds_read_b32 at immediate offsets from one address register, a pixel ahead of their use;
+//   * a tile is decoded in 7 PHASES of 2 planes (white/black, then G1/G3 and G2/G4 of each frequency): only 2 planes of a
+//     box are resident, so a 256 x 16 (or 512 x 8) tile fits a double / triple LDS buffer and its source row segments are
+//     2-4x longer than before (profiles/r02/exp_dmabox.txt: 37 us instead of 54 us to pull one camera's boxes, cold);
+//   * the tap state of a thread's 4 or 8 pixels stays in registers across the phases, the per-frequency results collapse
+//     to one wrapped phase per pixel as soon as their four planes have passed;
+//   * one s_barrier per phase; the DMA of phase k+A is in flight while phase k is decoded (A = 1 or 2); every wave issues
+//     the same static sequence of vector-memory operations, so the waits are COUNTED (s_waitcnt vmcnt(N), N from the
+//     sequence) and never drain the queue; the map digest of the next tile arrives by DMA as well.
+// Results are bit-identical to the other forms (same table-driven decode, same v_perm / v_dot2 blend).
+//
+// Reference behaviour restated (never copied): stereoRect::doStereoRectify (cv::remap INTER_LINEAR, BORDER_CONSTANT)
+// Duke/stereorect.cpp:26-34 fused with MFReconstruct::computeShadows/decodePatterns/getPhase Duke/mfreconstruct.cpp:190-269.
+#include "decode_common.hpp"
+
+#include <stdlib.h>
+
+namespace slr {
+
+constexpr unsigned kDmaInvalid = 0x80000000u;    // buffer offset beyond every descriptor's range: loads 0, stores nothing
+
+// destination tile TW x TH decoded by a workgroup of NT threads: pixel (row, col) of the tile belongs to pass q, wave w, lane l
+// with row = q * RPP + w / WPR, col = (w % WPR) * 64 + l.
+template <int TW, int TH, int NT>
+struct DmaGeom {
+    static constexpr int NWAVES = NT / 64;
+    static constexpr int PX = TW * TH / NT;                     // pixels per thread (= passes)
+    static constexpr int WPR = TW / 64;                         // waves per tile row
+    static constexpr int RPP = NWAVES / WPR;                    // tile rows per pass
+    static constexpr int CMAX = TW / 16 + 2;                    // 16-byte chunks per source row held in LDS
+    static constexpr int BHMAX = (TH + 8) * CMAX <= NT ? TH + 8 : NT / CMAX;   // source rows held (one chunk per thread)
+    static constexpr int RS = CMAX * 16;                        // LDS row stride (bytes)
+    static constexpr int NCH = (CMAX * BHMAX + 63) / 64 * 64;   // chunks of a plane image, whole waves
+    static constexpr int PS = NCH * 16;                         // LDS plane stride: the first NCH / 64 waves own a 1 KiB slot each
+    static_assert(TW % 64 == 0 && NWAVES % WPR == 0 && RPP >= 1 && PX >= 4 && PX % 4 == 0 && PX <= 8, "tile shape");
+    static_assert(BHMAX >= TH + 3, "no room for the bilinear row and a little tilt");
+    static_assert(BHMAX * RS <= PS && PS <= 8192 && NCH <= NT, "tap address field (13 bits), one chunk per thread");
+};
+
+// shapes (SLR_OPT_RECT_DMA_SHAPE): 0 = 256x16 / 512 threads, 1 = 256x8 / 512, 2 = 256x8 / 256, 3 = 128x16 / 512, 4 = 128x8 / 256,
+// 5 = 256x4 / 256, 6 = 128x16 / 256
+constexpr int kDmaShapes = 7;
+static int dma_shape_tw(int shape) { return shape == 3 || shape == 4 || shape == 6 ? 128 : 256; }
+static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape == 6 ? 16 : shape == 5 ? 4 : 8; }
+#define SLR_DMA_SHAPE_SWITCH(shape, X)                  \
+    switch (shape) {                                    \
+    case 1:  X(256, 8, 512); break;                     \
+    case 2:  X(256, 8, 256); break;                     \
+    case 3:  X(128, 16, 512); break;                    \
+    case 4:  X(128, 8, 256); break;                     \
+    case 5:  X(256, 4, 256); break;                     \
+    case 6:  X(128, 16, 256); break;                    \
+    default: X(256, 16, 512); break;                    \
+    }
+
+// map digest, one dword per destination pixel, [tile][thread][pass] (a thread's PX entries are contiguous):
+//   [12:2]  dword index of the tap's upper left byte in a plane's LDS image: (sy - y0) * (CMAX * 4) + ((sx - x0) >> 2)
+//   [14:13] (sx - x0) & 3
+//   [31:16] 4 * (fy << 5 | fx)  (cv::remap's 5-bit fractions: the byte offset of the pixel's entry in the weight tables), or
+//           4 * 1024: the sample is 0 (pixel beyond the ragged image edge, or footprint completely outside the source)
+// box table: int4 per tile = x0 (multiple of 16, may be negative), y0, chunks per row, rows; z == 0: nothing to fetch
+constexpr unsigned kDmaZeroEntry = 1024u << 18;
+template <int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                       int W, int H, int tiles_x, int4 *__restrict__ boxes,
+                                                       unsigned *__restrict__ digest, unsigned *__restrict__ nofit)
+{
+    typedef DmaGeom<TW, TH, NT> Gm;
+    __shared__ int red[Gm::NWAVES][4];
+    __shared__ int sbox[3];
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int sxs[Gm::PX], sys[Gm::PX];
+    unsigned frs[Gm::PX];
+    int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+#pragma unroll
+    for (int q = 0; q < Gm::PX; q++) {
+        const int row = ty * TH + q * Gm::RPP + wv / Gm::WPR, col = tx * TW + (wv % Gm::WPR) * 64 + lane;
+        sxs[q] = 0x7FFFFFFF; sys[q] = 0; frs[q] = 0;
+        if (row < H && col < W) {
+            const size_t m = (size_t)row * W + col;
+            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+            if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {       // footprints completely outside read 0
+                sxs[q] = sx; sys[q] = sy; frs[q] = map_frac[m] & 1023u;
+                mnx = sx < mnx ? sx : mnx; mxx = sx > mxx ? sx : mxx;
+                mny = sy < mny ? sy : mny; mxy = sy > mxy ? sy : mxy;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        int t;
+        t = __shfl_xor(mnx, d); mnx = t < mnx ? t : mnx;
+        t = __shfl_xor(mxx, d); mxx = t > mxx ? t : mxx;
+        t = __shfl_xor(mny, d); mny = t < mny ? t : mny;
+        t = __shfl_xor(mxy, d); mxy = t > mxy ? t : mxy;
+    }
+    if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < Gm::NWAVES; w++) {
+            mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
+            mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+        }
+        int4 b = make_int4(0, 0, 0, 0);
+        int fits = 1;
+        if (mnx <= mxx) {
+            b.x = mnx & ~15;                                 // 16-byte aligned origin (also for negative x)
+            b.y = mny;
+            b.z = (((mxx + 1) - b.x) >> 4) + 1;              // chunks covering x0 .. mxx+1
+            b.w = (mxy + 1) - mny + 1;                       // rows y0 .. mxy+1
+            fits = b.z <= Gm::CMAX && b.w <= Gm::BHMAX;
+            if (!fits) atomicAdd(nofit, 1u);
+        }
+        boxes[blockIdx.x] = b;
+        sbox[0] = b.x; sbox[1] = b.y; sbox[2] = fits;
+    }
+    __syncthreads();
+    const int x0 = sbox[0], y0 = sbox[1], fits = sbox[2];
+#pragma unroll
+    for (int q = 0; q < Gm::PX; q++) {
+        unsigned e = kDmaZeroEntry;
+        if (fits && sxs[q] != 0x7FFFFFFF) {
+            const int bx = sxs[q] - x0, r0 = sys[q] - y0;
+            e = (unsigned)(r0 * (Gm::CMAX * 4) + (bx >> 2)) << 2 | ((unsigned)bx & 3u) << 13 | frs[q] << 18;
+        }
+        digest[(size_t)blockIdx.x * (TW * TH) + threadIdx.x * Gm::PX + q] = e;
+    }
+}
+
+static size_t dma_tile_count(int W, int H, int shape)
+{
+    const int tw = dma_shape_tw(shape), th = dma_shape_th(shape);
+    return (size_t)((W + tw - 1) / tw) * ((H + th - 1) / th);
+}
+static size_t dma_digest_offset(int W, int H, int shape) { return (dma_tile_count(W, H, shape) * sizeof(int4) + 255) & ~(size_t)255; }
+static size_t dma_nofit_offset(int W, int H, int shape)
+{
+    return dma_digest_offset(W, H, shape) + dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+}
+size_t dma_tiles_bytes(int W, int H, int shape) { return dma_nofit_offset(W, H, shape) + 256; }
+
+hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
+                            unsigned *nofit_host, hipStream_t s)
+{
+    char *b = reinterpret_cast<char *>(buf);
+    int4 *boxes = reinterpret_cast<int4 *>(b);
+    unsigned *digest = reinterpret_cast<unsigned *>(b + dma_digest_offset(W, H, shape));
+    unsigned *nofit = reinterpret_cast<unsigned *>(b + dma_nofit_offset(W, H, shape));
+    hipError_t e = hipMemsetAsync(nofit, 0, 16, s);
+    if (e != hipSuccess) return e;
+    const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
+    const dim3 grid((unsigned)dma_tile_count(W, H, shape));
+#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit)
+    SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
+#undef SLR_DMA_X
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(nofit_host, nofit, sizeof(unsigned), hipMemcpyDeviceToHost, s);   // the caller synchronises the stream
+}
+
+// ------------------------------------------------------------------------------------------------------
+// the decode kernel
+// ------------------------------------------------------------------------------------------------------
+struct DmaJob {
+    const uint8_t *base;         // plane 0; plane p is base + p * pstride
+    unsigned pstride;
+    unsigned stack_bytes;        // 13 * pstride + H * pitch
+    const int4 *boxes;
+    const unsigned *digest;
+    unsigned digest_bytes;
+    float *phase;
+    uint8_t *valid;              // null: the flag is folded into the phase (NaN), see launch_mf_decode
+};
+struct DmaJobs { DmaJob j[2]; };
+
+// LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] = buffer[voff + soff .. + 15] (zeros beyond the descriptor's range).
+// M0 carries the LDS base and is compiler-reserved: saved and restored inside the one statement that uses it.
+__device__ __forceinline__ void dma16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned soff)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+// planes of phase p: (white, black), then per frequency c (G1, G3) -> d and (G2, G4) -> n   (plane 4c + 2 + s holds G(s+1))
+__device__ __host__ constexpr int dma_phase_plane(int p, int g)
+{
+    return p == 0 ? g : 2 + 4 * ((p - 1) >> 1) + ((p - 1) & 1) + 2 * g;
+}
+
+struct DmaTap {                          // per-pixel tap state, shared by all planes
+    unsigned a0;                         // LDS address of the dword holding the upper left tap in the plane image at offset 0
+    unsigned sel;                        // v_perm selector: bytes (sh, 0, sh+1, 0) -> u16 pair of the two taps
+    u16x2 w0, w1;                        // wx0*wy0, wx1*wy0 | wx0*wy1, wx1*wy1, times 64 (see tile_taps_map in kernels_decode.hip)
+};
+
+// the 16-bit blend weights of a (fx, fy) fraction pair -- what tile_taps_packed (kernels_decode.hip) computes per pixel; here
+// they come from a 1025-entry LDS table indexed by the digest (entry 1024 = zero weights: the sample is 0)
+__device__ __forceinline__ void dma_weights(unsigned i, unsigned &w0, unsigned &w1)
+{
+    const unsigned fx = i & 31u, fy6 = (i >> 5) << 6;                      // fy << 6
+    const unsigned wxp = i >= 1024u ? 0u : __umul24(fx, 0xFFFFu) + 32u;    // (32 - fx) | fx << 16
+    w0 = __umul24(wxp, 2048u - fy6);
+    w1 = __umul24(wxp, fy6);
+    w0 = w0 == 0x10000u ? 0xFFFFu : w0;                                   // fx = fy = 0: (S*65535 + 32768) >> 16 == S
+}
+
+// The taps of one pixel in the two planes of a phase: 8 dwords (plane 0: row 0 dwords c, c+1, row 1 dwords c, c+1; plane 1
+// the same).  hipcc would fold these loads into ds_read2_b32 behind a v_add per plane image (8-bit offsets) and wait for each
+// one; here they are ds_read_b32 with 16-bit immediate offsets from ONE address register, issued a pixel ahead of their use
+// and retired by a counted lgkmcnt (LDS operations return in order; anything the compiler interleaves only makes the count
+// stricter).  A 4-byte-aligned ds_read_b64 is NOT a fast path when the lanes' alignments differ (profiles/r02/exp_ldspat.txt:
+// 64 instead of 3 clocks per wave instruction), 2 x ds_read_b32 costs 4.9.
+struct DmaRd { unsigned v[8]; };
+
+template <unsigned IMG0, unsigned IMG1, unsigned RS>
+__device__ __forceinline__ void dma_rd(DmaRd &r, unsigned addr)
+{
+    asm volatile("ds_read_b32 %0, %8 offset:%9\n\t"
+                 "ds_read_b32 %1, %8 offset:%10\n\t"
+                 "ds_read_b32 %2, %8 offset:%11\n\t"
+                 "ds_read_b32 %3, %8 offset:%12\n\t"
+                 "ds_read_b32 %4, %8 offset:%13\n\t"
+                 "ds_read_b32 %5, %8 offset:%14\n\t"
+                 "ds_read_b32 %6, %8 offset:%15\n\t"
+                 "ds_read_b32 %7, %8 offset:%16"
+                 : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7])
+                 : "v"(addr), "n"(IMG0), "n"(IMG0 + 4), "n"(IMG0 + RS), "n"(IMG0 + RS + 4), "n"(IMG1), "n"(IMG1 + 4), "n"(IMG1 + RS),
+                   "n"(IMG1 + RS + 4)
+                 : "memory");
+}
+// at most N LDS operations issued after r's loads may still be outstanding
+template <int N>
+__device__ __forceinline__ void dma_rd_wait(DmaRd &r)
+{
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(r.v[0]), "+v"(r.v[1]), "+v"(r.v[2]), "+v"(r.v[3]), "+v"(r.v[4]), "+v"(r.v[5]), "+v"(r.v[6]), "+v"(r.v[7])
+                 : "n"(N) : "memory");
+}
+// blended sample of plane g of a phase: the sample is the HIGH half-word of the result (see tile_sample, kernels_decode.hip)
+__device__ __forceinline__ unsigned dma_blend(const DmaRd &r, int g, const DmaTap &k)
+{
+    const unsigned p0 = __builtin_amdgcn_perm(r.v[4 * g + 1], r.v[4 * g], k.sel);
+    const unsigned p1 = __builtin_amdgcn_perm(r.v[4 * g + 3], r.v[4 * g + 2], k.sel);
+    unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), k.w0, 512u << 6, false);
+    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), k.w1, acc, false);
+    return acc;
+}
+
+// LDS-DMA operations a wave issues per tile, in program order (the static sequence the counted waits rely on):
+//   start of phase p:  [p == 1: PX/4 digest DMAs of the next tile]  2 plane DMAs of phase p + A
+// The wait at the top of phase p lets everything issued after the plane DMAs of phase p itself stay in flight.  Only DMAs
+// are counted: LDS-DMA and ordinary vector-memory operations are NOT retired in order relative to each other (a count that
+// included the output stores let the wait pass with the DMA still pending -- found the hard way), so the stores of a tile
+// are issued at the start of the NEXT tile's phase 0, a whole phase before the following wait, and a wave that still has
+// one of them outstanding there merely waits a little longer.
+template <int PX, int A>
+__device__ __host__ constexpr int dma_wait_count(int p)
+{
+    int n = 0;
+    for (int j = 1; j < A; j++) { const int ph = ((p - A + j) % 7 + 7) % 7; n += 2 + (ph == 1 ? PX / 4 : 0); }
+    return n;
+}
+
+template <int TW, int TH, int NT, int A, bool HASVALID>
+struct DmaDecode {
+    typedef DmaGeom<TW, TH, NT> Gm;
+    static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS, D = A + 1;
+    // dynamic LDS (the kernel has no static LDS, so it starts at LDS address 0 and the tap addresses are 13-bit ORs):
+    // D buffers of 2 plane images | digest of the tile | weight table | decode tables (slr_create's, kLutWords)
+    // (waves beyond a plane image's chunks issue their DMAs all the same -- the counted waits need one sequence for every
+    // wave -- with an out-of-range source into a 1 KiB scratch slot)
+    static constexpr int SCRATCH_OFF = D * 2 * PS, DIG_OFF = SCRATCH_OFF + (Gm::NCH < NT ? 1024 : 0), DIG_BYTES = TW * TH * 4;
+    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4, WT_BYTES = 2 * 1026 * 4;   // two tables: w0[1025], w1[1025]
+    static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
+    static constexpr int LDS_BYTES = LUT_OFF + (kLutWords + 1) * 4;
+    static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
+    static constexpr int kSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
+
+    const uint8_t *smem;
+    const float *lut;
+    unsigned lds0, wave_off;
+    bool plane_wave;                     // this wave owns chunks of the plane images (wave-uniform)
+    __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_phase, rs_valid;
+    unsigned pstride;
+    int W, H, black_thr;
+    // per-tile state
+    DmaTap tap[PX];
+    // validity.  HASVALID: bit q of ok = pixel q passed the shadow mask and every (n | d) != 0 so far, bit 16 + q = the mask
+    // alone.  Folded mode (the flag travels in the phase as a NaN): pm[q] = max over "masked out ? sentinel : INT_MIN" and
+    // the wrapped phases so far -- the table returns the sentinel for the undefined case -- so one compare decides at the end.
+    unsigned ok;
+    int pm[PX];
+    int dd[PX];                          // d of the frequency in flight
+    int Pk[PX];                          // wrapped phase kept for the next heterodyne step
+    float F12[PX];
+    // results of the previous tile, stored at the start of the next phase 0 (see dma_wait_count)
+    float outv[PX];
+    unsigned out_ok;
+    int out_ty, out_tx;
+    bool out_pending;
+
+    __device__ __forceinline__ void flush() const
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int row0 = out_ty * TH + wv / Gm::WPR, col = out_tx * TW + (wv % Gm::WPR) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < PX; q++) {
+            const int row = row0 + q * Gm::RPP;
+            const bool inb = row < H && col < W;
+            const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+            if constexpr (HASVALID)
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((out_ok >> q) & 1u), rs_valid, inb ? m : kDmaInvalid, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, outv[q]), rs_phase, inb ? m * 4u : kDmaInvalid, 0, 2);
+        }
+    }
+
+    __device__ __forceinline__ void issue_planes(int p, int buf, unsigned voff) const
+    {
+#if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 1 || SLR_DMA_ABL == 6)
+        voff = kDmaInvalid;              // ablation: no source traffic (the DMA instructions still issue and zero-fill)
+#endif
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+            dma16(voff, rs_stack, plane_wave ? lds0 + (unsigned)((buf * 2 + g) * PS) + wave_off : lds0 + (unsigned)SCRATCH_OFF,
+                  (unsigned)dma_phase_plane(p, g) * pstride);
+    }
+    __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
+    {
+#pragma unroll
+        for (int r = 0; r < PX / 4; r++) {
+            const unsigned voff = live ? tile * (unsigned)DIG_BYTES + (threadIdx.x + (unsigned)(NT * r)) * 16u : kDmaInvalid;
+            dma16(voff, rs_dig, lds0 + (unsigned)(DIG_OFF + r * NT * 16) + wave_off, 0u);
+        }
+    }
+
+    // the wrapped phases' difference as the f32 image of the 2^24-scaled integers (het_pair_q24 with wrapping arithmetic: a
+    // sentinel operand must not be undefined behaviour, its result is discarded)
+    static __device__ __forceinline__ float pair_q24(int Pa, int Pb)
+    {
+        return (float)(int)(((unsigned)Pa - (unsigned)Pb) + ((Pa > Pb) ? 0u : (unsigned)kQ24TwoPI));
+    }
+    // het_finish_q24 with the 2^-24 scaling moved behind the division: every step is the same rounding of the same real
+    // number (power-of-two scalings are exact, 255 * 2^-24 is a float)
+    static __device__ __forceinline__ float finish_q24(float Fa, float Fb)
+    {
+        constexpr float two_pi_q24 = kTwoPI * 16777216.0f;
+        const float F123 = (Fa > Fb) ? (Fa - Fb) : (Fa - Fb + two_pi_q24);
+        constexpr float rc = 1.0f / kTwoPI;
+        const float q = F123 * rc;
+        const float r = __builtin_fmaf(-q, kTwoPI, F123);
+        return __builtin_fmaf(r, rc, q) * (255.0f / 16777216.0f);
+    }
+
+    // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur / voff_next: this thread's chunk of the current / next
+    // tile's box.
+    template <int K0, int P>
+    __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    {
+        wait_vm<dma_wait_count<PX, A>(P)>();
+#if !defined(SLR_DMA_ABL) || SLR_DMA_ABL != 3
+        asm volatile("s_barrier" ::: "memory");
+#endif
+        if (P == 1) issue_digest(next_tile, has_next);
+        issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? voff_next : voff_cur);
+        if constexpr (P == 0) {
+            if (out_pending) flush();
+        }
+        constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
+        if constexpr (P == 0) {                                    // tap state of the tile's pixels from the digest
+            const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
+#pragma unroll
+            for (int q = 0; q < PX; q++) {
+                const unsigned e = dg[q];
+                const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e >> 16));
+                tap[q].a0 = (e & 0x1FFCu) | lds0;
+                tap[q].sel = __umul24((e >> 13) & 3u, 0x10001u) + 0x0C010C00u;
+                tap[q].w0 = __builtin_bit_cast(u16x2, wt[WT_OFF / 4]);
+                tap[q].w1 = __builtin_bit_cast(u16x2, wt[WT1_OFF / 4]);
+            }
+            ok = 0;
+        }
+        // sd[q] = sample of the phase's first plane minus its second plane (white - black, G1 - G3, G2 - G4), reads one pixel ahead
+        int sd[PX];
+#if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 2 || SLR_DMA_ABL == 6)
+#pragma unroll
+        for (int q = 0; q < PX; q++) {   // ablation: no LDS tap reads (the blend runs on register junk)
+            DmaRd r;
+#pragma unroll
+            for (int i = 0; i < 8; i++) r.v[i] = tap[q].a0 * (unsigned)(i + 3 + P);
+            sd[q] = (int)(dma_blend(r, 0, tap[q]) >> 16) - (int)(dma_blend(r, 1, tap[q]) >> 16);
+        }
+#elif defined(SLR_DMA_ABL) && SLR_DMA_ABL == 4
+#pragma unroll
+        for (int q = 0; q < PX; q++) sd[q] = (int)tap[q].a0 + P;   // ablation: neither reads nor blend
+#elif defined(SLR_DMA_ABL) && SLR_DMA_ABL == 5
+        DmaRd r[2];
+        dma_rd<img0, img1, (unsigned)RS>(r[0], tap[0].a0);
+#pragma unroll
+        for (int q = 0; q < PX; q++) {   // ablation: the reads, but no blend
+            if (q + 1 < PX) { dma_rd<img0, img1, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
+            else dma_rd_wait<0>(r[q & 1]);
+            sd[q] = (int)(r[q & 1].v[0] ^ r[q & 1].v[1] ^ r[q & 1].v[2] ^ r[q & 1].v[3] ^ r[q & 1].v[4] ^ r[q & 1].v[5] ^ r[q & 1].v[6] ^ r[q & 1].v[7]) & 255;
+        }
+#else
+        DmaRd r[2];
+        dma_rd<img0, img1, (unsigned)RS>(r[0], tap[0].a0);
+#pragma unroll
+        for (int q = 0; q < PX; q++) {
+            if (q + 1 < PX) { dma_rd<img0, img1, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
+            else dma_rd_wait<0>(r[q & 1]);
+            sd[q] = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
+        }
+#endif
+        if constexpr (P == 0) {
+#pragma unroll
+            for (int q = 0; q < PX; q++) {                         // computeShadows :198-204
+                if constexpr (HASVALID) ok |= (sd[q] > black_thr ? 0x10001u : 0u) << q;
+                else pm[q] = sd[q] > black_thr ? (int)0x80000000 : kSentinel;
+            }
+        } else if constexpr ((P & 1) != 0) {
+#pragma unroll
+            for (int q = 0; q < PX; q++) dd[q] = sd[q];            // d = G1 - G3
+        } else {
+#pragma unroll
+            for (int q = 0; q < PX; q++) {
+                int nz;
+                const int Pw = wrapped_nd_q24(-sd[q], dd[q], lut, nz);   // n = G4 - G2
+                if constexpr (HASVALID) { if (nz == 0) ok &= ~(1u << q); }  // Q5 rule: an undefined P makes the pixel invalid
+                if constexpr (P == 2) { Pk[q] = Pw; if constexpr (!HASVALID) pm[q] = pm[q] > Pw ? pm[q] : Pw; }
+                else if constexpr (P == 4) { F12[q] = pair_q24(Pk[q], Pw); Pk[q] = Pw; if constexpr (!HASVALID) pm[q] = pm[q] > Pw ? pm[q] : Pw; }
+                else {
+                    const float ph = finish_q24(F12[q], pair_q24(Pk[q], Pw));
+                    if constexpr (HASVALID) {
+                        // as mf_pixel_sh: the mask alone decides between the computed phase and 0
+                        outv[q] = ((ok >> (q + 16)) & 1u) ? ph : 0.0f;
+                    } else {
+                        const int m3 = pm[q] > Pw ? pm[q] : Pw;
+                        outv[q] = m3 != kSentinel ? ph : kInvalidPhase;    // folded flag
+                    }
+                }
+            }
+            if constexpr (P == 6) { out_ok = ok; out_ty = ty; out_tx = tx; out_pending = true; }
+        }
+    }
+
+    template <int K0>
+    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    {
+        const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
+        phase<K0, 0>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 1>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 2>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 3>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 4>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 5>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 6>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+    }
+};
+
+// resident workgroups per CU that the LDS allows -> waves per SIMD the register allocation should aim for
+template <int LDS_BYTES, int NT>
+constexpr int dma_waves_per_simd()
+{
+    constexpr int wgs = 160 * 1024 / LDS_BYTES, w = wgs * NT / 256;
+    return w > 8 ? 8 : w < 1 ? 1 : w;
+}
+
+template <int TW, int TH, int NT, int A, bool HASVALID>
+__global__ __launch_bounds__(NT, (dma_waves_per_simd<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
+void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
+                               int tiles_x, int tiles_y)
+{
+    typedef DmaDecode<TW, TH, NT, A, HASVALID> Dec;
+    typedef DmaGeom<TW, TH, NT> Gm;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Dec d;
+    d.smem = smem;
+    d.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    if (d.lds0 & 0x1FFFu) __builtin_trap();                 // the tap addresses OR the buffer base in (no static LDS here: 0)
+    float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
+    d.lut = lut;
+    for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
+    for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
+        unsigned w0, w1;
+        dma_weights(i, w0, w1);
+        *reinterpret_cast<unsigned *>(smem + Dec::WT_OFF + 4u * i) = w0;
+        *reinterpret_cast<unsigned *>(smem + Dec::WT1_OFF + 4u * i) = w1;
+    }
+    __syncthreads();
+    if (!HASVALID && threadIdx.x == 0)                      // the undefined wrapped phase (n == d == 0: lutR -> S = 9, s = 0, sgn 0)
+        reinterpret_cast<int *>(lut)[kLutP + (9 << 8)] = Dec::kSentinel;
+    __syncthreads();
+    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
+    const bool second = blockIdx.x >= nblk;
+    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
+    const int ji = second ? 1 : 0;
+    const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
+    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
+    if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
+
+    d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
+    d.plane_wave = d.wave_off < (unsigned)Dec::PS;
+    d.pstride = jobs.j[ji].pstride;
+    d.W = W; d.H = H; d.black_thr = black_thr;
+    d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
+    d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
+    d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, (int)((unsigned)W * (unsigned)H * 4u), 0x00020000);
+    d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, HASVALID ? (int)((unsigned)W * (unsigned)H) : 0, 0x00020000);
+    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
+
+    // this thread's chunk of a box: row crow, 16-byte column ccol
+    const int crow = (int)threadIdx.x / Gm::CMAX, ccol = (int)threadIdx.x - crow * Gm::CMAX;
+    auto box_voff = [&](const int4 b) -> unsigned {
+        const int gx = b.x + 16 * ccol, gy = b.y + crow;
+        const bool in = (int)threadIdx.x < Gm::NCH && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
+    };
+
+    int cur = xcd * per + lb;
+    unsigned voff_cur = box_voff(boxes[cur]);
+    // prologue = what the last phases of a previous tile would have issued: digest, plane DMAs of phases 0 .. A-1
+    d.out_pending = false;
+    d.ok = 0;
+    d.issue_digest((unsigned)cur, true);
+#pragma unroll
+    for (int a = 0; a < A; a++) d.issue_planes(a, a % Dec::D, voff_cur);
+
+    int it = 1;
+    for (;;) {
+        // the phase-0 buffer index advances by 7 mod D from tile to tile: D tiles per round of this loop
+#define SLR_DMA_TILE(K0)                                                                                       \
+        {                                                                                                      \
+            const int nl = lb + it * nbx;                                                                      \
+            const bool has_next = nl < per && xcd * per + nl < T;                                              \
+            const int nxt = has_next ? xcd * per + nl : cur;                                                   \
+            const unsigned voff_next = has_next ? box_voff(boxes[nxt]) : kDmaInvalid;                          \
+            d.template tile<K0>(cur, tiles_x, voff_cur, voff_next, (unsigned)nxt, has_next);                   \
+            if (!has_next) break;                                                                              \
+            cur = nxt; voff_cur = voff_next; it++;                                                             \
+        }
+        SLR_DMA_TILE(0)
+        SLR_DMA_TILE(7 % Dec::D)
+        if constexpr (Dec::D >= 3) SLR_DMA_TILE(14 % Dec::D)
+        if constexpr (Dec::D >= 4) SLR_DMA_TILE(21 % Dec::D)
+#undef SLR_DMA_TILE
+    }
+    d.flush();
+    wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
+}
+
+// the stack layout this form needs: 14 planes equally spaced in one allocation (buffer addressing: plane = scalar offset),
+// 16-byte aligned rows, W a multiple of 16 (a chunk is completely inside or completely outside the image)
+static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, uint8_t *valid, const void *tiles, int shape, DmaJob &j)
+{
+    if (!tiles || W % 16 != 0 || pitch % 16 != 0 || ((uintptr_t)pl.p[0] % 16) != 0 || ((uintptr_t)phase % 4) != 0) return false;
+    const long long st = (long long)(pl.p[1] - pl.p[0]);
+    if (st < (long long)H * pitch || st % 16 != 0) return false;
+    for (int i = 2; i < SLR_MF_PLANES; i++) if ((long long)(pl.p[i] - pl.p[0]) != st * i) return false;
+    const long long bytes = st * (SLR_MF_PLANES - 1) + (long long)H * pitch;
+    if (bytes >= (1ll << 31) || (long long)W * H * 4 >= (1ll << 31)) return false;
+    const char *b = reinterpret_cast<const char *>(tiles);
+    j.base = pl.p[0]; j.pstride = (unsigned)st; j.stack_bytes = (unsigned)bytes;
+    j.boxes = reinterpret_cast<const int4 *>(b);
+    j.digest = reinterpret_cast<const unsigned *>(b + dma_digest_offset(W, H, shape));
+    const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+    if (dg >= (1ull << 31)) return false;
+    j.digest_bytes = (unsigned)dg;
+    j.phase = phase; j.valid = valid;
+    return true;
+}
+
+template <int TW, int TH, int NT, int A, bool HV>
+static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, const float *lut, hipStream_t s)
+{
+    typedef DmaDecode<TW, TH, NT, A, HV> Dec;
+    auto kern = mf_rect_decode_dma_kernel<TW, TH, NT, A, HV>;
+    static int resident[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &res = resident[dev & 63];
+    if (!res) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        res = per_cu * cus;
+    }
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int T = tiles_x * tiles_y, per = (T + 7) / 8;
+    const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
+    const int r = (dbg && atoi(dbg) > 0 ? atoi(dbg) : res) / njobs;
+    int nbx = r / 8 < per ? r / 8 : per;
+    if (nbx < 1) nbx = 1;
+    SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, lut,
+               tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// one camera (n == 1) or both cameras of a stereo frame (n == 2) in one launch.  *done = false: this form does not apply
+// (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
+hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
+                                     float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
+                                     bool *done, hipStream_t s)
+{
+    *done = false;
+    if (shape < 0 || shape >= kDmaShapes) return hipSuccess;
+    DmaJobs j;
+    for (int c = 0; c < n; c++)
+        if (!dma_job(pl[c], pitch, W, H, phase[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
+    if (n == 1) j.j[1] = j.j[0];
+    const bool hv = valid[0] != nullptr;
+    for (int c = 1; c < n; c++) if ((valid[c] != nullptr) != hv) return hipSuccess;
+    *done = true;
+    hipError_t e = hipSuccess;
+#define SLR_DMA_X(TW, TH, NT)                                                                                          \
+    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, 2, true>(j, n, pitch, W, H, black_thr, lut, s)              \
+                         : launch_dma_variant<TW, TH, NT, 2, false>(j, n, pitch, W, H, black_thr, lut, s))            \
+                   : (hv ? launch_dma_variant<TW, TH, NT, 1, true>(j, n, pitch, W, H, black_thr, lut, s)              \
+                         : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, s))
+    SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
+#undef SLR_DMA_X
+    return e;
+}
+
+}  // namespace slr

@@ -52,6 +52,10 @@ struct slr_ctx {
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
     unsigned tile_nofit[2][2] = {};             // per camera: tiles that do not fit the 64x8 / the 128x8 fused-decode form
+    void *d_dma_tiles[2] = {nullptr, nullptr};  // boxes + map digest of the LDS-DMA fused decode (launch_dma_tiles), or null
+    unsigned dma_nofit[2] = {0, 0};             // tiles whose box does not fit that form
+    int dma_shape_built[2] = {-1, -1};          // SLR_OPT_RECT_DMA_SHAPE the tables were built for
+    int opt_dma_shape = 1, opt_dma_depth = 1;   // SLR_OPT_RECT_DMA_SHAPE / _DEPTH (256x8 tiles on 512 threads measured best)
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
@@ -89,7 +93,7 @@ int fail(slr_ctx *c, int code, const char *what, const char *detail = nullptr)
 // form (5) unless more of these maps' pixels would fall back to the per-pixel gather there than in the 64x8 form (6)
 int mf_rect_algo(const slr_ctx *c, int a, int b)
 {
-    if (c->opt_rect_algo != 0) return c->opt_rect_algo;
+    if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return c->opt_rect_algo;
     unsigned mid = 0, wide = 0;
     for (int cam = a; cam <= b; cam++) { mid += c->tile_nofit[cam][0]; wide += c->tile_nofit[cam][1]; }
     return 2u * wide <= mid ? 5 : 6;
@@ -106,6 +110,15 @@ int mf_rect_algo(const slr_ctx *c, int a, int b)
         int s__ = (expr);            \
         if (s__ != SLR_OK) return s__; \
     } while (0)
+
+// the LDS-DMA form (7) is used when it is asked for or auto is on, and the installed maps fit it
+bool dma_form_wanted(const slr_ctx *c, int a, int b)
+{
+    if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return false;
+    for (int cam = a; cam <= b; cam++)
+        if (!c->d_dma_tiles[cam] || c->dma_nofit[cam] != 0 || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
+    return true;
+}
 
 int use_device(slr_ctx *c)
 {
@@ -268,6 +281,18 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
     MfPlanes mp;
     for (int i = 0; i < SLR_MF_PLANES; i++) mp.p[i] = pl[i];
     ProfScope ps(c, rectify ? K_MF_RECT_DECODE : K_MF_DECODE, true);
+    if (rectify && dma_form_wanted(c, cam, cam)) {
+        bool done = false;
+        float *const ph[1] = {phase};
+        uint8_t *const vd[1] = {valid};
+        const void *const tl[1] = {c->d_dma_tiles[cam]};
+        SLR_HIP(c, launch_mf_rect_decode_dma(&mp, 1, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
+                                             &done, c->stream));
+        if (done) return SLR_OK;
+    }
+    if (rectify && c->opt_rect_algo == 7)
+        return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_RECT_DECODE_ALGO = 7 (LDS-DMA form) does not apply: it needs 14 equally spaced planes in one "
+                                            "allocation, 16-byte aligned rows, W % 16 == 0 and maps whose tile boxes fit");
     SLR_HIP(c, launch_mf_decode(mp, pitch, W, H, black_thr, c->d_lut, phase, valid,
                                 rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
                                 rectify ? c->d_tile_box[cam] : nullptr, c->opt_mf_decode_vec, mf_rect_algo(c, cam, cam), c->stream));
@@ -445,7 +470,7 @@ int slr_destroy(slr_ctx *c)
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     for (int i = 0; i < S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); }
+    for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); if (c->d_dma_tiles[k]) (void)hipFree(c->d_dma_tiles[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -517,6 +542,7 @@ static int map_storage(slr_ctx *c, int cam, int W, int H)
             if (c->d_map_xy[k]) { SLR_HIP(c, hipFree(c->d_map_xy[k])); c->d_map_xy[k] = nullptr; }
             if (c->d_map_frac[k]) { SLR_HIP(c, hipFree(c->d_map_frac[k])); c->d_map_frac[k] = nullptr; }
             if (c->d_tile_box[k]) { SLR_HIP(c, hipFree(c->d_tile_box[k])); c->d_tile_box[k] = nullptr; }
+            if (c->d_dma_tiles[k]) { SLR_HIP(c, hipFree(c->d_dma_tiles[k])); c->d_dma_tiles[k] = nullptr; c->dma_shape_built[k] = -1; }
         }
         c->map_w = W; c->map_h = H;
     }
@@ -524,6 +550,24 @@ static int map_storage(slr_ctx *c, int cam, int W, int H)
     if (!c->d_map_xy[cam]) SLR_HIP(c, hipMalloc(&c->d_map_xy[cam], n * 4));
     if (!c->d_map_frac[cam]) SLR_HIP(c, hipMalloc(&c->d_map_frac[cam], n * 2));
     if (!c->d_tile_box[cam]) SLR_HIP(c, hipMalloc(&c->d_tile_box[cam], tile_boxes_bytes(W, H)));
+    return SLR_OK;
+}
+
+// tile tables of the LDS-DMA fused decode for the maps of `cam` (enqueued; the caller synchronises the stream)
+static int build_dma_tiles(slr_ctx *c, int cam)
+{
+    const int W = c->map_w, H = c->map_h;
+    if (c->d_dma_tiles[cam] && c->dma_shape_built[cam] != c->opt_dma_shape) {
+        SLR_HIP(c, hipStreamSynchronize(c->stream));
+        SLR_HIP(c, hipFree(c->d_dma_tiles[cam]));
+        c->d_dma_tiles[cam] = nullptr;
+    }
+    c->dma_shape_built[cam] = -1;
+    if (W % 16 != 0) return SLR_OK;                         // the form needs whole 16-byte chunks per row
+    if (!c->d_dma_tiles[cam]) SLR_HIP(c, hipMalloc(&c->d_dma_tiles[cam], dma_tiles_bytes(W, H, c->opt_dma_shape)));
+    SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape,
+                                &c->dma_nofit[cam], c->stream));
+    c->dma_shape_built[cam] = c->opt_dma_shape;
     return SLR_OK;
 }
 
@@ -537,6 +581,7 @@ int slr_set_rectify_maps(slr_ctx *c, int cam, const int16_t *map_xy, const uint1
     SLR_HIP(c, hipMemcpyAsync(c->d_map_xy[cam], map_xy, n * 4, kind, c->stream));
     SLR_HIP(c, hipMemcpyAsync(c->d_map_frac[cam], map_frac, n * 2, kind, c->stream));
     SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->tile_nofit[cam], c->stream));
+    SLR_TRY(build_dma_tiles(c, cam));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }
@@ -548,6 +593,7 @@ int slr_init_rectify_maps(slr_ctx *c, int cam, const double M[9], const double D
     SLR_TRY(map_storage(c, cam, W, H));
     SLR_HIP(c, launch_init_rectify_map(M, D, R, P, W, H, c->d_map_xy[cam], c->d_map_frac[cam], c->stream));
     SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->tile_nofit[cam], c->stream));
+    SLR_TRY(build_dma_tiles(c, cam));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     return SLR_OK;
 }
@@ -829,6 +875,12 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
         const uint16_t *const mfr[2] = {c->d_map_frac[0], c->d_map_frac[1]};
         const void *const box[2] = {c->d_tile_box[0], c->d_tile_box[1]};
         ProfScope ps(c, K_MF_RECT_DECODE_PAIR, true);
+        if (dma_form_wanted(c, 0, 1)) {
+            const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
+            SLR_HIP(c, launch_mf_rect_decode_dma(mp, 2, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
+                                                 &paired, c->stream));
+        }
+        if (!paired && c->opt_rect_algo != 7)
         SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, mf_rect_algo(c, 0, 1),
                                               &paired, c->stream));
     }
@@ -979,8 +1031,22 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->opt_mf_decode_vec = value;
             return SLR_OK;
         case SLR_OPT_RECT_DECODE_ALGO:
-            if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..6");
+            if (value < 0 || value > 7) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..7");
             c->opt_rect_algo = value;
+            return SLR_OK;
+        case SLR_OPT_RECT_DMA_SHAPE:
+            if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_SHAPE must be 0..6");
+            if (value != c->opt_dma_shape) {
+                c->opt_dma_shape = value;
+                SLR_TRY(use_device(c));
+                for (int cam = 0; cam < 2; cam++)
+                    if (c->d_map_xy[cam]) SLR_TRY(build_dma_tiles(c, cam));
+                SLR_HIP(c, hipStreamSynchronize(c->stream));
+            }
+            return SLR_OK;
+        case SLR_OPT_RECT_DMA_DEPTH:
+            if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_DEPTH must be 1 or 2");
+            c->opt_dma_depth = value;
             return SLR_OK;
         case SLR_OPT_PROFILE_STRIDE:
             if (value < 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_PROFILE_STRIDE must be >= 1");

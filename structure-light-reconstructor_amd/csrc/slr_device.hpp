@@ -85,6 +85,18 @@ size_t     tile_boxes_bytes(int W, int H);
 hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, unsigned nofit_host[2],
                              hipStream_t s);
 
+// LDS-DMA form of the fused rectify + multi-frequency decode (kernels_rectdma.hip).  shape: destination tile 0 = 256x16,
+// 1 = 256x8, 2 = 512x8, 3 = 128x16.  launch_dma_tiles builds the per-tile source boxes + the map digest of one shape into
+// `buf` (dma_tiles_bytes) and copies the number of tiles whose box does not fit the form to *nofit_host (valid after the
+// stream is synchronised).  launch_mf_rect_decode_dma: one camera (n == 1) or both cameras of a frame (n == 2) in one
+// launch; *done = false -> the stack layout / image width does not allow this form, nothing was launched.
+size_t     dma_tiles_bytes(int W, int H, int shape);
+hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
+                            unsigned *nofit_host, hipStream_t s);
+hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
+                                     float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
+                                     bool *done, hipStream_t s);
+
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,

@@ -38,9 +38,10 @@ def test_header_constants_match_the_binding(slr):
     defines = {k: int(v) for k, v in re.findall(r"#define\s+(SLR_[A-Z0-9_]+)\s+(-?\d+)\b", text)}
     enums = {k: int(v) for k, v in re.findall(r"\b(SLR_[A-Z_]+)\s*=\s*(-?\d+)", text)}
     cap = slr.capi
-    for name in ("MF_MATCH_ALGO", "MF_DECODE_VEC", "RECT_DECODE_ALGO", "ASYNC_HOST", "PROFILE_STRIDE"):
+    for name in ("MF_MATCH_ALGO", "MF_DECODE_VEC", "RECT_DECODE_ALGO", "ASYNC_HOST", "PROFILE_STRIDE", "RECT_DMA_SHAPE",
+                 "RECT_DMA_DEPTH"):
         assert defines["SLR_OPT_" + name] == getattr(cap, "OPT_" + name), name
-    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 6))   # no duplicate ids
+    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 8))   # no duplicate ids
     for name in ("OK", "ERR_INVALID_ARG", "ERR_NO_DEVICE", "ERR_HIP", "ERR_NOT_CONFIGURED", "ERR_UNSUPPORTED", "ERR_OOM"):
         assert enums["SLR_" + name] == getattr(cap, name), name
     assert (enums["SLR_MEM_HOST"], enums["SLR_MEM_DEVICE"]) == (cap.MEM_HOST, cap.MEM_DEVICE)

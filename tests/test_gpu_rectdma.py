@@ -1,0 +1,172 @@
+"""The LDS-DMA form of the fused rectify + multi-frequency decode (SLR_OPT_RECT_DECODE_ALGO = 7, kernels_rectdma.hip):
+every tile shape x DMA depth x (valid bytes | valid folded into the phase) against the oracle's cv::remap + getPhase, bit for
+bit -- smooth maps, maps that leave the image on every side (BORDER_CONSTANT), ragged sizes, many tiles per workgroup, the
+strictness of an explicit 7 and the fallback of auto."""
+import numpy as np
+import pytest
+import torch
+
+from util import bits_equal, np_of
+
+pytestmark = pytest.mark.gpu
+BLACK = 40
+SHAPES = tuple(range(7))         # 256x16/512 threads, 256x8/512, 256x8/256, 128x16/512, 128x8/256, 256x4/256, 128x16/256
+
+
+def _expect(oracle, raw, mx, mf):
+    rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+    return oracle.mf_decode(rect, BLACK)
+
+
+def _opts(ctx, slr, algo=7, shape=0, depth=1):
+    ctx.set_option(slr.capi.OPT_RECT_DMA_SHAPE, shape)
+    ctx.set_option(slr.capi.OPT_RECT_DMA_DEPTH, depth)
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+
+
+@pytest.fixture
+def dma_ctx(ctx, slr):
+    yield ctx
+    _opts(ctx, slr, 0, 1, 1)
+
+
+@pytest.mark.parametrize("W,H,strength", [(640, 480, 1.0), (1024, 100, 2.0), (4096, 40, 1.0), (400, 77, 2.0), (16, 5, 1.0),
+                                          (272, 33, 3.0)])
+def test_dma_form_every_shape_and_depth(dma_ctx, slr, oracle, synth, W, H, strength):
+    ctx = dma_ctx
+    st = synth.render_mf_stack(W, H, seed=W + H, noise=3)
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=strength)
+        mxn, mfn = mx.numpy(), mf.numpy()
+        raw = st[cam].numpy()
+        eph, ev = _expect(oracle, raw, mxn, mfn)
+        dev = st[cam].cuda()
+        ran = 0
+        for shape in SHAPES:
+            _opts(ctx, slr, 7, shape, 1)
+            ctx.set_rectify_maps(cam, mxn, mfn)
+            try:
+                for depth in (1, 2):
+                    ctx.set_option(slr.capi.OPT_RECT_DMA_DEPTH, depth)
+                    ph, v = ctx.mf_decode(dev, BLACK, rectify_cam=cam)          # device stack, separate valid bytes
+                    ctx.synchronize()
+                    assert bits_equal(np_of(v), ev) and bits_equal(np_of(ph), eph), (shape, depth)
+                ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)              # host planes staged by the library
+                assert bits_equal(v, ev) and bits_equal(ph, eph), shape
+                ran += 1
+            except slr.capi.SlrError as e:                                      # a strong map: some tile's box exceeds this shape
+                assert e.status == slr.capi.ERR_UNSUPPORTED and strength > 1.0, (shape, str(e))
+        assert ran >= 4, ran
+
+
+def test_dma_form_borders_on_every_side(dma_ctx, slr, oracle, synth):
+    """identity maps shifted far enough that footprints leave the source image left, right, above and below: everything
+    outside must read as 0 (BORDER_CONSTANT), partially outside footprints blend the zeros in"""
+    ctx = dma_ctx
+    W, H = 512, 64
+    st = synth.render_mf_stack(W, H, seed=5, noise=3)
+    raw = st[0].numpy() | 1                                                      # no zero samples: zeros can only come from the border
+    dev = torch.from_numpy(raw).cuda()
+    for dx, dy, fx, fy in [(-37, -9, 7, 19), (41, 11, 31, 31), (-1, 0, 0, 13), (0, -1, 30, 0), (700, 0, 3, 3), (0, 90, 1, 1),
+                           (-16, -16, 0, 0), (15, 3, 16, 16)]:
+        mx, mf = synth.identity_maps(W, H, dx=dx, dy=dy, fx=fx, fy=fy)
+        mxn, mfn = mx.numpy(), mf.numpy()
+        eph, ev = _expect(oracle, raw, mxn, mfn)
+        for shape in SHAPES:
+            _opts(ctx, slr, 7, shape, 1 + shape % 2)
+            ctx.set_rectify_maps(0, mxn, mfn)
+            ph, v = ctx.mf_decode(dev, BLACK, rectify_cam=0)
+            ctx.synchronize()
+            assert bits_equal(np_of(v), ev) and bits_equal(np_of(ph), eph), (dx, dy, shape)
+
+
+@pytest.mark.parametrize("resident", ["8", "16"])
+def test_dma_form_many_tiles_per_workgroup_and_whole_path(dma_ctx, slr, oracle, synth, monkeypatch, resident):
+    """few resident workgroups -> every workgroup walks many tiles (buffer rotation over tile boundaries, the dummy DMAs
+    behind the last tile); then the whole path (both cameras in one launch, valid folded into the phase as a NaN) against
+    the step-by-step oracle pipeline"""
+    from util import calib_parts
+    ctx = dma_ctx
+    monkeypatch.setenv("SLR_DEBUG_RECT_RESIDENT", resident)
+    W, H = 1280, 200
+    calib, _ = synth.make_calibration(W, H)
+    ctx.set_calibration(calib)
+    st = synth.render_mf_stack(W, H, seed=11, noise=2)
+    maps = [synth.make_rectify_maps(W, H, cam) for cam in range(2)]
+    exp = []
+    for cam in range(2):
+        exp.append(_expect(oracle, st[cam].numpy(), maps[cam][0].numpy(), maps[cam][1].numpy()))
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    exyz, ehas, _ = oracle.mf_triangulate(exp[0][0], exp[0][1], exp[1][0], exp[1][1], camL, camR, Q, T)
+    dev = st.cuda()
+    for shape in SHAPES:
+        for depth in (1, 2):
+            _opts(ctx, slr, 7, shape, depth)
+            for cam in range(2):
+                ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+            for cam in range(2):
+                ph, v = ctx.mf_decode(dev[cam], BLACK, rectify_cam=cam)
+                ctx.synchronize()
+                assert bits_equal(np_of(v), exp[cam][1]) and bits_equal(np_of(ph), exp[cam][0]), (shape, depth, cam)
+            xyz, has = ctx.reconstruct_mf(dev[0], dev[1], BLACK, True)
+            ctx.synchronize()
+            assert bits_equal(np_of(has), ehas) and bits_equal(np_of(xyz), exyz), (shape, depth)
+    assert ehas.mean() > 0.2
+
+
+def test_dma_form_strict_when_asked_for_and_auto_falls_back(dma_ctx, slr, oracle, synth):
+    ctx = dma_ctx
+    rng = np.random.default_rng(3)
+    W, H = 320, 48
+    st = synth.render_mf_stack(W, H, seed=2, noise=3)
+    raw = st[0].numpy()
+    wild = (np.stack([rng.integers(-9, W + 9, (H, W)), rng.integers(-9, H + 9, (H, W))], -1).astype(np.int16),
+            rng.integers(0, 1024, (H, W)).astype(np.uint16))
+    eph, ev = _expect(oracle, raw, wild[0], wild[1])
+    _opts(ctx, slr, 7, 0, 1)
+    ctx.set_rectify_maps(0, wild[0], wild[1])                                    # tile boxes far too large for the form
+    with pytest.raises(slr.capi.SlrError) as ei:
+        ctx.mf_decode(st[0].cuda(), BLACK, rectify_cam=0)
+    assert ei.value.status == slr.capi.ERR_UNSUPPORTED
+    _opts(ctx, slr, 0, 0, 1)                                                     # auto: silently the round-1 forms
+    ph, v = ctx.mf_decode(st[0].cuda(), BLACK, rectify_cam=0)
+    ctx.synchronize()
+    assert bits_equal(np_of(v), ev) and bits_equal(np_of(ph), eph)
+    # separate plane allocations (no common stride): not this form either
+    mx, mf = synth.make_rectify_maps(W, H, 0)
+    ctx.set_rectify_maps(0, mx.numpy(), mf.numpy())
+    planes = [st[0, p].cuda().clone() for p in range(14)]
+    planes[3] = torch.cat([torch.zeros(7, W, dtype=torch.uint8, device="cuda"), planes[3]])[7:]
+    _opts(ctx, slr, 7, 0, 1)
+    with pytest.raises(slr.capi.SlrError):
+        ctx.mf_decode(planes, BLACK, rectify_cam=0)
+    _opts(ctx, slr, 0, 0, 1)
+    eph, ev = _expect(oracle, raw, mx.numpy(), mf.numpy())
+    ph, v = ctx.mf_decode(planes, BLACK, rectify_cam=0)
+    ctx.synchronize()
+    assert bits_equal(np_of(v), ev) and bits_equal(np_of(ph), eph)
+
+
+def test_dma_form_fullsize_pair_launch(dma_ctx, slr, oracle, synth):
+    """4096x3000, both cameras: the bench configuration, every shape at depth 1 and three of them at depth 2"""
+    ctx = dma_ctx
+    W, H = 4096, 3000
+    dev = torch.device("cuda", 0)
+    st = synth.render_mf_stack(W, H, seed=1234, device=dev)
+    maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
+    torch.cuda.synchronize()
+    exp = [_expect(oracle, st[cam].cpu().numpy(), maps[cam][0].cpu().numpy(), maps[cam][1].cpu().numpy()) for cam in range(2)]
+    ran = []
+    for shape, depth in [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (0, 2), (1, 2), (4, 2)]:
+        _opts(ctx, slr, 7, shape, depth)
+        for cam in range(2):
+            ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+        try:
+            for cam in range(2):
+                ph, v = ctx.mf_decode(st[cam], BLACK, rectify_cam=cam)
+                ctx.synchronize()
+                assert bits_equal(np_of(v), exp[cam][1]) and bits_equal(np_of(ph), exp[cam][0]), (shape, depth, cam)
+            ran.append((shape, depth))
+        except slr.capi.SlrError as e:       # the 256-thread shapes hold few source rows: these maps' corner tiles may not fit
+            assert e.status == slr.capi.ERR_UNSUPPORTED and shape not in (0, 1, 3), (shape, str(e))
+    assert (0, 1) in ran and (1, 1) in ran and len(ran) >= 6, ran
