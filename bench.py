@@ -2,10 +2,12 @@
 """bench.py -- throughput of the structured-light hot path on MI355X.
 
 Metric (BASELINE.json): Mpixels/s of decode + unwrap + triangulate on synthetic 4096x3000 stereo x 14-image
-multi-frequency stacks (configs[1]).  One "step" = one stereo frame per GPU through the whole MF path
-(MFReconstruct::runReconstruction between imread and MeshCreator): fused rectify+decode of both cameras, then
-row-wise phase match + Q-matrix triangulation -> XYZ [H][W][3] + mask.  1 pixel = one (row, col) of one stereo
-frame.  Inputs are resident in HBM when the timed region starts.
+multi-frequency stacks (configs[1]).  One "step" = one batch of --frames (default 8: config 4's 64 frames over 8 GPUs)
+DISTINCT stereo frames per GPU through the whole MF path (MFReconstruct::runReconstruction between imread and
+MeshCreator): fused rectify+decode of both cameras, then row-wise phase match + Q-matrix triangulation -> XYZ [H][W][3] +
+mask.  1 pixel = one (row, col) of one stereo frame.  The frames are resident in HBM when the timed region starts (8 x 344 MB:
+nothing of a frame survives in the 256 MB Infinity Cache until its next turn).  --mode ge / gray time the two Gray-code
+modes of the reference (GRAY_EPI: Reconstruct::runReconstruction_GE, GRAY_ONLY: Reconstruct::runReconstruction) the same way.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): frames shard across ranks (weak scaling, no
 data-path collective inside the kernels); the per-step point cloud is assembled on every rank with one RCCL
@@ -17,20 +19,28 @@ per peer: that mode measures xGMI, not the kernels); --gather off
 measures the sharded path alone.
 
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed inside the timed
-region on the kernels' own stream), "kernels" (all kernels), "cpu_baseline" (the CPU oracle on a bounded sample).
+region on the kernels' own stream; "traffic" = HBM bytes per launch from rocprofv3 PMC passes run by this script when
+rocprofv3 is on PATH, else from profiles/pmc_traffic.json -- "traffic_source" says which), "kernels" (all kernels),
+"cpu_baseline" (the CPU oracle on a bounded sample).
 """
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6300.0    # what the same guide gives as achievable; both fractions are reported
 BLACK_THR = 40                 # Duke/Set.ui:429-431 default
 
 # algorithmic bytes per camera-pixel (or stereo-pixel for the match kernel) -- SURVEY.md 8(d), DESIGN.md
@@ -41,6 +51,22 @@ ALG_BYTES = {
     "slr_mf_decode": 19.0,             # 12 fringe + 2 white/black + 4 phase + 1 valid
     "slr_mf_match_triangulate": 21.0,  # 2 x 4 phase read + 12 xyz + 1 mask write (23 with separate valid bytes)
     "slr_remap_u8": 8.0,
+    # Gray modes (per cam-px / per st-px), 4096-wide projector: 2 + 2 x 12 planes
+    "slr_gray_rectify_decode": 36.0,   # 26 src + 6 map + 4 code (inside slr_reconstruct_ge the valid flag is code -1)
+    "slr_ge_match_triangulate": 21.0,  # 2 x 4 code read + 12 xyz + 1 mask write
+}
+
+# rocprofv3 kernel-name prefixes of the profiler names above (roofline.traffic)
+DEVICE_KERNEL = {
+    "slr_mf_rectify_decode_pair": ("mf_rect_decode_dma_kernel", "mf_rect_decode_lds_kernel"),
+    "slr_mf_rectify_decode": ("mf_rect_decode_dma_kernel", "mf_rect_decode_lds_kernel"),
+    "slr_mf_match_triangulate": ("mf_match_binned_kernel", "mf_match_chunked_kernel"),
+    "slr_mf_decode": ("mf_decode_kernel",),
+    "slr_gray_rectify_decode": ("gray_rect_decode_lds_kernel",),
+    "slr_gray_decode": ("gray_decode_kernel",),
+    "slr_ge_match_triangulate": ("ge_match_kernel",),
+    "slr_ray_triangulate": ("ray_triangulate_kernel",),
+    "slr_ray_count": ("ray_count_kernel",),
 }
 
 
@@ -49,6 +75,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=["mf", "ge", "gray"], default="mf",
+                    help="mf: the metric's 3-freq x 4-step path (default); ge: GRAY_EPI (Gray columns + rectification); gray: GRAY_ONLY "
+                         "(Gray columns + rows, ray-ray triangulation, 1280x1024 projector)")
+    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident stereo frames per GPU per step (0 = 8; gray: 4)")
+    ap.add_argument("--traffic", choices=["auto", "live", "file", "off"], default="auto",
+                    help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a 3-step child run, "
+                         "file = profiles/pmc_traffic.json, auto = live when rocprofv3 is on PATH and N == 1")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--width", type=int, default=4096)
     ap.add_argument("--height", type=int, default=3000)
     ap.add_argument("--rectify", type=int, default=1, help="1: raw planes + fused rectification (the reference path)")
@@ -143,6 +177,45 @@ def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
                   "rows (%.1f s), scaled to the frame; single thread, gcc -O2" % (W, H, t_dec, rows, H, t_tri),
         "host_cpus": os.cpu_count(), "all_cores_extra": extra,
     }
+
+
+def live_traffic(args, kernel_name):
+    """HBM bytes per launch of `kernel_name` (a profiler name) from two rocprofv3 --pmc passes over a 3-step child run of this
+    script (one frame per step), collected and corrected as MI355X_MICROARCH.md's HBM section prescribes: separate passes for
+    FETCH_SIZE and WRITE_SIZE (KiB), gfx950's FETCH_SIZE doubled.  Returns (bytes, detail) or (None, reason)."""
+    exe = shutil.which("rocprofv3")
+    prefixes = DEVICE_KERNEL.get(kernel_name)
+    if not exe or not prefixes:
+        return None, "rocprofv3 not on PATH" if not exe else "no device kernel name known for " + kernel_name
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="slr_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", "1", "--mode", args.mode, "--width", str(args.width), "--height", str(args.height),
+               "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--dma-shape", str(args.dma_shape),
+               "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
+            got = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        kn = row.get("Kernel_Name", "")
+                        if row.get("Counter_Name") == counter and any(px in kn for px in prefixes):
+                            got.append(float(row["Counter_Value"]))
+            if got:
+                vals[counter] = sum(got) / len(got)
+        except Exception as e:                              # the bench line must survive a profiler hiccup
+            vals[counter + "_error"] = repr(e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, "rocprofv3 produced no counters for %s (%s)" % (kernel_name, vals)
+    rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
+    return int(rd + wr), {"hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+                          "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, mean per dispatch of a 3-step child run; "
+                                 "FETCH_SIZE KiB x 2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE KiB x 1"}
 
 
 def copy_ceiling(torch, dev, stream):
@@ -243,14 +316,23 @@ def main():
     slr = importlib.import_module("structure-light-reconstructor_amd")
     synth = importlib.import_module("structure-light-reconstructor_amd.synth")
     W, H = args.width, args.height
+    mode = args.mode
+    F = args.frames if args.frames > 0 else (4 if mode == "gray" else 8)
+    if args.pmc_child:                                   # the rocprofv3 child of live_traffic(): one frame, three steps
+        F, args.steps, args.warmup, args.profile, args.cpu_baseline, args.host_io, args.traffic = 1, 3, 1, 0, 0, 0, "off"
+    scan_w, scan_h = (W, 0) if mode == "ge" else ((1280, 1024) if mode == "gray" else (0, 0))
+    ncol = synth.gray_num_bits(scan_w) if mode != "mf" else 0
+    nrow = synth.gray_num_bits(scan_h) if mode == "gray" else 0
+    ppc = 14 if mode == "mf" else 2 + 2 * ncol + 2 * nrow
+    rectify = bool(args.rectify) and mode != "gray"      # GRAY_ONLY never rectifies (reconstruct.cpp:230-265)
 
     S = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     ctxs = [slr.Context(local, stream=st_) for st_ in streams]
     compute, ctx = streams[0], ctxs[0]
-    calib, _ = synth.make_calibration(W, H)
+    calib, _ = synth.make_calibration(W, H) if mode != "gray" else synth.make_calibration(W, H, baseline=400.0, theta=0.6)
     maps = None
-    if args.rectify:
+    if rectify:
         maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
         torch.cuda.synchronize()
     for c_ in ctxs:
@@ -261,42 +343,61 @@ def main():
             c_.set_option(slr.capi.OPT_RECT_DMA_SHAPE, args.dma_shape)
         if args.dma_depth >= 0:
             c_.set_option(slr.capi.OPT_RECT_DMA_DEPTH, args.dma_depth)
-        if args.rectify:
+        if rectify:
             for cam in range(2):
                 c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
-    # one synthetic stereo frame per rank (seed 1234 + rank), resident in HBM
-    rendered = synth.render_mf_stack(W, H, seed=1234 + rank, noise=2, device=dev)
+    # F distinct synthetic stereo frames per rank (seeds 1234 + 100 rank + f), resident in HBM
     pitch = W + max(0, args.pitch_pad)
-    stack = torch.zeros((1, 2, 14, H, pitch), dtype=torch.uint8, device=dev)      # rows padded: see --pitch-pad
-    stack[0, :, :, :, :W] = rendered
-    del rendered
+    stack = torch.zeros((F, 2, ppc, H, pitch), dtype=torch.uint8, device=dev)      # rows padded: see --pitch-pad
+    for f in range(F):
+        seed = 1234 + 100 * rank + f
+        if mode == "mf":
+            rendered = synth.render_mf_stack(W, H, seed=seed, noise=2, device=dev)
+        elif mode == "ge":
+            rendered = synth.render_gray_stack(W, H, scan_w, seed=seed, noise=2, device=dev)
+        else:
+            rendered = synth.render_gray_stack(W, H, scan_w, scan_h, seed=seed, noise=2, device=dev, rows=True)
+        stack[f, :, :, :, :W] = rendered
+        del rendered
     torch.cuda.synchronize()
 
     nbuf = 2 if S == 1 else S
-    xyz = [torch.empty((1, H, W, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    has = [torch.empty((1, H, W), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    oh, ow = (scan_h, scan_w) if mode == "gray" else (H, W)
+    xyz = [torch.empty((F, oh, ow, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    has = [torch.empty((F, oh, ow), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
     after_gather = world > 1 and args.gather == "after"
     if do_gather or final_gather or after_gather:
         comm = torch.cuda.Stream(device=dev)
         # output = concatenation of the per-rank clouds along dim 0 (the form every backend accepts)
-        g_xyz = torch.empty((world * H, W, 3), dtype=torch.float32, device=dev)
-        g_has = torch.empty((world * H, W), dtype=torch.uint8, device=dev)
+        g_xyz = torch.empty((world * F * oh, ow, 3), dtype=torch.float32, device=dev)
+        g_has = torch.empty((world * F * oh, ow), dtype=torch.uint8, device=dev)
         done_compute = [torch.cuda.Event() for _ in range(nbuf)]
         done_gather = [torch.cuda.Event() for _ in range(nbuf)]
+
+    def gather(b):
+        dist.all_gather_into_tensor(g_xyz, xyz[b].view(F * oh, ow, 3))
+        dist.all_gather_into_tensor(g_has, has[b].view(F * oh, ow))
 
     def step(i):
         b = i % nbuf
         if do_gather:
             streams[i % S].wait_event(done_gather[b])   # buffer b is free again once its gather finished
-        ctxs[i % S].reconstruct_mf_batch(stack, BLACK_THR, bool(args.rectify), W=W, xyz=xyz[b], has=has[b])
+        c_ = ctxs[i % S]
+        if mode == "mf":
+            c_.reconstruct_mf_batch(stack, BLACK_THR, rectify, W=W, xyz=xyz[b], has=has[b])
+        elif mode == "ge":
+            c_.reconstruct_batch(slr.capi.MODE_GE, stack, BLACK_THR, 0, n_col_bits=ncol, scan_w=scan_w, rectify=rectify, W=W,
+                                 xyz=xyz[b], has=has[b])
+        else:
+            c_.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK_THR, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=scan_w,
+                                 scan_h=scan_h, rectify=False, W=W, xyz=xyz[b], has=has[b])
         if do_gather:
             done_compute[b].record(streams[i % S])
             comm.wait_event(done_compute[b])
             with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(g_xyz, xyz[b][0])
-                dist.all_gather_into_tensor(g_has, has[b][0])
+                gather(b)
                 done_gather[b].record(comm)
 
     def sync_all():
@@ -324,8 +425,7 @@ def main():
         done_compute[b].record(streams[(args.steps - 1) % S])
         comm.wait_event(done_compute[b])
         with torch.cuda.stream(comm):
-            dist.all_gather_into_tensor(g_xyz, xyz[b][0])
-            dist.all_gather_into_tensor(g_has, has[b][0])
+            gather(b)
     sync_all()
     elapsed = time.perf_counter() - t0
     gather_ms = None
@@ -333,8 +433,7 @@ def main():
         b = (args.steps - 1) % nbuf
         tg = time.perf_counter()
         with torch.cuda.stream(comm):
-            dist.all_gather_into_tensor(g_xyz, xyz[b][0])
-            dist.all_gather_into_tensor(g_has, has[b][0])
+            gather(b)
         sync_all()
         tt = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -352,8 +451,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if args.pmc_child:
+        for c_ in ctxs:
+            c_.close()
+        return
     npix = float(W) * H
-    value = world * npix * args.steps / elapsed / 1e6
+    value = world * npix * F * args.steps / elapsed / 1e6
 
     kernels, roofline = [], None
     for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
@@ -366,32 +469,39 @@ def main():
         kernels.append(entry)
     if kernels:
         k0 = kernels[0]                                  # dominant kernel by total time in the timed region
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tpath):
+        traffic, tsrc, tdetail = None, None, None
+        want_live = args.traffic == "live" or (args.traffic == "auto" and world == 1 and shutil.which("rocprofv3"))
+        if rank == 0 and want_live:
+            traffic, tdetail = live_traffic(args, k0["name"])
+            tsrc = "live: rocprofv3 --pmc child runs of this command" if traffic else None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch of an earlier profile run
+        if traffic is None and args.traffic != "off" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if k0["name"].endswith("_pair"):         # both cameras in one launch: 2 x the per-camera launch measured
-                    traffic = tj.get(k0["name"][:-5], {}).get("hbm_bytes_per_launch")
-                    traffic = 2 * traffic if traffic else None
-                else:
-                    traffic = tj.get(k0["name"], {}).get("hbm_bytes_per_launch")
+                ent = tj.get(k0["name"]) or ({k: 2 * v if isinstance(v, int) else v for k, v in tj.get(k0["name"][:-5], {}).items()}
+                                             if k0["name"].endswith("_pair") else None)   # pair launch = 2 x the per-camera launch
+                if ent:
+                    traffic, tsrc = ent.get("hbm_bytes_per_launch"), "file: profiles/pmc_traffic.json (" + str(ent.get("kernel")) + ")"
             except Exception:
                 traffic = None
         roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0.get("achieved_GBs"), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": k0.get("frac_hbm_peak"), "traffic": traffic,
+                    "unit": "GB/s", "frac": k0.get("frac_hbm_peak"),
+                    "frac_of_achievable_6300": round(k0["achieved_GBs"] / HBM_ACHIEVABLE_GBS, 4) if k0.get("achieved_GBs") else None,
+                    "traffic": traffic, "traffic_source": tsrc, "traffic_detail": tdetail if isinstance(tdetail, dict) else None,
+                    "traffic_over_algorithmic": round(traffic / (ALG_BYTES.get(k0["name"], 0) * npix), 3)
+                    if traffic and ALG_BYTES.get(k0["name"]) else None,
                     "avg_launch_us": k0["avg_us"], "alg_bytes_per_launch": ALG_BYTES.get(k0["name"], 0) * npix}
 
     # outside the timed region: the other kernels of the path on the same frame (HIP-event timed, same stream):
     # the unfused phase-decode+unwrap kernel (north_star's named roofline target), the standalone remap and the
     # literal linear-sweep form of the match kernel
     extras = []
-    if rank == 0 and args.profile:
+    if rank == 0 and args.profile and mode == "mf":
         reps = 10
         ph = torch.empty((H, W), dtype=torch.float32, device=dev)
         vd = torch.empty((H, W), dtype=torch.uint8, device=dev)
         tmp = plane3 = None
-        if args.rectify:
+        if rectify:
             tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
             plane3 = stack[0, 0, 3, :, :W].contiguous()
         for timed in (False, True):                      # two untimed launches first (new output buffers, cold code), as
@@ -401,7 +511,7 @@ def main():
                 ctx.profile_reset()
             for _ in range(reps if timed else 2):
                 ctx.mf_decode(stack[0, 0], BLACK_THR, W=W, phase=ph, valid=vd)
-            if args.rectify:
+            if rectify:
                 for _ in range(reps if timed else 2):
                     ctx.remap_u8(0, plane3, out=tmp)
         for name, (ms, n) in sorted(ctx.profile().items()):
@@ -414,13 +524,12 @@ def main():
     if rank == 0:
         ceiling = copy_ceiling(torch, dev, compute)
         if roofline and roofline.get("achieved"):
-            roofline["copy_ceiling"] = round(ceiling, 1)
-            roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / ceiling, 4)
-        if world == 1 and args.host_io:
-            hostio = host_io_rate(np, torch, ctx, stack, W, H, bool(args.rectify), slr, calib)
+            roofline["copy_ceiling_this_box"] = round(ceiling, 1)   # 1 GiB device-to-device copy, varies 4.7-5.5 TB/s between boxes
+        if world == 1 and args.host_io and mode == "mf":
+            hostio = host_io_rate(np, torch, ctx, stack, W, H, rectify, slr, calib)
 
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_baseline:
+    if rank == 0 and world == 1 and args.cpu_baseline and mode == "mf":
         rows = args.cpu_rows or H          # whole frame: ~8 s of single-thread CPU work at 4096x3000
         maps_cpu = None if maps is None else [(m[0].cpu().numpy(), m[1].cpu().numpy()) for m in maps]
         cpu = cpu_baseline(synth, W, H, np.ascontiguousarray(stack[0, :, :, :, :W].cpu().numpy()), maps_cpu, calib, rows)
@@ -431,9 +540,14 @@ def main():
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 in, f32 phase/XYZ (f64 undistort + Q reprojection)", "data": "synthetic",
-            "config": {"workload": "1x %dx%d stereo, 3-freq x 4-step (14 planes/camera) rectify+decode+unwrap+match+"
-                                   "triangulate per GPU per step" % (W, H),
-                       "frames_per_gpu_per_step": 1, "rectify": bool(args.rectify), "streams_per_gpu": S,
+            "ms_per_frame": round(elapsed / args.steps / F * 1e3, 4),
+            "config": {"workload": {"mf": "%dx%d stereo, 3-freq x 4-step (14 planes/camera): rectify+decode+unwrap+match+triangulate",
+                                    "ge": "%dx%d stereo, GRAY_EPI (Gray-code columns, 26 planes/camera at a 4096-wide projector): "
+                                          "rectify+decode+code match+triangulate",
+                                    "gray": "%dx%d stereo, GRAY_ONLY (Gray-code columns+rows, 44 planes/camera, 1280x1024 projector): "
+                                            "decode+bucket scatter+ray-ray triangulation"}[mode] % (W, H)
+                                   + "; a step = %d distinct HBM-resident frames per GPU" % F,
+                       "mode": mode, "frames_per_gpu_per_step": F, "rectify": rectify, "streams_per_gpu": S,
                        "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else
@@ -442,7 +556,7 @@ def main():
                              if after_gather else "")))},
             "device": _device_info(torch, local),
             "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
-            "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * npix * 13),
+            "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
             "roofline": roofline,
             # the kernel north_star's ">= 60 % of the HBM roofline" target names: the UNFUSED phase-decode + unwrap kernel

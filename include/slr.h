@@ -240,6 +240,28 @@ int slr_reconstruct_gray(slr_ctx *ctx, const uint8_t *const *planesL, const uint
 int slr_reconstruct_mf_batch(slr_ctx *ctx, int n_frames, const uint8_t *stack, int pitch, int W, int H,
                              int black_thr, int rectify, float *xyz, uint8_t *has);
 
+/* The same for every reconstruction mode (MainWindow::startreconstruct's switch on codePatternUsed, mainwindow.cpp:562-652;
+ * mode ids as mainwindow.h:95): one GPU's shard of frames, device-resident, processed back to back on the ctx stream.
+ *   stack            [n_frames][2 cams][planes_per_cam][H][pitch] contiguous u8 in HBM
+ *   SLR_MODE_MF      planes_per_cam >= 14; xyz [n][H][W][3], has [n][H][W]
+ *   SLR_MODE_GE      planes_per_cam >= 2 + 2 n_col_bits; xyz / has as above, color [n][H][W] or NULL (have_color = 0)
+ *   SLR_MODE_GRAY    planes_per_cam >= 2 + 2 n_col_bits + 2 n_row_bits; xyz = PointCloudImage sums [n][scan_h][scan_w][3],
+ *                    has = the u8 counts [n][scan_h][scan_w]
+ * Every argument is validated before the first frame is enqueued, so a call either fails as a whole or only a HIP runtime
+ * error (reported by status, frames before it already enqueued) can interrupt it. */
+#define SLR_MODE_GRAY 0
+#define SLR_MODE_GE 1
+#define SLR_MODE_MF 2
+typedef struct slr_batch_desc {
+    int mode, n_frames, planes_per_cam;
+    int pitch, W, H;
+    int black_thr, white_thr;
+    int n_col_bits, n_row_bits, scan_w, scan_h;   /* Gray modes */
+    int rectify, have_color;
+} slr_batch_desc;
+int slr_reconstruct_batch(slr_ctx *ctx, const slr_batch_desc *desc, const uint8_t *stack, float *xyz, uint8_t *has,
+                          uint8_t *color);
+
 /* ---- measurement hooks (bench.py): HIP-event timing on the ctx stream ------------------------------ */
 int slr_timer_begin(slr_ctx *ctx);                 /* records an event on the ctx stream */
 int slr_timer_end(slr_ctx *ctx, float *ms);        /* records + synchronises, returns elapsed ms */

@@ -36,7 +36,7 @@ SYMBOLS = [
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
 ]
@@ -51,6 +51,14 @@ class SlrError(RuntimeError):
 class Camera(C.Structure):
     _fields_ = [("fc", C.c_float * 2), ("cc", C.c_float * 2), ("k", C.c_float * 5),
                 ("R", C.c_float * 9), ("t", C.c_float * 3)]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mode", "n_frames", "planes_per_cam", "pitch", "W", "H", "black_thr", "white_thr",
+                                        "n_col_bits", "n_row_bits", "scan_w", "scan_h", "rectify", "have_color")]
+
+
+MODE_GRAY, MODE_GE, MODE_MF = 0, 1, 2
 
 
 class Calib(C.Structure):
@@ -423,6 +431,24 @@ class Context:
                                                     C.c_int(H), C.c_int(black_thr), C.c_int(1 if rectify else 0),
                                                     _ptr(xyz), _ptr(has)))
         return xyz, has
+
+    def reconstruct_batch(self, mode, stack, black_thr, white_thr=0, n_col_bits=0, n_row_bits=0, scan_w=0, scan_h=0, rectify=True,
+                          have_color=False, W=None, xyz=None, has=None, color=None):
+        """slr_reconstruct_batch: stack = torch.cuda u8 [n_frames][2][planes_per_cam][H][pitch]; returns (xyz, has/count, color)."""
+        import torch
+        nf, two, ppc, H, pitch = stack.shape
+        assert two == 2 and stack.is_cuda and stack.is_contiguous()
+        W = pitch if W is None else W
+        oh, ow = (scan_h, scan_w) if mode == MODE_GRAY else (H, W)
+        xyz = torch.empty((nf, oh, ow, 3), dtype=torch.float32, device=stack.device) if xyz is None else xyz
+        has = torch.empty((nf, oh, ow), dtype=torch.uint8, device=stack.device) if has is None else has
+        if have_color and color is None:
+            color = torch.empty((nf, H, W), dtype=torch.uint8, device=stack.device)
+        self._mem([stack, xyz, has, color])
+        d = BatchDesc(mode, nf, ppc, pitch, W, H, black_thr, white_thr, n_col_bits, n_row_bits, scan_w, scan_h,
+                      1 if rectify else 0, 1 if have_color else 0)
+        self._chk(self.lib.slr_reconstruct_batch(self.h, C.byref(d), _ptr(stack), _ptr(xyz), _ptr(has), _ptr(color)))
+        return xyz, has, color
 
     def reconstruct_ge(self, planesL, planesR, n_col_bits, black_thr, white_thr, scan_w, rectify, have_color, W=None):
         pl, n, H, pitch = _plane_ptrs(planesL)

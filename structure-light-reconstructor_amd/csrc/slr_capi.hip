@@ -1017,6 +1017,49 @@ int slr_reconstruct_gray(slr_ctx *c, const uint8_t *const *planesL, const uint8_
     return st.finish();
 }
 
+int slr_reconstruct_batch(slr_ctx *c, const slr_batch_desc *d, const uint8_t *stack, float *xyz, uint8_t *has, uint8_t *color)
+{
+    if (!c || !d || !stack || !xyz || !has || d->n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    int need = 0;
+    switch (d->mode) {
+        case SLR_MODE_MF:   need = SLR_MF_PLANES; break;
+        case SLR_MODE_GE:   need = 2 + 2 * d->n_col_bits; break;
+        case SLR_MODE_GRAY: need = 2 + 2 * d->n_col_bits + 2 * d->n_row_bits; break;
+        default: return fail(c, SLR_ERR_INVALID_ARG, "mode must be SLR_MODE_GRAY, SLR_MODE_GE or SLR_MODE_MF");
+    }
+    if (d->mode != SLR_MODE_MF && (d->n_col_bits < 1 || d->n_col_bits > SLR_MAX_GRAY_BITS || d->scan_w <= 0))
+        return fail(c, SLR_ERR_INVALID_ARG, "bit counts / scan size out of range");
+    if (d->mode == SLR_MODE_GRAY && (d->n_row_bits < 1 || d->n_row_bits > SLR_MAX_GRAY_BITS || d->scan_h <= 0))
+        return fail(c, SLR_ERR_INVALID_ARG, "bit counts / scan size out of range");
+    if (d->planes_per_cam < need || d->planes_per_cam > SLR_MAX_GRAY_PLANES) return fail(c, SLR_ERR_INVALID_ARG, "planes_per_cam does not hold the mode's stack");
+    if (d->mode == SLR_MODE_GE && d->have_color && !color) return fail(c, SLR_ERR_INVALID_ARG, "color buffer required");
+    SLR_TRY(check_dims(c, d->W, d->H, d->pitch));
+    if (d->mode == SLR_MODE_MF && d->W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    if (d->mode == SLR_MODE_GE && d->W > 16384) return fail(c, SLR_ERR_UNSUPPORTED, "W > 16384 does not fit the LDS row (Gray-code match)");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    const bool rect = d->rectify != 0 && d->mode != SLR_MODE_GRAY;          // GRAY_ONLY never rectifies (reconstruct.cpp:230-265)
+    if (rect) { SLR_TRY(need_maps(c, 0, d->W, d->H)); SLR_TRY(need_maps(c, 1, d->W, d->H)); }
+    if (d->mode == SLR_MODE_GE && d->have_color && !rect && d->pitch != d->W)
+        return fail(c, SLR_ERR_UNSUPPORTED, "have_color without rectify needs pitch == W");
+    const size_t plane = (size_t)d->pitch * d->H, n = (size_t)d->W * d->H, cells = (size_t)(d->scan_w > 0 ? d->scan_w : 0) * (d->scan_h > 0 ? d->scan_h : 0);
+    for (int f = 0; f < d->n_frames; f++) {
+        const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];
+        const uint8_t *base = stack + (size_t)f * 2 * d->planes_per_cam * plane;
+        for (int i = 0; i < need; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (d->planes_per_cam + i); }
+        if (d->mode == SLR_MODE_MF)
+            SLR_TRY(reconstruct_mf_dev(c, pl, pr, d->pitch, d->W, d->H, d->black_thr, rect, xyz + (size_t)f * n * 3, has + (size_t)f * n));
+        else if (d->mode == SLR_MODE_GE)
+            SLR_TRY(slr_reconstruct_ge(c, pl, pr, d->n_col_bits, d->pitch, d->W, d->H, d->black_thr, d->white_thr, d->scan_w, rect,
+                                       d->have_color, xyz + (size_t)f * n * 3, has + (size_t)f * n,
+                                       d->have_color ? color + (size_t)f * n : nullptr, SLR_MEM_DEVICE));
+        else
+            SLR_TRY(slr_reconstruct_gray(c, pl, pr, d->n_col_bits, d->n_row_bits, d->pitch, d->W, d->H, d->black_thr, d->white_thr,
+                                         d->scan_w, d->scan_h, xyz + (size_t)f * cells * 3, has + (size_t)f * cells, SLR_MEM_DEVICE));
+    }
+    return SLR_OK;
+}
+
 int slr_set_option(slr_ctx *c, int option, int value)
 {
     if (!c) return SLR_ERR_INVALID_ARG;
