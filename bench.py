@@ -377,8 +377,15 @@ def main():
         done_gather = [torch.cuda.Event() for _ in range(nbuf)]
 
     def gather(b):
-        dist.all_gather_into_tensor(g_xyz, xyz[b].view(F * oh, ow, 3))
-        dist.all_gather_into_tensor(g_has, has[b].view(F * oh, ow))
+        if dist.get_backend() == "nccl":                 # RCCL over xGMI
+            dist.all_gather_into_tensor(g_xyz, xyz[b].view(F * oh, ow, 3))
+            dist.all_gather_into_tensor(g_has, has[b].view(F * oh, ow))
+        else:                                            # dry run of the N > 1 path on a box without several GPUs: via the host
+            torch.cuda.current_stream().synchronize()
+            cx, ch = torch.empty(g_xyz.shape, dtype=g_xyz.dtype), torch.empty(g_has.shape, dtype=g_has.dtype)
+            dist.all_gather_into_tensor(cx, xyz[b].view(F * oh, ow, 3).cpu())
+            dist.all_gather_into_tensor(ch, has[b].view(F * oh, ow).cpu())
+            g_xyz.copy_(cx); g_has.copy_(ch)
 
     def step(i):
         b = i % nbuf

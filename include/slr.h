@@ -262,6 +262,33 @@ typedef struct slr_batch_desc {
 int slr_reconstruct_batch(slr_ctx *ctx, const slr_batch_desc *desc, const uint8_t *stack, float *xyz, uint8_t *has,
                           uint8_t *color);
 
+/* Several GPUs of one node from ONE process (what a Qt/C++ host can call; SURVEY 8e: frames shard across GPUs, no
+ * data-path collective, the final point cloud is assembled over xGMI).  ctxs[k] lives on its own device (slr_create(dev, ..));
+ * several ctx on one device are allowed (testing).  Frame f of the job is frame f / n_ctx of ctxs[f % n_ctx]'s shard:
+ *   stacks[k]  device-resident on ctxs[k]'s device: [frames of k][2 cams][14][H][pitch] u8
+ *   xyz[k], has[k]  ctxs[k]'s own results, [frames of k][H][W][3] / [frames of k][H][W], on its device
+ *   gather_ctx >= 0: xyz_all [n_frames][H][W][3] and has_all [n_frames][H][W] on ctxs[gather_ctx]'s device receive every frame
+ *   in job order by direct peer copies (hipMemcpyPeerAsync on the producing stream: one xGMI hop per source); -1: no assembly.
+ * All devices run concurrently; the call returns when every stream is idle (the same calibration / maps / options must have
+ * been installed on every ctx).  MFReconstruct::runReconstruction x n_frames (mfreconstruct.cpp:160-187). */
+int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W,
+                             int H, int black_thr, int rectify, float *const *xyz, uint8_t *const *has, int gather_ctx,
+                             float *xyz_all, uint8_t *has_all);
+
+/* Ordered prefix index of a u8 flag image [h][w] (nonzero = flagged), enumerated row-major (column_major = 0) or in the
+ * column-outer / row-inner order in which MeshCreator numbers the vertices of a PointCloudImage (meshcreator.cpp:21-33,
+ * 71-84): index[j][i] = first + (flagged elements before (i, j) in that order), or `none` where the flag is 0; *total = the
+ * flagged count.  slr_compact_points: the flagged points of an XYZ array, in array order, into out_xyz (capacity n; out_src,
+ * optional, gets their source positions) -- the sparse form of a point cloud for transport. */
+int slr_prefix_index(slr_ctx *ctx, const uint8_t *flags, int w, int h, int column_major, uint32_t first, uint32_t none,
+                     uint32_t *index, uint32_t *total, slr_mem mem);
+int slr_compact_points(slr_ctx *ctx, const float *xyz, const uint8_t *has, size_t n, float *out_xyz, uint32_t *out_src,
+                       uint32_t *count, slr_mem mem);
+
+/* page-locked host memory (the H2D / D2H copies of SLR_MEM_HOST calls are truly asynchronous only from / to it) */
+int slr_host_alloc(void **ptr, size_t bytes);
+int slr_host_free(void *ptr);
+
 /* ---- measurement hooks (bench.py): HIP-event timing on the ctx stream ------------------------------ */
 int slr_timer_begin(slr_ctx *ctx);                 /* records an event on the ctx stream */
 int slr_timer_end(slr_ctx *ctx, float *ms);        /* records + synchronises, returns elapsed ms */

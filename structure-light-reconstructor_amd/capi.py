@@ -36,7 +36,8 @@ SYMBOLS = [
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_multi", "slr_prefix_index", "slr_compact_points",
+    "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
 ]
@@ -481,6 +482,44 @@ class Context:
                                                 _ptr(cnt), C.c_int(mem)))
         return xyz, cnt
 
+    # -- ordered prefix index / compaction
+    def prefix_index(self, flags, column_major=False, first=0, none=0xFFFFFFFF):
+        """slr_prefix_index of a [h][w] u8 flag image -> (index [h][w] uint32, total)."""
+        h, w = flags.shape
+        mem = self._mem([flags])
+        if mem == MEM_DEVICE:
+            import torch
+            idx = torch.empty((h, w), dtype=torch.int32, device=flags.device)
+            tot = torch.zeros(1, dtype=torch.int32, device=flags.device)
+            idx.record_stream(self.stream) if self.stream is not None else None
+            tot.record_stream(self.stream) if self.stream is not None else None
+        else:
+            idx, tot = np.empty((h, w), np.uint32), np.zeros(1, np.uint32)
+        self._chk(self.lib.slr_prefix_index(self.h, _ptr(flags), C.c_int(w), C.c_int(h), C.c_int(1 if column_major else 0),
+                                            C.c_uint32(first), C.c_uint32(none), _ptr(idx), _ptr(tot), C.c_int(mem)))
+        if mem == MEM_DEVICE:
+            self.synchronize()
+            return idx, int(tot.item()) & 0xFFFFFFFF
+        return idx, int(tot[0])
+
+    def compact_points(self, xyz, has):
+        """slr_compact_points -> (points [count][3], source positions [count])."""
+        n = int(np.prod(has.shape))
+        mem = self._mem([xyz, has])
+        out = self._new(mem, (n, 3), np.float32, xyz)
+        src = self._new(mem, (n,), np.int32, xyz)
+        if mem == MEM_DEVICE:
+            import torch
+            cnt = torch.zeros(1, dtype=torch.int32, device=xyz.device)
+        else:
+            cnt = np.zeros(1, np.uint32)
+        self._chk(self.lib.slr_compact_points(self.h, _ptr(xyz), _ptr(has), C.c_size_t(n), _ptr(out), _ptr(src), _ptr(cnt),
+                                              C.c_int(mem)))
+        if mem == MEM_DEVICE:
+            self.synchronize()
+        k = int(cnt[0]) & 0xFFFFFFFF
+        return out[:k], src[:k]
+
     # -- measurement
     def timer_begin(self):
         self._chk(self.lib.slr_timer_begin(self.h))
@@ -505,3 +544,34 @@ class Context:
             if n.value:
                 out[self.lib.slr_profile_kernel_name(C.c_int(i)).decode()] = (ms.value, n.value)
         return out
+
+
+def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0):
+    """slr_reconstruct_mf_multi: one Context per device (or several on one device), stacks[k] = torch.cuda u8
+    [frames of k][2][14][H][pitch] on ctxs[k]'s device; frame f of the job is stacks[f % n][f // n].
+    Returns (xyz_all, has_all) on ctxs[gather_ctx]'s device (or the per-ctx lists when gather_ctx < 0)."""
+    import torch
+    n = len(ctxs)
+    nf = sum(int(s.shape[0]) for s in stacks)
+    _, two, npl, H, pitch = stacks[0].shape
+    assert two == 2 and npl == MF_PLANES
+    W = pitch if W is None else W
+    for k, s in enumerate(stacks):
+        assert s.is_cuda and s.is_contiguous() and int(s.shape[0]) == (nf - k + n - 1) // n
+    torch.cuda.synchronize()                               # inputs made by torch on any stream / device are complete
+    xyz = [torch.empty((int(s.shape[0]), H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
+    has = [torch.empty((int(s.shape[0]), H, W), dtype=torch.uint8, device=s.device) for s in stacks]
+    xa = ha = None
+    if gather_ctx >= 0:
+        gdev = stacks[gather_ctx].device
+        xa = torch.empty((nf, H, W, 3), dtype=torch.float32, device=gdev)
+        ha = torch.empty((nf, H, W), dtype=torch.uint8, device=gdev)
+    arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
+    arr_s = (C.c_void_p * n)(*[s.data_ptr() for s in stacks])
+    arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xyz])
+    arr_h = (C.c_void_p * n)(*[t.data_ptr() for t in has])
+    st = ctxs[0].lib.slr_reconstruct_mf_multi(arr_c, C.c_int(n), C.c_int(nf), arr_s, C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                              C.c_int(black_thr), C.c_int(1 if rectify else 0), arr_x, arr_h, C.c_int(gather_ctx),
+                                              _ptr(xa), _ptr(ha))
+    ctxs[0]._chk(st)
+    return (xa, ha) if gather_ctx >= 0 else (xyz, has)

@@ -30,7 +30,7 @@ enum Slot {
     S_PHASE_L = 16, S_VALID_L, S_PHASE_R, S_VALID_R,
     S_CODEX_L, S_CODEY_L, S_CODEX_R, S_CODEY_R,
     S_RAY_CELL, S_RAY_CELL2, S_RAY_RANK, S_RAY_CNT, S_RAY_OFFS, S_RAY_ITEMS, S_SCAN_TMP,
-    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R, S_RAYS_L, S_RAYS_R,
+    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R, S_RAYS_L, S_RAYS_R, S_FLAGSCAN, S_COMPACT,
     S_COUNT
 };
 
@@ -1015,6 +1015,110 @@ int slr_reconstruct_gray(slr_ctx *c, const uint8_t *const *planesL, const uint8_
     SLR_TRY(core_ray(c, (const int32_t *)cxl, (const int32_t *)cyl, (const uint8_t *)vl, (const int32_t *)cxr,
                      (const int32_t *)cyr, (const uint8_t *)vr, W, H, scan_w, scan_h, (float *)dx, (uint8_t *)dc));
     return st.finish();
+}
+
+// ---- ordered prefix index / compaction (mesh vertex numbering, sparse point-cloud assembly) --------------------------------
+int slr_prefix_index(slr_ctx *c, const uint8_t *flags, int w, int h, int column_major, uint32_t first, uint32_t none,
+                     uint32_t *index, uint32_t *total, slr_mem mem)
+{
+    if (!c || !flags || !index || !total || w <= 0 || h <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    const size_t n = (size_t)w * h;
+    if (n >= (1ull << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "image too large");
+    SLR_TRY(use_device(c));
+    Stage st(c, mem);
+    const void *df; void *di, *tmp;
+    SLR_TRY(st.in(flags, n, &df));
+    SLR_TRY(st.out(index, n * 4, &di));
+    SLR_TRY(get_scratch(c, S_FLAGSCAN, flag_scan_temp_bytes(n), &tmp));
+    uint32_t *tot_dev = nullptr;
+    SLR_HIP(c, launch_flag_scan((const uint8_t *)df, n, w, h, column_major != 0, first, none, (uint32_t *)di, nullptr, nullptr, nullptr,
+                                tmp, &tot_dev, c->stream));
+    SLR_HIP(c, hipMemcpyAsync(total, tot_dev, sizeof(uint32_t), mem == SLR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+    return st.finish();
+}
+
+int slr_compact_points(slr_ctx *c, const float *xyz, const uint8_t *has, size_t n, float *out_xyz, uint32_t *out_src,
+                       uint32_t *count, slr_mem mem)
+{
+    if (!c || !xyz || !has || !out_xyz || !count) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    if (n >= (1ull << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "too many points");
+    SLR_TRY(use_device(c));
+    Stage st(c, mem);
+    const void *dx, *dh; void *ox, *os, *tmp;
+    SLR_TRY(st.in(xyz, n * 12, &dx)); SLR_TRY(st.in(has, n, &dh));
+    SLR_TRY(st.out(out_xyz, n * 12, &ox)); SLR_TRY(st.out(out_src, n * 4, &os));
+    SLR_TRY(get_scratch(c, S_FLAGSCAN, flag_scan_temp_bytes(n), &tmp));
+    uint32_t *tot_dev = nullptr;
+    SLR_HIP(c, launch_flag_scan((const uint8_t *)dh, n, (int)(n > 0 ? n : 1), 1, 0, 0u, 0u, nullptr, (const float *)dx, (float *)ox,
+                                (uint32_t *)os, tmp, &tot_dev, c->stream));
+    SLR_HIP(c, hipMemcpyAsync(count, tot_dev, sizeof(uint32_t), mem == SLR_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+    return st.finish();
+}
+
+// ---- several GPUs in one process -------------------------------------------------------------------------------------------------
+// Frame f of the job runs on ctxs[f % n_ctx] (its shard index is f / n_ctx); every ctx works through its shard on its own
+// stream, so the devices run concurrently; afterwards the shards are assembled on ctxs[gather_ctx] by direct peer copies
+// (one hop over xGMI per source device; a frame's XYZ + mask go straight to their slot of the assembled [n_frames] arrays).
+int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
+                             int black_thr, int rectify, float *const *xyz, uint8_t *const *has, int gather_ctx,
+                             float *xyz_all, uint8_t *has_all)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c0 = ctxs[0];
+    if (!stacks || !xyz || !has || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
+    if (gather_ctx >= n_ctx || (gather_ctx >= 0 && (!xyz_all || !has_all))) return fail(c0, SLR_ERR_INVALID_ARG, "gather target");
+    for (int k = 0; k < n_ctx; k++) {
+        const int share = (n_frames - k + n_ctx - 1) / n_ctx;            // frames k, k + n_ctx, ...
+        if (!ctxs[k] || (share > 0 && (!stacks[k] || !xyz[k] || !has[k]))) return fail(c0, SLR_ERR_INVALID_ARG, "null shard");
+    }
+    const size_t n = (size_t)W * H;
+    // 1. every device starts on its shard (asynchronous on its own stream)
+    for (int k = 0; k < n_ctx; k++) {
+        const int share = (n_frames - k + n_ctx - 1) / n_ctx;
+        if (share <= 0) continue;
+        const int st = slr_reconstruct_mf_batch(ctxs[k], share, stacks[k], pitch, W, H, black_thr, rectify, xyz[k], has[k]);
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "shard failed", slr_last_error(ctxs[k])); return st; }
+    }
+    // 2. assembly: each source stream pushes its frames to the target device as soon as they are done
+    if (gather_ctx >= 0) {
+        slr_ctx *g = ctxs[gather_ctx];
+        for (int k = 0; k < n_ctx; k++) {
+            const int share = (n_frames - k + n_ctx - 1) / n_ctx;
+            slr_ctx *c = ctxs[k];
+            SLR_TRY(use_device(c));
+            if (c->device != g->device) {                                    // one-hop peer access (idempotent)
+                int can = 0;
+                SLR_HIP(c, hipDeviceCanAccessPeer(&can, c->device, g->device));
+                if (can) { const hipError_t e = hipDeviceEnablePeerAccess(g->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SLR_HIP(c, e); (void)hipGetLastError(); }
+            }
+            for (int j = 0; j < share; j++) {
+                const size_t f = (size_t)j * n_ctx + k;
+                SLR_HIP(c, hipMemcpyPeerAsync(xyz_all + f * n * 3, g->device, xyz[k] + (size_t)j * n * 3, c->device, n * 12, c->stream));
+                SLR_HIP(c, hipMemcpyPeerAsync(has_all + f * n, g->device, has[k] + (size_t)j * n, c->device, n, c->stream));
+            }
+        }
+    }
+    // 3. the call returns when every device is done (the assembled cloud is complete)
+    for (int k = 0; k < n_ctx; k++) {
+        SLR_TRY(use_device(ctxs[k]));
+        SLR_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+    }
+    return SLR_OK;
+}
+
+// pinned host memory for callers that feed SLR_MEM_HOST buffers (PNG decoders, camera SDK ring buffers): the H2D / D2H
+// copies of the host-buffer entry points are only asynchronous (SLR_OPT_ASYNC_HOST) from page-locked memory
+int slr_host_alloc(void **p, size_t bytes)
+{
+    if (!p) return SLR_ERR_INVALID_ARG;
+    *p = nullptr;
+    const hipError_t e = hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault);
+    return e == hipSuccess ? SLR_OK : (e == hipErrorOutOfMemory ? SLR_ERR_OOM : SLR_ERR_HIP);
+}
+int slr_host_free(void *p)
+{
+    if (!p) return SLR_OK;
+    return hipHostFree(p) == hipSuccess ? SLR_OK : SLR_ERR_HIP;
 }
 
 int slr_reconstruct_batch(slr_ctx *c, const slr_batch_desc *d, const uint8_t *stack, float *xyz, uint8_t *has, uint8_t *color)

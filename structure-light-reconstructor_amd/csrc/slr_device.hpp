@@ -135,6 +135,14 @@ hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const D
                                   int W, const float *raysL, const float *raysR, float *xyz_sum, uint8_t *count,
                                   hipStream_t s);
 
+// ordered prefix index / compaction of a u8 flag image (kernels_compact.hip): enumeration row-major or column-major over an
+// [h][w] image; index (may be null) gets first + rank for flagged elements and `none` otherwise; with xyz the flagged points
+// are compacted into out_xyz (+ their source positions into out_src).  *total_dev = device address of the flagged count.
+size_t     flag_scan_temp_bytes(size_t n);
+hipError_t launch_flag_scan(const uint8_t *flags, size_t n, int w, int h, int column_major, uint32_t first, uint32_t none,
+                            uint32_t *index, const float *xyz, float *out_xyz, uint32_t *out_src, void *temp,
+                            uint32_t **total_dev, hipStream_t s);
+
 hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8_t *color, int W, int H,
                                int scan_w, int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color,
                                hipStream_t s);

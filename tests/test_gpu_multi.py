@@ -1,0 +1,136 @@
+"""Row 8(e) on the GPU box: the one-process multi-GPU entry of the C ABI (slr_reconstruct_mf_multi: frame f -> ctx f mod n, peer
+copies assemble the cloud), its helpers (ordered prefix index, valid-point compaction) and the torchrun + collective leg of
+bench.py with two ranks.  The box has ONE GPU: several contexts / ranks share device 0 -- the code path is the same, the peer
+copies and the all-gather just do not leave the device."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from util import bits_equal, calib_parts, np_of
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BLACK = 40
+
+
+def test_prefix_index_row_and_column_major(ctx):
+    rng = np.random.default_rng(5)
+    for h, w, p in [(1, 1, 1.0), (3, 5, 0.5), (37, 129, 0.3), (480, 640, 0.7), (1024, 1280, 0.05), (2, 4099, 0.9)]:
+        flags = (rng.random((h, w)) < p).astype(np.uint8) * rng.integers(1, 255, (h, w), dtype=np.uint8)
+        for cm in (False, True):
+            f = flags.T if cm else flags                                   # enumeration order as a flat array
+            rank = np.cumsum(f.reshape(-1) != 0) - (f.reshape(-1) != 0)
+            exp = np.where(f.reshape(-1) != 0, rank + 7, 0xFFFFFFFF).astype(np.uint32).reshape(f.shape)
+            exp = exp.T if cm else exp
+            idx, tot = ctx.prefix_index(flags, column_major=cm, first=7)
+            assert tot == int((flags != 0).sum()) and np.array_equal(idx, exp), (h, w, cm)
+            didx, dtot = ctx.prefix_index(torch.from_numpy(flags).cuda(), column_major=cm, first=7)
+            assert dtot == tot and np.array_equal(didx.cpu().numpy().view(np.uint32), exp)
+
+
+def test_compact_points(ctx):
+    rng = np.random.default_rng(6)
+    for n, p in [(1, 1.0), (1000, 0.5), (300000, 0.2), (4097, 0.0)]:
+        xyz = rng.standard_normal((n, 3)).astype(np.float32)
+        has = (rng.random(n) < p).astype(np.uint8)
+        pts, src = ctx.compact_points(xyz, has)
+        sel = np.flatnonzero(has)
+        assert np.array_equal(src.view(np.uint32), sel.astype(np.uint32)) and bits_equal(pts, xyz[sel])
+        dp, ds = ctx.compact_points(torch.from_numpy(xyz).cuda(), torch.from_numpy(has).cuda())
+        assert bits_equal(np_of(dp), xyz[sel]) and np.array_equal(np_of(ds).view(np.uint32), sel.astype(np.uint32))
+
+
+@pytest.mark.parametrize("n_ctx,n_frames", [(2, 5), (3, 3), (1, 2), (3, 2)])
+def test_multi_ctx_entry_against_the_oracle(slr, oracle, synth, n_ctx, n_frames):
+    W, H = 320, 64
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    maps = [synth.make_rectify_maps(W, H, cam) for cam in range(2)]
+    ctxs = [slr.Context(0) for _ in range(n_ctx)]
+    try:
+        for c in ctxs:
+            c.set_calibration(calib)
+            for cam in range(2):
+                c.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+        frames = [synth.render_mf_stack(W, H, seed=100 + f, noise=2) for f in range(n_frames)]
+        stacks = []
+        for k in range(n_ctx):
+            mine = [frames[f] for f in range(k, n_frames, n_ctx)]
+            stacks.append(torch.stack(mine).cuda().contiguous() if mine else torch.empty((0, 2, 14, H, W), dtype=torch.uint8, device="cuda"))
+        xa, ha = slr.capi.reconstruct_mf_multi(ctxs, stacks, BLACK, True, gather_ctx=n_ctx - 1)
+        camL, camR, Q, T = calib_parts(oracle, calib)
+        for f in range(n_frames):
+            dec = []
+            for cam in range(2):
+                raw = frames[f][cam].numpy()
+                rect = np.stack([oracle.remap_u8(raw[p], maps[cam][0].numpy(), maps[cam][1].numpy()) for p in range(14)])
+                dec.append(oracle.mf_decode(rect, BLACK))
+            exyz, ehas, _ = oracle.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q, T)
+            assert bits_equal(np_of(ha[f]), ehas) and bits_equal(np_of(xa[f]), exyz), f
+        # without assembly: the shards stay on their contexts
+        xs, hs = slr.capi.reconstruct_mf_multi(ctxs, stacks, BLACK, True, gather_ctx=-1)
+        for k in range(n_ctx):
+            for j, f in enumerate(range(k, n_frames, n_ctx)):
+                assert torch.equal(xs[k][j], xa[f]) and torch.equal(hs[k][j], ha[f])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_multi_ctx_entry_fullsize_equals_the_batch_entry(slr, synth):
+    """config 4's shape on what the box has: 4 frames of 4096x3000 over two contexts == slr_reconstruct_mf_batch on one"""
+    W, H = 4096, 3000
+    dev = torch.device("cuda", 0)
+    calib, _ = synth.make_calibration(W, H)
+    maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
+    frames = torch.stack([synth.render_mf_stack(W, H, seed=40 + f, noise=2, device=dev) for f in range(4)])
+    torch.cuda.synchronize()
+    ctxs = [slr.Context(0) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.set_calibration(calib)
+            for cam in range(2):
+                c.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+        ex, eh = ctxs[0].reconstruct_mf_batch(frames, BLACK, True)
+        ctxs[0].synchronize()
+        stacks = [frames[0::2].contiguous(), frames[1::2].contiguous()]
+        xa, ha = slr.capi.reconstruct_mf_multi(ctxs, stacks, BLACK, True, gather_ctx=0)
+        assert torch.equal(ha, eh) and torch.equal(xa, ex)
+        assert 0.2 < eh.float().mean().item() < 1.0
+        # sparse assembly: only the valid points of a frame
+        pts, src = ctxs[1].compact_points(xa[3], ha[3])
+        sel = torch.nonzero(ha[3].reshape(-1)).reshape(-1)
+        assert torch.equal(src.to(torch.int64), sel) and torch.equal(pts, xa[3].reshape(-1, 3)[sel])
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_bench_two_ranks_with_a_collective_on_this_box():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU", frames sharded, one all-gather of
+    the final cloud) with both ranks on device 0.  RCCL first; RCCL refuses two ranks on one device on some builds -- then the
+    same code path runs over gloo, which is what this box can offer."""
+    env = dict(os.environ, SLR_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    last = None
+    for backend, port in (("nccl", "29541"), ("gloo", "29542")):
+        env["SLR_BENCH_BACKEND"] = backend
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2",
+               "--width", "1024", "--height", "512", "--gather", "final", "--traffic", "off", "--cpu-baseline", "0"]
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired as e:
+            last = (backend, "timeout", str(e)[:300])
+            continue
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+            assert d["config"]["frames_per_gpu_per_step"] == 2 and "all-gather" in d["config"]["parallelism"]
+            return
+        last = (backend, r.returncode, r.stderr[-600:])
+    pytest.fail("bench.py --gpus 2 ran with neither RCCL nor gloo on this box: %r" % (last,))
