@@ -235,6 +235,12 @@ int slr_reconstruct_gray(slr_ctx *ctx, const uint8_t *const *planesL, const uint
                          int black_thr, int white_thr, int scan_w, int scan_h,
                          float *xyz_sum, uint8_t *count, slr_mem mem);          /* runReconstruction */
 
+/* slr_reconstruct_mf followed by slr_pointcloud_from_grid without the W x H XYZ grid ever leaving the device: what
+ * MFReconstruct::runReconstruction hands to the application (mfreconstruct.cpp:160-187 -> points3DProjView). */
+int slr_reconstruct_mf_cloud(slr_ctx *ctx, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
+                             int pitch, int W, int H, int black_thr, int rectify, int scan_w, int scan_h,
+                             float *pc_sum, uint8_t *pc_count, slr_mem mem);
+
 /* Device-resident batch fast path (frames of one GPU's shard).  stack = [n_frames][2 cams][14][H][pitch]
  * contiguous u8 in HBM; xyz = [n_frames][H][W][3], has = [n_frames][H][W].  Always SLR_MEM_DEVICE. */
 int slr_reconstruct_mf_batch(slr_ctx *ctx, int n_frames, const uint8_t *stack, int pitch, int W, int H,

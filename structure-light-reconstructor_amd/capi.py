@@ -36,7 +36,7 @@ SYMBOLS = [
     "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_multi", "slr_prefix_index", "slr_compact_points",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_prefix_index", "slr_compact_points",
     "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",

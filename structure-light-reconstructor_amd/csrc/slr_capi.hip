@@ -505,10 +505,13 @@ const char *slr_last_error(const slr_ctx *c) { return c ? c->err.c_str() : "null
 int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
 {
     if (!c || !cal) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    for (int k = 0; k < 2; k++)
+        if (cal->cam[k].fc[0] == 0.0f || cal->cam[k].fc[1] == 0.0f) return fail(c, SLR_ERR_INVALID_ARG, "zero focal length");
+    const DevCamera before[2] = {c->cal.cam[0], c->cal.cam[1]};
+    const bool had = c->has_calib;
     for (int k = 0; k < 2; k++) {
         const slr_camera &s = cal->cam[k];
         DevCamera &d = c->cal.cam[k];
-        if (s.fc[0] == 0.0f || s.fc[1] == 0.0f) return fail(c, SLR_ERR_INVALID_ARG, "zero focal length");
         d.fx = s.fc[0]; d.fy = s.fc[1];                 // utilities.cpp:68-73: f32 widened, ifx = 1./fx in f64
         d.ifx = 1. / d.fx; d.ify = 1. / d.fy;
         d.cx = s.cc[0]; d.cy = s.cc[1];
@@ -526,8 +529,9 @@ int slr_set_calibration(slr_ctx *c, const slr_calib *cal)
                            Q[8] == 0.0 && Q[9] == 0.0 && Q[10] == 0.0 && Q[12] == 0.0 && Q[13] == 0.0) ? 1 : 0;
     }
     c->has_calib = true;
-    c->und_valid = false;
-    c->rays_valid = false;
+    // the per-pixel undistortion / ray tables depend on the cameras only: a new Q or transfer matrix (every scan of a series
+    // brings its own, mfreconstruct.cpp:278-282) keeps them
+    if (!had || memcmp(before, c->cal.cam, sizeof before) != 0) { c->und_valid = false; c->rays_valid = false; }
     return SLR_OK;
 }
 
@@ -910,6 +914,37 @@ int slr_reconstruct_mf(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], 
     SLR_TRY(st.out(xyz, (size_t)W * H * 12, &dx));
     SLR_TRY(st.out(has, (size_t)W * H, &dh));
     SLR_TRY(reconstruct_mf_dev(c, dl, dr, pitch, W, H, black_thr, rectify, (float *)dx, (uint8_t *)dh));
+    return st.finish();
+}
+
+// MFReconstruct::runReconstruction as the application consumes it: the PointCloudImage of the scan (transposed + cropped grid,
+// Q11).  The full-resolution XYZ grid stays on the device: a host caller uploads 2 x 14 planes and downloads scan_w x scan_h x 13
+// bytes instead of W x H x 13.
+int slr_reconstruct_mf_cloud(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
+                             int pitch, int W, int H, int black_thr, int rectify, int scan_w, int scan_h, float *pc_sum,
+                             uint8_t *pc_count, slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !pc_sum || !pc_count) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    for (int i = 0; i < SLR_MF_PLANES; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    if (scan_w <= 0 || scan_h <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bad scan size");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    Stage st(c, mem);
+    const size_t n = (size_t)W * H, nb = (size_t)scan_w * scan_h;
+    const uint8_t *dl[SLR_MF_PLANES], *dr[SLR_MF_PLANES];
+    void *dx, *dh, *ps_, *pc_;
+    SLR_TRY(st.planes(planesL, SLR_MF_PLANES, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, SLR_MF_PLANES, pitch, H, dr));
+    SLR_TRY(get_scratch(c, S_XYZ, n * 12, &dx));
+    SLR_TRY(get_scratch(c, S_HAS, n, &dh));
+    SLR_TRY(st.out(pc_sum, nb * 12, &ps_)); SLR_TRY(st.out(pc_count, nb, &pc_));
+    SLR_TRY(reconstruct_mf_dev(c, dl, dr, pitch, W, H, black_thr, rectify, (float *)dx, (uint8_t *)dh));
+    { ProfScope ps(c, K_PC_FROM_GRID);
+      SLR_HIP(c, launch_pc_from_grid((const float *)dx, (const uint8_t *)dh, nullptr, W, H, scan_w, scan_h, (float *)ps_,
+                                     (uint8_t *)pc_, nullptr, c->stream)); }
     return st.finish();
 }
 

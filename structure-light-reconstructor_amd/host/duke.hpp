@@ -16,6 +16,7 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -45,11 +46,14 @@ struct Matf {                         // cv::Mat CV_32F
 };
 struct Point3f { float x = 0, y = 0, z = 0; };
 
-// cv::imread(path, 0): 8-bit greyscale.  PGM (P5) and PNG (8-bit grey / RGB / RGBA / palette-free, non-interlaced;
-// zlib inflate).  Colour is converted like OpenCV: (R*4899 + G*9617 + B*1868 + 8192) >> 14.
+// cv::imread(path, 0): 8-bit greyscale.  PGM (P5) and PNG (grey / grey+alpha / RGB / RGBA at 8 or 16 bits, non-interlaced or
+// Adam7; chunk CRCs and every size are verified -- image_io.cpp).  Colour is converted like OpenCV:
+// (R*4899 + G*9617 + B*1868 + 8192) >> 14.  Never throws; an unreadable file is an empty image.
 Image8 imread_gray(const std::string &path);
+// the same, decoded straight into a caller buffer of w * h bytes (e.g. page-locked memory); the file must have that size
+bool imread_gray_into(const std::string &path, int w, int h, uint8_t *dst, std::string &err);
 bool imwrite_pgm(const std::string &path, const Image8 &img);
-bool imwrite_png(const std::string &path, const Image8 &img);
+bool imwrite_png(const std::string &path, const Image8 &img, bool adam7 = false);
 // Utilities::exportMat (utilities.cpp:364-378): default ostream precision (6 significant digits, Q14), tab separated
 bool exportMat(const std::string &path, const double *m, int rows, int cols);
 
@@ -167,7 +171,6 @@ private:
     bool EPI;
     stereoRect *sr = nullptr;
     slr_ctx *ctx = nullptr;
-    bool loadCamImgs(int cam, std::vector<Image8> &imgs);
     bool fillCalib(slr_calib &cal);
     std::string scanFolder[2], imgPrefix[2];
     int numberOfImgs = 0, numOfColBits = 0, numOfRowBits = 0;
@@ -183,13 +186,18 @@ public:
     void getParameters(int scansn, int scanw, int scanh, int camw, int camh, int blackt, int whitet,
                        const std::string &savePath);
     bool runReconstruction();
+    // a series of scans of this project, pipelined over two contexts (PNG decode of scan i+1 into page-locked memory while the
+    // GPU works on scan i): sink(sn, cloud) receives every PointCloudImage in order and owns it; false + lastError on failure
+    bool runReconstructionSeries(const std::vector<int> &scan_sns, const std::function<bool(int, PointCloudImage *)> &sink);
     PointCloudImage *points3DProjView;
     std::string imgSuffix = ".png";
     std::string lastError;
     bool camerasLoaded = false;
 private:
     bool loadCameras();
-    bool loadCamImgs(int cam, std::vector<Image8> &imgs);
+    void setScan(int sn);
+    bool configure(slr_ctx *c, int sn);
+    slr_ctx *ctx2 = nullptr;
     int scanSN = 0, numberOfImgs = 14, blackThreshold = 40, whiteThreshold = 0;
     int cameraWidth = 0, cameraHeight = 0, scan_w = 0, scan_h = 0;
     std::string savePath_, calibFolder[2], scanFolder[2], imgPrefix[2];
@@ -198,15 +206,13 @@ private:
     slr_ctx *ctx = nullptr;
 };
 
-// ---- MeshCreator (meshcreator.cpp:16-172) ---------------------------------------------------------------------
+// ---- MeshCreator (meshcreator.cpp:16-172; vertex numbering by slr_prefix_index on the GPU) ----------------------------
 class MeshCreator {
 public:
     explicit MeshCreator(PointCloudImage *in);
-    void exportObjMesh(const std::string &path);
-    void exportPlyMesh(const std::string &path);
+    bool exportObjMesh(const std::string &path);     // false: no GPU context for the vertex numbering, or the file cannot be written
+    bool exportPlyMesh(const std::string &path);
 private:
-    int access(int i, int j) const { return i * h + j; }
-    std::vector<int> pixelNum;
     PointCloudImage *cloud;
     int w, h;
 };

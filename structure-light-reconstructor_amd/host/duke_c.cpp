@@ -2,13 +2,26 @@
 // the body of slr_cli.  duke_run_project mirrors MainWindow::startreconstruct (Duke/mainwindow.cpp:562-652).
 #include <string.h>
 
+#include <memory>
 #include <string>
+#include <vector>
 
 #include "duke.hpp"
 
 using namespace duke;
 
 extern "C" {
+
+static void set_err(char *err, int err_len, const std::string &msg)
+{
+    if (err && err_len > 0) { strncpy(err, msg.c_str(), (size_t)err_len - 1); err[err_len - 1] = 0; }
+}
+
+// every entry point below is a C boundary: no exception may cross it
+#define DUKE_GUARD_BEGIN try {
+#define DUKE_GUARD_END(fail_value, err, err_len)                                                      \
+    } catch (const std::exception &ex) { set_err(err, err_len, std::string("exception: ") + ex.what()); return fail_value; } \
+      catch (...) { set_err(err, err_len, "unknown exception"); return fail_value; }
 
 // mode: 0 = GRAY_ONLY, 1 = GRAY_EPI, 2 = MULTIFREQ_EPI (mainwindow.h:95 codePatternUsed)
 // pc_sum [scan_h][scan_w][3], pc_count [scan_h][scan_w] receive the PointCloudImage (may be NULL); out_ply may be NULL/"".
@@ -17,13 +30,18 @@ int duke_run_project(const char *project, int mode, int sn, int scan_w, int scan
                      int white_thr, int have_color, const char *suffix, const char *out_ply, float *pc_sum,
                      uint8_t *pc_count, uint8_t *pc_color, char *err, int err_len)
 {
+    DUKE_GUARD_BEGIN
+    if (!project || cam_w <= 0 || cam_h <= 0 || scan_w <= 0 || scan_h <= 0 || (long long)cam_w * cam_h > (1ll << 28)) {
+        set_err(err, err_len, "bad argument");
+        return 0;
+    }
     std::string msg;
     PointCloudImage *cloud = nullptr;
-    Reconstruct *reconstructor = nullptr;
-    MFReconstruct *mfr = nullptr;
+    std::unique_ptr<Reconstruct> reconstructor;
+    std::unique_ptr<MFReconstruct> mfr;
     bool ok = false;
     if (mode == 0 || mode == 1) {
-        reconstructor = new Reconstruct(mode == 1);
+        reconstructor.reset(new Reconstruct(mode == 1));
         reconstructor->scanSN = sn;
         if (suffix && *suffix) reconstructor->imgSuffix = suffix;
         reconstructor->getParameters(scan_w, scan_h, cam_w, cam_h, false, have_color != 0, project);
@@ -37,24 +55,76 @@ int duke_run_project(const char *project, int mode, int sn, int scan_w, int scan
         } else reconstructor->lastError = "Load Calibration files failed.";
         msg = reconstructor->lastError;
         cloud = reconstructor->points3DProjView;
-    } else {
-        mfr = new MFReconstruct();
+    } else if (mode == 2) {
+        mfr.reset(new MFReconstruct());
         if (suffix && *suffix) mfr->imgSuffix = suffix;
         mfr->getParameters(sn, scan_w, scan_h, cam_w, cam_h, black_thr, white_thr, project);
         ok = mfr->camerasLoaded && mfr->runReconstruction();
         msg = mfr->lastError.empty() && !mfr->camerasLoaded ? "Load Calibration files failed." : mfr->lastError;
         cloud = mfr->points3DProjView;
-    }
+    } else msg = "mode must be 0 (GRAY_ONLY), 1 (GRAY_EPI) or 2 (MULTIFREQ_EPI)";
     if (ok && cloud) {
         if (pc_sum) memcpy(pc_sum, cloud->points.data(), cloud->points.size() * sizeof(float));
         if (pc_count) memcpy(pc_count, cloud->numOfPointsForPixel.data(), cloud->numOfPointsForPixel.size());
         if (pc_color && !cloud->color.empty()) memcpy(pc_color, cloud->color.data(), cloud->color.size());
-        if (out_ply && *out_ply) { MeshCreator mc(cloud); mc.exportPlyMesh(out_ply); }
+        if (out_ply && *out_ply) {
+            MeshCreator mc(cloud);
+            if (!mc.exportPlyMesh(out_ply)) { ok = false; msg = "cannot write the mesh"; }
+        }
     }
-    if (err && err_len > 0) { strncpy(err, msg.c_str(), (size_t)err_len - 1); err[err_len - 1] = 0; }
-    delete reconstructor;
-    delete mfr;
+    set_err(err, err_len, msg);
     return ok ? 1 : 0;
+    DUKE_GUARD_END(0, err, err_len)
+}
+
+// MULTIFREQ_EPI over scans sn_first .. sn_first + n_scans - 1 of one project, pipelined (MFReconstruct::runReconstructionSeries).
+// pc_sum [n_scans][scan_h][scan_w][3] / pc_count [n_scans][scan_h][scan_w] (may be NULL); ply_prefix (may be NULL/""):
+// <prefix><sn>.ply per scan.  Returns the number of scans completed.
+int duke_run_series(const char *project, int sn_first, int n_scans, int scan_w, int scan_h, int cam_w, int cam_h, int black_thr,
+                    int white_thr, const char *suffix, const char *ply_prefix, float *pc_sum, uint8_t *pc_count, char *err,
+                    int err_len)
+{
+    DUKE_GUARD_BEGIN
+    if (!project || n_scans < 0 || cam_w <= 0 || cam_h <= 0 || scan_w <= 0 || scan_h <= 0 || (long long)cam_w * cam_h > (1ll << 28)) {
+        set_err(err, err_len, "bad argument");
+        return 0;
+    }
+    MFReconstruct mfr;
+    if (suffix && *suffix) mfr.imgSuffix = suffix;
+    mfr.getParameters(sn_first, scan_w, scan_h, cam_w, cam_h, black_thr, white_thr, project);
+    if (!mfr.camerasLoaded) { set_err(err, err_len, "Load Calibration files failed."); return 0; }
+    std::vector<int> sns;
+    for (int i = 0; i < n_scans; i++) sns.push_back(sn_first + i);
+    const size_t cells = (size_t)scan_w * scan_h;
+    int done = 0;
+    const bool ok = mfr.runReconstructionSeries(sns, [&](int sn, PointCloudImage *pc) {
+        std::unique_ptr<PointCloudImage> own(pc);
+        const size_t i = (size_t)(sn - sn_first);
+        if (pc_sum) memcpy(pc_sum + i * cells * 3, pc->points.data(), cells * 12);
+        if (pc_count) memcpy(pc_count + i * cells, pc->numOfPointsForPixel.data(), cells);
+        if (ply_prefix && *ply_prefix) {
+            MeshCreator mc(pc);
+            if (!mc.exportPlyMesh(std::string(ply_prefix) + std::to_string(sn) + ".ply")) return false;
+        }
+        done++;
+        return true;
+    });
+    set_err(err, err_len, ok ? "" : mfr.lastError);
+    return done;
+    DUKE_GUARD_END(0, err, err_len)
+}
+
+// PLY / OBJ export of a cloud handed over as arrays (tests: the file-level parity of MeshCreator)
+int duke_export_mesh(const char *path, int obj, int w, int h, const float *pc_sum, const uint8_t *pc_count)
+{
+    DUKE_GUARD_BEGIN
+    if (!path || !pc_sum || !pc_count || w <= 0 || h <= 0) return 0;
+    PointCloudImage pc(w, h, false);
+    memcpy(pc.points.data(), pc_sum, (size_t)w * h * 12);
+    memcpy(pc.numOfPointsForPixel.data(), pc_count, (size_t)w * h);
+    MeshCreator mc(&pc);
+    return (obj ? mc.exportObjMesh(path) : mc.exportPlyMesh(path)) ? 1 : 0;
+    DUKE_GUARD_END(0, nullptr, 0)
 }
 
 // ---- host-only pieces (no GPU needed) ---------------------------------------------------------------------------
@@ -102,6 +172,8 @@ void duke_init_undistort_rectify_map(const double *M, const double *D, const dou
 int duke_stereo_rect(const char *project, int W, int H, double *R1, double *R2, double *P1, double *P2, double *Q,
                      int16_t *map11, uint16_t *map12, int16_t *map21, uint16_t *map22)
 {
+    DUKE_GUARD_BEGIN
+    if (!project || W <= 0 || H <= 0 || (long long)W * H > (1ll << 28)) return 0;
     stereoRect sr(project, W, H);
     sr.getParameters();
     sr.calParameters();
@@ -114,23 +186,31 @@ int duke_stereo_rect(const char *project, int W, int H, double *R1, double *R2, 
     if (map21) memcpy(map21, sr.map21.data(), sr.map21.size() * 2);
     if (map22) memcpy(map22, sr.map22.data(), sr.map22.size() * 2);
     return 1;
+    DUKE_GUARD_END(0, nullptr, 0)
 }
 
+// png: 0 = PGM, 1 = PNG, 2 = Adam7-interlaced PNG (test input)
 int duke_imwrite(const char *path, const uint8_t *data, int w, int h, int png)
 {
+    DUKE_GUARD_BEGIN
+    if (!path || !data || w <= 0 || h <= 0) return 0;
     Image8 img;
     img.w = w; img.h = h; img.d.assign(data, data + (size_t)w * h);
-    return (png ? imwrite_png(path, img) : imwrite_pgm(path, img)) ? 1 : 0;
+    return (png ? imwrite_png(path, img, png == 2) : imwrite_pgm(path, img)) ? 1 : 0;
+    DUKE_GUARD_END(0, nullptr, 0)
 }
 
 int duke_imread(const char *path, uint8_t *data, int cap, int *w, int *h)
 {
+    DUKE_GUARD_BEGIN
+    if (!path || !w || !h) return 0;
     Image8 img = imread_gray(path);
     if (img.empty()) return 0;
     *w = img.w; *h = img.h;
-    if ((size_t)cap < img.d.size()) return -1;
+    if (!data || (size_t)cap < img.d.size()) return -1;
     memcpy(data, img.d.data(), img.d.size());
     return 1;
+    DUKE_GUARD_END(0, nullptr, 0)
 }
 
 int duke_export_mat(const char *path, const double *m, int rows, int cols) { return exportMat(path, m, rows, cols) ? 1 : 0; }

@@ -225,3 +225,100 @@ def pointcloud_from_grid(xyz, has, scan_w, scan_h):   # C9 / Q11: camera (row i,
     s[:ww, :hh] = np.where(sub[..., None], xyz[:hh, :ww], f32(0)).transpose(1, 0, 2)
     c[:ww, :hh] = sub.T
     return s, c
+
+
+# ---------------------------------------------------------------------------------------------------------
+# cv::stereoRectify (flags = 0, alpha = -1) -- independent fp64 transcription of the published algorithm (OpenCV 2.4
+# calib3d: cvStereoRectify / cvRodrigues2 / cvUndistortPoints / cvProjectPoints2), with LAPACK's SVD for the
+# re-orthonormalisation step of Rodrigues(matrix).  Checks structure-light-reconstructor_amd/host/calib.cpp (row f4).
+# ---------------------------------------------------------------------------------------------------------
+def rodrigues_to_matrix(r):
+    r = np.asarray(r, np.float64)
+    theta = np.sqrt((r * r).sum())
+    if theta < np.finfo(np.float64).eps:
+        return np.eye(3)
+    k = r / theta
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(theta) * np.eye(3) + (1 - np.cos(theta)) * np.outer(k, k) + np.sin(theta) * K
+
+
+def rodrigues_to_vector(R):
+    U, _, Vt = np.linalg.svd(np.asarray(R, np.float64))
+    R = U @ Vt                                           # nearest rotation
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.sqrt((v * v).sum() * 0.25)
+    c = np.clip((np.trace(R) - 1) * 0.5, -1.0, 1.0)
+    theta = np.arccos(c)
+    if s < 1e-5:
+        if c > 0:
+            return np.zeros(3)
+        r = np.sqrt(np.maximum((np.diag(R) + 1) * 0.5, 0))
+        r[1] *= -1 if R[0, 1] < 0 else 1
+        r[2] *= -1 if R[0, 2] < 0 else 1
+        if abs(r[0]) < abs(r[1]) and abs(r[0]) < abs(r[2]) and (R[1, 2] > 0) != (r[1] * r[2] > 0):
+            r[2] = -r[2]
+        return r * (theta / np.sqrt((r * r).sum()))
+    return v * (theta / (2 * s))
+
+
+def undistort_normalized(u, v, A, k):
+    """cvUndistortPoints of one pixel with identity R and P: 5 fixed-point iterations, result narrowed to f32"""
+    x0 = x = (u - A[0, 2]) / A[0, 0]
+    y0 = y = (v - A[1, 2]) / A[1, 1]
+    for _ in range(5):
+        r2 = x * x + y * y
+        icd = 1.0 / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        x, y = (x0 - dx) * icd, (y0 - dy) * icd
+    return np.float64(np.float32(x)), np.float64(np.float32(y))
+
+
+def stereo_rectify(M1, D1, M2, D2, R, T, nx, ny):
+    """-> R1, R2, P1 (3x4), P2 (3x4), Q (4x4)"""
+    M1, M2, R, T = (np.asarray(a, np.float64) for a in (M1, M2, R, T))
+    D1, D2 = np.asarray(D1, np.float64).reshape(-1), np.asarray(D2, np.float64).reshape(-1)
+    T = T.reshape(3)
+    r_r = rodrigues_to_matrix(-0.5 * rodrigues_to_vector(R))
+    t = r_r @ T
+    idx = 0 if abs(t[0]) > abs(t[1]) else 1
+    c, nt = t[idx], np.sqrt((t * t).sum())
+    uu = np.zeros(3)
+    uu[idx] = 1.0 if c > 0 else -1.0
+    ww = np.cross(t, uu)
+    nw = np.sqrt((ww * ww).sum())
+    if nw > 0:
+        ww = ww * (np.arccos(abs(c) / nt) / nw)
+    wR = rodrigues_to_matrix(ww)
+    R1, R2 = wR @ r_r.T, wR @ r_r
+    t = R2 @ T
+    fc_new = np.inf
+    for A, D in ((M1, D1), (M2, D2)):
+        fc = A[idx ^ 1, idx ^ 1]
+        if D[0] < 0:
+            fc = fc * (1 + D[0] * (nx * nx + ny * ny) / (4 * fc * fc))
+        fc_new = min(fc_new, fc)
+    cc = np.zeros((2, 2))
+    for kcam, (A, D, Rk) in enumerate(((M1, D1, R1), (M2, D2, R2))):
+        acc = np.zeros(2)
+        for i in range(4):
+            j = 0 if i < 2 else 1
+            px, py = undistort_normalized(np.float64(np.float32((i % 2) * (nx - 1))), np.float64(np.float32(j * (ny - 1))), A, D)
+            X = Rk @ np.array([px, py, 1.0])
+            acc += np.array([np.float32(fc_new * X[0] / X[2]), np.float32(fc_new * X[1] / X[2])], np.float64)
+        cc[kcam] = [(nx - 1) // 2 - acc[0] / 4, (ny - 1) // 2 - acc[1] / 4]
+    if idx == 0:
+        cc[:, 1] = (cc[0, 1] + cc[1, 1]) * 0.5
+    else:
+        cc[:, 0] = (cc[0, 0] + cc[1, 0]) * 0.5
+    P1 = np.zeros((3, 4)); P2 = np.zeros((3, 4))
+    P1[0, 0] = P1[1, 1] = P2[0, 0] = P2[1, 1] = fc_new
+    P1[0, 2], P1[1, 2], P2[0, 2], P2[1, 2] = cc[0, 0], cc[0, 1], cc[1, 0], cc[1, 1]
+    P1[2, 2] = P2[2, 2] = 1
+    P2[idx, 3] = t[idx] * fc_new
+    Q = np.zeros((4, 4))
+    Q[0, 0] = Q[1, 1] = 1
+    Q[0, 3], Q[1, 3], Q[2, 3] = -cc[0, 0], -cc[0, 1], fc_new
+    Q[3, 2] = -1.0 / t[idx]
+    Q[3, 3] = ((cc[0, 0] - cc[1, 0]) if idx == 0 else (cc[0, 1] - cc[1, 1])) / t[idx]
+    return R1, R2, P1, P2, Q

@@ -104,6 +104,63 @@ def test_png_and_pgm_io(host, tmp_path):
     assert host.duke_imread(str(tmp_path / "nope.png").encode(), _p(out), out.size, C.byref(w), C.byref(h)) == 0
 
 
+def test_png_decoder_rejects_what_it_cannot_trust(host, tmp_path):
+    """chunk CRCs, announced sizes and the inflated length are verified; interlaced (Adam7), 16-bit and colour PNGs decode;
+    nothing here may crash or throw through the C boundary"""
+    rng = np.random.default_rng(9)
+    w, h = C.c_int(0), C.c_int(0)
+
+    def read(path, shape):
+        out = np.zeros(shape, np.uint8)
+        return host.duke_imread(str(path).encode(), _p(out), out.size, C.byref(w), C.byref(h)), out
+    for (ww, hh) in ((53, 37), (1, 1), (3, 2), (8, 8), (9, 17), (5, 1), (1, 6)):
+        img = rng.integers(0, 256, size=(hh, ww), dtype=np.uint8)
+        assert host.duke_imwrite(str(tmp_path / "i.png").encode(), _p(img), ww, hh, 2) == 1          # Adam7
+        rc, out = read(tmp_path / "i.png", (hh, ww))
+        assert rc == 1 and (w.value, h.value) == (ww, hh) and np.array_equal(out, img), (ww, hh)
+    img = rng.integers(0, 256, size=(21, 34), dtype=np.uint8)
+    good = _png_bytes(img, [4, 1, 3])
+    open(tmp_path / "ok.png", "wb").write(good)
+    assert read(tmp_path / "ok.png", img.shape)[0] == 1
+    bad = bytearray(good); bad[60] ^= 0x40                                                           # a bit flip inside IDAT
+    open(tmp_path / "crc.png", "wb").write(bytes(bad))
+    assert read(tmp_path / "crc.png", img.shape)[0] == 0
+    open(tmp_path / "cut.png", "wb").write(good[:len(good) // 2])
+    assert read(tmp_path / "cut.png", img.shape)[0] == 0
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    sig = b"\x89PNG\r\n\x1a\n"
+    huge = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(b"\0")) + chunk(b"IEND", b"")
+    open(tmp_path / "huge.png", "wb").write(huge)
+    assert read(tmp_path / "huge.png", (4, 4))[0] == 0
+    raw = b"".join(b"\0" + bytes(img[y]) for y in range(img.shape[0]))
+    short = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 34, 22, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    open(tmp_path / "short.png", "wb").write(short)                                                  # IHDR announces one row more
+    assert read(tmp_path / "short.png", (22, 34))[0] == 0
+    trailing = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 34, 21, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw) + b"junk") + chunk(b"IEND", b"")
+    open(tmp_path / "trail.png", "wb").write(trailing)                                               # bytes behind the zlib stream
+    rc, out = read(tmp_path / "trail.png", img.shape)
+    assert rc == 1 and np.array_equal(out, img)
+    # 16-bit grey keeps the high byte; RGB goes through OpenCV's fixed-point grey conversion
+    g16 = rng.integers(0, 65536, size=(7, 11)).astype(">u2")
+    raw16 = b"".join(b"\0" + g16[y].tobytes() for y in range(7))
+    open(tmp_path / "g16.png", "wb").write(sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 11, 7, 16, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw16)) + chunk(b"IEND", b""))
+    rc, out = read(tmp_path / "g16.png", (7, 11))
+    assert rc == 1 and np.array_equal(out, (g16.astype(np.uint16) >> 8).astype(np.uint8))
+    rgb = rng.integers(0, 256, size=(6, 9, 3), dtype=np.uint8)
+    rawc = b"".join(b"\0" + rgb[y].tobytes() for y in range(6))
+    open(tmp_path / "rgb.png", "wb").write(sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 9, 6, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rawc)) + chunk(b"IEND", b""))
+    rc, out = read(tmp_path / "rgb.png", (6, 9))
+    exp = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    assert rc == 1 and np.array_equal(out, exp)
+    # PGM with an absurd header
+    open(tmp_path / "bad.pgm", "wb").write(b"P5\n99999999999 3\n255\n" + b"x" * 10)
+    assert read(tmp_path / "bad.pgm", (4, 4))[0] == 0
+    open(tmp_path / "cut.pgm", "wb").write(b"P5\n10 10\n255\n" + b"x" * 50)
+    assert read(tmp_path / "cut.pgm", (10, 10))[0] == 0
+
+
 def test_map_builder_matches_oracle(host, oracle):
     W, H = 96, 64
     M = np.array([[110.0, 0, 47.3], [0, 112.0, 31.8], [0, 0, 1]])
@@ -189,6 +246,29 @@ def _oracle_calib_from_project(O, proj):
     return cams
 
 
+@pytest.mark.parametrize("th,T", [(0.01, (-120.0, 0.8, -1.5)), (0.2, (-80.0, -3.0, 6.0)), (-0.05, (2.0, 95.0, -4.0)), (0.0, (60.0, 0.0, 0.0))])
+def test_stereo_rectify_against_the_numpy_model(host, synth, tmp_path, th, T):
+    """row f4: the C++ restatement of cv::stereoRectify (one-sided Jacobi SVD in Rodrigues(matrix)) against the independent fp64
+    NumPy transcription with LAPACK's SVD, to 1e-12; horizontal and vertical baselines, zero rotation"""
+    import np_model
+    W, H = 128, 96
+    calib, _ = synth.make_calibration(W, H)
+    proj = _write_project(host, tmp_path, synth, W, H, calib, [np.zeros((0, H, W), np.uint8)] * 2)
+    ax = np.array([0.3, 1.0, -0.2]); ax /= np.linalg.norm(ax)
+    Rm = np_model.rodrigues_to_matrix(ax * th) @ (np.eye(3) + 3e-7 * np.arange(9).reshape(3, 3))     # not exactly orthonormal
+    for name, arr in (("calib/R_stereo.txt", Rm), ("calib/T_stereo.txt", np.array(T).reshape(3, 1))):
+        a = np.ascontiguousarray(arr, np.float64)
+        assert host.duke_export_mat(os.path.join(proj, name).encode(), _p(a), a.shape[0], a.shape[1]) == 1
+    R1, R2, P1, P2, Q = np.zeros(9), np.zeros(9), np.zeros(12), np.zeros(12), np.zeros(16)
+    assert host.duke_stereo_rect(proj.encode(), W, H, _p(R1), _p(R2), _p(P1), _p(P2), _p(Q), None, None, None, None) == 1
+    rd = lambda rel, shape: _float_text(os.path.join(proj, rel), shape).astype(np.float64)
+    e = np_model.stereo_rectify(rd("calib/left/cam_stereo.txt", (3, 3)), rd("calib/left/distortion_stereo.txt", (5,)),
+                                rd("calib/right/cam_stereo.txt", (3, 3)), rd("calib/right/distortion_stereo.txt", (5,)),
+                                rd("calib/R_stereo.txt", (3, 3)), rd("calib/T_stereo.txt", (3,)), W, H)
+    for got, exp in zip((R1.reshape(3, 3), R2.reshape(3, 3), P1.reshape(3, 4), P2.reshape(3, 4), Q.reshape(4, 4)), e):
+        assert np.allclose(got, exp, rtol=1e-12, atol=1e-12), (got, exp)
+
+
 def test_stereo_rectify_sanity(host, synth, tmp_path):
     W, H = 128, 96
     calib, _ = synth.make_calibration(W, H)
@@ -252,9 +332,119 @@ def test_project_directory_through_the_host_mirror(host, oracle, synth, tmp_path
             assert np.array_equal(pc_col[..., 0], ecol) and np.array_equal(pc_col[..., 2], ecol)
     assert np.array_equal(pc_cnt, ec) and bits_equal(pc_sum, es)
     assert ec.sum() > 50
-    # PLY written by MeshCreator::exportPlyMesh: header vertex count == number of cells with a point
-    head = open(ply).read(400).split("\n")
-    assert head[0] == "ply" and head[2] == "element vertex %d" % int((ec > 0).sum())
+    # PLY written by MeshCreator::exportPlyMesh: the whole file against the format spec restated in Python
+    assert open(ply).read() == _expected_ply(es, ec, ecol if mode == 1 else None)
+
+
+def _fmt(v):
+    return "%g" % float(v)
+
+
+def _cloud_points(pc_sum, pc_cnt):
+    """PointCloudImage::getPoint: f32(f64(sum) / f64(f32(count))) per component"""
+    return (pc_sum.astype(np.float64) / pc_cnt.astype(np.float32).astype(np.float64)[..., None]).astype(np.float32)
+
+
+def _mesh_numbers(pc_cnt, first):
+    h, w = pc_cnt.shape
+    ids = np.full((h, w), -1, np.int64)
+    k = first
+    for i in range(w):
+        for j in range(h):
+            if pc_cnt[j, i]:
+                ids[j, i] = k
+                k += 1
+    return ids, k - first
+
+
+def _mesh_faces(ids, first):
+    h, w = ids.shape
+    ok = lambda i, j: 0 <= i < w and 0 <= j < h and ids[j, i] >= 0 and not (first == 0 and ids[j, i] == 0)
+    out = []
+    for i in range(w):
+        for j in range(h):
+            if ok(i, j) and ok(i + 1, j):
+                if ok(i, j + 1):
+                    out.append((ids[j, i], ids[j, i + 1], ids[j + 1, i]))
+                if ok(i + 1, j - 1):
+                    out.append((ids[j, i], ids[j - 1, i + 1], ids[j, i + 1]))
+    return out
+
+
+def _expected_ply(pc_sum, pc_cnt, col=None):
+    """meshcreator.cpp:67-166 as a format: vertices column by column numbered from 0 (number 0 can never be a face corner),
+    colour 100 100 100 without a colour image, two triangles per pixel over the right / lower / upper-right neighbours"""
+    ids, n = _mesh_numbers(pc_cnt, 0)
+    faces = _mesh_faces(ids, 0)
+    pts = _cloud_points(pc_sum, np.maximum(pc_cnt, 1))
+    h, w = pc_cnt.shape
+    lines = ["ply", "format ascii 1.0", "element vertex %d" % n, "property float x", "property float y", "property float z",
+             "property uchar red", "property uchar green", "property uchar blue", "element face %d" % len(faces),
+             "property list uchar int vertex_indices", "end_header"]
+    for i in range(w):
+        for j in range(h):
+            if pc_cnt[j, i]:
+                c = 100 if col is None else int(round(float(col[j, i]) / float(np.float32(pc_cnt[j, i]))))
+                lines.append("%s %s %s %d %d %d" % (_fmt(pts[j, i, 0]), _fmt(pts[j, i, 1]), _fmt(pts[j, i, 2]), c, c, c))
+    lines += ["3 %d %d %d" % f for f in faces]
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.gpu
+def test_mesh_files_against_the_format_spec(host, tmp_path):
+    """row f2: PLY and OBJ of random clouds, byte for byte -- vertex order, numbering from 0 / 1, the vertex-0 sentinel of the PLY
+    numbering, face winding, borders, an empty cloud"""
+    rng = np.random.default_rng(11)
+    for (w, h, p) in ((7, 5, 0.7), (40, 33, 0.5), (64, 64, 0.97), (3, 3, 0.0), (1, 9, 1.0), (130, 2, 0.8)):
+        cnt = (rng.random((h, w)) < p).astype(np.uint8) * rng.integers(1, 4, (h, w)).astype(np.uint8)
+        if p >= 0.5:
+            cnt[0, 0] = 2                                   # vertex 0 exists and has usable neighbours: the sentinel matters
+            cnt[0, 1 % w] = 1; cnt[1 % h, 0] = 1
+        s = (rng.standard_normal((h, w, 3)) * 100).astype(np.float32)
+        ply, obj = str(tmp_path / "m.ply"), str(tmp_path / "m.obj")
+        assert host.duke_export_mesh(ply.encode(), 0, w, h, _p(s), _p(cnt)) == 1
+        assert host.duke_export_mesh(obj.encode(), 1, w, h, _p(s), _p(cnt)) == 1
+        assert open(ply).read() == _expected_ply(s, cnt), (w, h)
+        ids, n = _mesh_numbers(cnt, 1)
+        pts = _cloud_points(s, np.maximum(cnt, 1))
+        lines = ["v %s %s %s" % tuple(_fmt(x) for x in pts[j, i]) for i in range(w) for j in range(h) if cnt[j, i]]
+        lines += ["f %d/%d %d/%d %d/%d" % (a, a, b, b, c, c) for a, b, c in _mesh_faces(ids, 1)]
+        assert open(obj).read() == ("\n".join(lines) + "\n" if lines else ""), (w, h)
+        if p >= 0.5 and w > 1 and h > 1:
+            assert len(_mesh_faces(_mesh_numbers(cnt, 0)[0], 0)) < len(_mesh_faces(ids, 1))          # the PLY lost vertex 0's faces
+
+
+@pytest.mark.gpu
+def test_scan_series_is_pipelined_and_identical_to_single_scans(host, synth, tmp_path):
+    """row f1: MFReconstruct::runReconstructionSeries (PNG decode into page-locked memory, two contexts with SLR_OPT_ASYNC_HOST,
+    decode of scan i+1 overlapping the GPU work of scan i) == one duke_run_project per scan"""
+    W, H, scan_w, scan_h = 320, 96, 200, 340
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    n = 4
+    proj = None
+    for sn in range(n):
+        st = synth.render_mf_stack(W, H, seed=70 + sn).numpy()
+        proj = _write_project(host, tmp_path, synth, W, H, calib, st, sn=sn)
+    for sn in (1, 2, 3):                                     # every scan after the first brings its transfer matrix (mfreconstruct.cpp:278-282)
+        Tm = np.array([[1, 0, 0, 5.0 * sn], [0, 1, 0, -2.0], [0, 0, 1, 0.5]], np.float64)
+        assert host.duke_export_mat(os.path.join(proj, "scan/transfer_mat%d.txt" % sn).encode(), _p(Tm), 3, 4) == 1
+    err = C.create_string_buffer(512)
+    ss = np.zeros((n, scan_h, scan_w, 3), np.float32)
+    sc = np.zeros((n, scan_h, scan_w), np.uint8)
+    pre = os.path.join(proj, "reconstruction", "s")
+    assert host.duke_run_series(proj.encode(), 0, n, scan_w, scan_h, W, H, 40, 0, b".png", pre.encode(), _p(ss), _p(sc), err, 512) == n, err.value
+    for sn in range(n):
+        es = np.zeros((scan_h, scan_w, 3), np.float32)
+        ec = np.zeros((scan_h, scan_w), np.uint8)
+        ply = os.path.join(proj, "reconstruction", "one%d.ply" % sn)
+        assert host.duke_run_project(proj.encode(), 2, sn, scan_w, scan_h, W, H, 40, 0, 0, b".png", ply.encode(), _p(es), _p(ec), None, err, 512) == 1
+        assert np.array_equal(sc[sn], ec) and bits_equal(ss[sn], es), sn
+        assert open(pre + "%d.ply" % sn).read() == open(ply).read()
+        assert ec.sum() > 50
+    assert not bits_equal(ss[0], ss[1])
+    # a missing scan stops the series where the reference's loop would
+    assert host.duke_run_series(proj.encode(), 2, 4, scan_w, scan_h, W, H, 40, 0, b".png", None, None, None, err, 512) == 2
+    assert b"not found" in err.value
 
 
 @pytest.mark.gpu
