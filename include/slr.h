@@ -122,6 +122,13 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * the decode, 1 (double buffer) or 2 (triple buffer). */
 #define SLR_OPT_RECT_DMA_SHAPE 6
 #define SLR_OPT_RECT_DMA_DEPTH 7
+/* Test knobs (results never change).  SLR_OPT_DEBUG_RECT_RESIDENT: n > 0 = run the persistent fused decodes on n workgroups
+ * (many tiles per workgroup), 0 = as many as are resident.  SLR_OPT_DEBUG_FLAGS: bit 0 = fused decode reads the caller's map
+ * entries instead of the digest, bit 1 = per-plane pointers instead of one buffer descriptor.  SLR_OPT_DEBUG_K4_STOP exists only
+ * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
+#define SLR_OPT_DEBUG_RECT_RESIDENT 8
+#define SLR_OPT_DEBUG_FLAGS 9
+#define SLR_OPT_DEBUG_K4_STOP 10
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */
@@ -191,7 +198,8 @@ int slr_mf_triangulate_rows(slr_ctx *ctx, const float *phaseL, const uint8_t *va
                             float *xyz, uint8_t *has, int32_t *match_k, slr_mem mem);
 
 /* ---- K5: Reconstruct::triangulation_ge (reconstruct.cpp:555-611).  whiteL/whiteR: rectified white planes
- * (pitch W) or NULL; color [H][W] u8 grey or NULL (haveColor, reconstruct.cpp:597-601). */
+ * (pitch W) or NULL; color [H][W] u8 grey or NULL (haveColor, reconstruct.cpp:597-601).  Codes are Gray-decoded projector
+ * columns in [0, 65535] (SLR_MAX_GRAY_BITS); a pixel whose code lies outside that range is treated as having no code. */
 int slr_ge_triangulate(slr_ctx *ctx, const int32_t *codeL, const uint8_t *validL,
                        const int32_t *codeR, const uint8_t *validR, int W, int H,
                        const uint8_t *whiteL, const uint8_t *whiteR,

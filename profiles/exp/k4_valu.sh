@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 2): the stop hook is compiled only into -DSLR_DEBUG_HOOKS builds: make -C structure-light-reconstructor_amd/csrc clean all CXXFLAGS+=-DSLR_DEBUG_HOOKS
 # VALU / LDS instruction counts of the binned K4 per phase (SLR_DEBUG_K4_STOP ablation), per pixel at 4096x3000
 REPO=$PWD; export TMPDIR=/tmp; cd /tmp
 cat > /tmp/k4drv.py <<PY

@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE (round 2): the stop hook is compiled only into -DSLR_DEBUG_HOOKS builds: make -C structure-light-reconstructor_amd/csrc clean all CXXFLAGS+=-DSLR_DEBUG_HOOKS
 # K4 phase ablation: SLR_DEBUG_K4_STOP=N makes the indexed match kernels return after phase N
 # binned form: 1 loads + histogram clear, 4 histogram + scan + scatter, 5 queries, 0 everything
 # sorted form: 1 loads+keys, 2 sort, 3 run heads + compaction, 4 bin index, 5 queries, 0 everything

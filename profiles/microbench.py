@@ -17,6 +17,8 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 dev = torch.device("cuda", 0)
 ctx = slr.Context(0)
+if os.environ.get("SLR_DEBUG_K4_STOP"):     # phase ablation: needs a -DSLR_DEBUG_HOOKS build of libslr_hip.so (profiles/k4_stages.sh)
+    ctx.set_option(slr.capi.OPT_DEBUG_K4_STOP, int(os.environ["SLR_DEBUG_K4_STOP"]))
 calib, _ = synth.make_calibration(W, H)
 ctx.set_calibration(calib)
 maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]

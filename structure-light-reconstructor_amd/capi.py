@@ -22,6 +22,9 @@ OPT_RECT_DECODE_ALGO = 3       # fused rectify+decode: 0 auto (5, else 6), 1 dir
 OPT_RECT_DMA_SHAPE = 6         # tile / threads of form 7 (LDS-DMA fused decode): 0 = 256x16/512, 1 = 256x8/512, 2 = 256x8/256,
                                # 3 = 128x16/512, 4 = 128x8/256, 5 = 256x4/256, 6 = 128x16/256
 OPT_RECT_DMA_DEPTH = 7         # phases of LDS-DMA in flight ahead of the decode: 1 or 2
+OPT_DEBUG_RECT_RESIDENT = 8    # tests: workgroups of the persistent fused decodes (0 = resident set)
+OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form
+OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()
 OPT_MF_DECODE_VEC = 2          # 0 auto, 4 / 8 / 16 pixels per thread in the unfused K2 kernel

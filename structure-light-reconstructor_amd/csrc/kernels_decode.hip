@@ -1117,8 +1117,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
             ring_cache[dev & 63] = per_cu * cus;
         }
-        const char *dbgr = getenv("SLR_DEBUG_RECT_RESIDENT");
-        const int res = (dbgr && atoi(dbgr) > 0 ? atoi(dbgr) : ring_cache[dev & 63]) / njobs;
+        const int res = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : ring_cache[dev & 63]) / njobs;
         int nbx = res / 8 > 0 ? res / 8 : 1;
         const int R = (tiles_y8 + 7) / 8;                    // tile rows per XCD band
         if (nbx > R * tiles_x) nbx = R * tiles_x;
@@ -1143,7 +1142,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     j.j[0] = jobs[0]; j.j[1] = jobs[njobs - 1];
     for (int jq = 0; jq < 2; jq++) {                      // the tiled map copy lives behind the box tables (launch_tile_boxes)
         const char *basep = reinterpret_cast<const char *>(j.j[jq].boxes);
-        j.j[jq].pk_t = mid && !wide && !getenv("SLR_DEBUG_RECT_NO_TILED_MAP") ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
+        j.j[jq].pk_t = mid && !wide && !tl_debug.no_tiled_map ? reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) : nullptr;
         if (wide8) j.j[jq].pk_t = reinterpret_cast<const unsigned *>(basep + tiled_map_offset(W, H)) + tile_count(W, H, kMidTileH) * 512;
     }
     j.j[0].boxes += box_off; j.j[1].boxes += box_off;
@@ -1158,7 +1157,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         j.j[jq].plane_stride = ok ? (unsigned)st : 0u;
         strided = strided && ok;
     }
-    if (getenv("SLR_DEBUG_RECT_NO_BUFFER")) strided = false;   // tests: force the pointer form
+    if (tl_debug.no_buffer_form) strided = false;         // tests: force the pointer form
     static int resident_cache[64][4][2] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1181,8 +1180,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
     }
     const int resident_blocks = resident_slot;
     const int T = tiles_x * tiles_yy, per = (T + 7) / 8;
-    const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
-    const int res = (dbg && atoi(dbg) > 0 ? atoi(dbg) : resident_blocks) / njobs;
+    const int res = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : resident_blocks) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = res / 8 < per ? res / 8 : per;
     if (nbx < 1) nbx = 1;
     const dim3 grid(8u * (unsigned)nbx * (unsigned)njobs);
@@ -1238,7 +1236,9 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
         return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
     }
     if (map_xy) {
-        const bool vec = (W % 4 == 0);
+        // the 4-pixel form stores 16-byte phase vectors and loads the map entries of 4 pixels as vectors
+        const bool vec = (W % 4 == 0) && ((uintptr_t)phase % 16 == 0) && (!valid || (uintptr_t)valid % 4 == 0) &&
+                         ((uintptr_t)map_xy % 16 == 0) && ((uintptr_t)map_frac % 8 == 0);
         if (vec) SLR_LAUNCH(mf_rect_decode_kernel<4>, dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
                                     pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
         else     SLR_LAUNCH(mf_rect_decode_kernel<1>, dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
@@ -1551,7 +1551,7 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
         const unsigned blocks = ((unsigned)(tiles_x * tiles_y) + 7u) & ~7u;
         const int4 *boxes = (const int4 *)tile_boxes + tile_count(W, H, kTileH) + (mid ? tile_count(W, H, kGrayTileH) : 0);
         long long st = nplanes > 1 ? (long long)(pl.p[1] - pl.p[0]) : 0;
-        bool strided = st >= (long long)H * pitch && st * nplanes < (1ll << 31) && !getenv("SLR_DEBUG_RECT_NO_BUFFER");
+        bool strided = st >= (long long)H * pitch && st * nplanes < (1ll << 31) && !tl_debug.no_buffer_form;
         for (int i = 2; i < nplanes && strided; i++) strided = (long long)(pl.p[i] - pl.p[0]) == st * i;
 #define SLR_GRAY_LDS(TH_, S_)                                                                                          \
         SLR_LAUNCH((gray_rect_decode_lds_kernel<TH_, S_>), dim3(blocks), dim3(256), (size_t)budget + 16, s, pl,     \

@@ -787,8 +787,12 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 {
     const float2 *undL = (const float2 *)undL_xy;
     if (algo != 1 && W <= 256 * 32) {
-        const char *dbg = getenv("SLR_DEBUG_K4_STOP");
-        const int vec_ok = ((dbg ? atoi(dbg) : 0) << 8) | (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
+#ifdef SLR_DEBUG_HOOKS
+        const int k4_stop = tl_debug.k4_stop;                // phase ablation (profiles/k4_stages.sh): outputs are NOT written
+#else
+        const int k4_stop = 0;
+#endif
+        const int vec_ok = (k4_stop << 8) | (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
                            ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
 #define SLR_SORTED(BLOCK, IPT)                                                                                     \
@@ -866,7 +870,9 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
         const int k = threadIdx.x * IPT + i;
         // (validR == null: the Gray decode was launched without a valid plane, code -1 marks the invalid pixels)
         const int cr = k < W ? codeR[base + k] : -1;
-        keys[i] = (k < W && (validR ? validR[base + k] != 0 : cr >= 0)) ? (((unsigned)cr << 16) | (unsigned)k) : 0xFFFFFFFFu;
+        // codes are Gray-decoded projector columns: [0, 65535] (SLR_MAX_GRAY_BITS = 16, include/slr.h).  Anything else cannot
+        // be packed next to the column and is treated as "no code" instead of aliasing another one.
+        keys[i] = (k < W && (validR ? validR[base + k] != 0 : true) && (unsigned)cr <= 0xFFFFu) ? (((unsigned)cr << 16) | (unsigned)k) : 0xFFFFFFFFu;
     }
     for (int t = threadIdx.x; t < TC; t += 256) first[t] = 0xFFFFu;
     Sort(sh.sort).Sort(keys, 16, 32);
@@ -911,6 +917,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
     for (int i = 0; i < IPT; i++) {
         const int j = j0 + i;
         cl[i] = (j < W && (!validL || validL[base + j])) ? codeL[base + j] : -1;   // (null validL: invalid pixels hold -1)
+        if ((unsigned)cl[i] > 0xFFFFu) cl[i] = -1;                                // outside [0, 65535]: no code (see the keys above)
     }
     int ks_in = 0, lm = -1, fm = 0x7FFFFFFF;       // incoming kstart, last and first match of this thread
     bool dirty = true;

@@ -605,8 +605,7 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int T = tiles_x * tiles_y, per = (T + 7) / 8;
-    const char *dbg = getenv("SLR_DEBUG_RECT_RESIDENT");  // tests: few workgroups -> many tiles per workgroup
-    const int r = (dbg && atoi(dbg) > 0 ? atoi(dbg) : res) / njobs;
+    const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, lut,

@@ -38,7 +38,7 @@ struct ProfRec { hipEvent_t a, b; int id; };
 
 }  // namespace
 
-namespace slr { thread_local hipEvent_t tl_prof_start = nullptr, tl_prof_stop = nullptr; }
+namespace slr { thread_local hipEvent_t tl_prof_start = nullptr, tl_prof_stop = nullptr; thread_local DebugKnobs tl_debug; }
 
 struct slr_ctx {
     int device = 0;
@@ -55,6 +55,7 @@ struct slr_ctx {
     void *d_dma_tiles[2] = {nullptr, nullptr};  // boxes + map digest of the LDS-DMA fused decode (launch_dma_tiles), or null
     unsigned dma_nofit[2] = {0, 0};             // tiles whose box does not fit that form
     int dma_shape_built[2] = {-1, -1};          // SLR_OPT_RECT_DMA_SHAPE the tables were built for
+    DebugKnobs debug;              // SLR_OPT_DEBUG_*
     int opt_dma_shape = 1, opt_dma_depth = 1;   // SLR_OPT_RECT_DMA_SHAPE / _DEPTH (256x8 tiles on 512 threads measured best)
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
@@ -122,6 +123,7 @@ bool dma_form_wanted(const slr_ctx *c, int a, int b)
 
 int use_device(slr_ctx *c)
 {
+    tl_debug = c->debug;                                     // every entry point passes here before it launches anything
     SLR_HIP(c, hipSetDevice(c->device));
     return SLR_OK;
 }
@@ -257,6 +259,7 @@ int check_dims(slr_ctx *c, int W, int H, int pitch)
     if (W <= 0 || H <= 0 || pitch < W) return fail(c, SLR_ERR_INVALID_ARG, "bad image size/pitch");
     if ((long long)W * H >= (1ll << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "image too large");
     if (W > 65535 || H > 65535) return fail(c, SLR_ERR_UNSUPPORTED, "W,H must be < 65536");
+    if ((long long)pitch * H >= (1ll << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "pitch * H must be < 2^31 (32-bit plane offsets)");
     return SLR_OK;
 }
 
@@ -1226,6 +1229,20 @@ int slr_set_option(slr_ctx *c, int option, int value)
                 SLR_HIP(c, hipStreamSynchronize(c->stream));
             }
             return SLR_OK;
+        case SLR_OPT_DEBUG_RECT_RESIDENT:
+            if (value < 0) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_RECT_RESIDENT must be >= 0");
+            c->debug.rect_resident = value;
+            return SLR_OK;
+        case SLR_OPT_DEBUG_FLAGS:
+            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..3");
+            c->debug.no_tiled_map = (value & 1) != 0;
+            c->debug.no_buffer_form = (value & 2) != 0;
+            return SLR_OK;
+#ifdef SLR_DEBUG_HOOKS
+        case SLR_OPT_DEBUG_K4_STOP:
+            c->debug.k4_stop = value;
+            return SLR_OK;
+#endif
         case SLR_OPT_RECT_DMA_DEPTH:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_DEPTH must be 1 or 2");
             c->opt_dma_depth = value;

@@ -45,6 +45,18 @@ enum KernelId {
 // and end -- the same duration rocprofv3's kernel trace reports -- instead of two hipEventRecord around the launch, which
 // also time the launch gap (4-5 % of a 0.2 ms kernel) and serialise the stream with barrier packets.
 extern thread_local hipEvent_t tl_prof_start, tl_prof_stop;
+
+// Test / tuning knobs of the launchers.  They are ctx fields (slr_set_option: SLR_OPT_DEBUG_RECT_RESIDENT, SLR_OPT_DEBUG_FLAGS) that the
+// C-ABI layer publishes to the calling thread before every call -- never the process environment: a stray variable in a user's
+// shell must not change which kernel form runs.  k4_stop (K4 phase ablation: the kernel returns early WITHOUT writing its
+// outputs) only exists in builds with -DSLR_DEBUG_HOOKS (profiles/k4_stages.sh).
+struct DebugKnobs {
+    int rect_resident = 0;       // > 0: resident workgroups of the persistent fused decodes (tests: many tiles per workgroup)
+    bool no_tiled_map = false;   // fused decode: read the caller's 6-byte map entries instead of the digest
+    bool no_buffer_form = false; // fused decode: per-plane pointers instead of one buffer descriptor
+    int k4_stop = 0;
+};
+extern thread_local DebugKnobs tl_debug;
 #define SLR_LAUNCH(kernel, grid, block, lds, stream, ...)                                                            \
     do {                                                                                                             \
         if (::slr::tl_prof_start) {                                                                                  \

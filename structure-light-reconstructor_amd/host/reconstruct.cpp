@@ -45,40 +45,43 @@ unsigned loader_threads(int n)
     return nt;
 }
 
-// n images <folder><prefix><i><suffix> (".pgm" is tried when the configured suffix is missing) of w x h pixels into
-// dst + i * w * h.  The first failing file in index order is reported, like the reference's sequential loop would.
-bool load_stack_into(const std::string &folder, const std::string &prefix, const std::string &suffix, int n, int w, int h,
-                     uint8_t *dst, std::string &err)
+// n images <folder[cam]><prefix[cam]><i><suffix> per camera (".pgm" is tried when the configured suffix is missing) of w x h
+// pixels into dst + (cam * n + i) * w * h: ONE pool over the 2 n files.  The first failing file in (camera, index) order is
+// reported, like the reference's sequential loops would.
+bool load_stacks_into(const std::string folder[2], const std::string prefix[2], const std::string &suffix, int n, int w, int h,
+                      uint8_t *dst, std::string &err)
 {
     if (n <= 0) return true;
-    std::vector<std::string> errs((size_t)n);
+    const int total = 2 * n;
+    std::vector<std::string> errs((size_t)total);
     std::atomic<int> next(0);
     auto work = [&]() {
-        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+        for (int t = next.fetch_add(1); t < total; t = next.fetch_add(1)) {
             try {
+                const int cam = t / n, i = t - cam * n;
                 std::ostringstream p;
-                p << folder << prefix << i;
+                p << folder[cam] << prefix[cam] << i;
                 std::string e1, e2;
-                uint8_t *out = dst + (size_t)i * w * h;
+                uint8_t *out = dst + (size_t)t * w * h;
                 if (imread_gray_into(p.str() + suffix, w, h, out, e1)) continue;
                 if (suffix != ".pgm" && imread_gray_into(p.str() + ".pgm", w, h, out, e2)) continue;
-                errs[(size_t)i] = e1.compare(0, 11, "cannot open") == 0 ? "Scan Images not found! (" + p.str() + suffix + ")" : e1;
+                errs[(size_t)t] = e1.compare(0, 11, "cannot open") == 0 ? "Scan Images not found! (" + p.str() + suffix + ")" : e1;
             } catch (const std::exception &ex) {             // bad_alloc and the like must not leave a worker thread
-                errs[(size_t)i] = std::string("image decoder: ") + ex.what();
+                errs[(size_t)t] = std::string("image decoder: ") + ex.what();
             } catch (...) {
-                errs[(size_t)i] = "image decoder: unknown exception";
+                errs[(size_t)t] = "image decoder: unknown exception";
             }
         }
     };
     std::vector<std::thread> pool;
-    const unsigned nt = loader_threads(n);
+    const unsigned nt = loader_threads(total);
     try {
         for (unsigned t = 1; t < nt; t++) pool.emplace_back(work);
     } catch (...) { /* fewer threads than hoped: the ones that exist (and this one) drain the queue */ }
     work();
     for (auto &t : pool) t.join();
-    for (int i = 0; i < n; i++)
-        if (!errs[(size_t)i].empty()) { err = errs[(size_t)i]; warn("Load Images", err); return false; }
+    for (int t = 0; t < total; t++)
+        if (!errs[(size_t)t].empty()) { err = errs[(size_t)t]; warn("Load Images", err); return false; }
     return true;
 }
 
@@ -167,9 +170,7 @@ static bool load_pair(const std::string folder[2], const std::string prefix[2], 
 {
     const size_t plane = (size_t)w * h;
     if (!buf.ensure(2 * (size_t)n * plane)) { err = "out of page-locked memory"; return false; }
-    for (int cam = 0; cam < 2; cam++)
-        if (!load_stack_into(folder[cam], prefix[cam], suffix, n, w, h, buf.u8() + (size_t)cam * n * plane, err)) return false;
-    return true;
+    return load_stacks_into(folder, prefix, suffix, n, w, h, buf.u8(), err);
 }
 
 bool Reconstruct::runReconstruction_GE()

@@ -209,12 +209,12 @@ def test_fused_rectify_decode_pipeline_many_tiles_per_workgroup(ctx, oracle, syn
     rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
     exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
     for res in ("8", "16", "40"):
-        monkeypatch.setenv("SLR_DEBUG_RECT_RESIDENT", res)
+        ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, int(res))
         for algo in (0, 2, 3, 4, 5, 6):
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), (res, algo)
-    monkeypatch.delenv("SLR_DEBUG_RECT_RESIDENT")
+    ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, 0)
     ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
 
 

@@ -27,6 +27,7 @@ def _opts(ctx, slr, algo=7, shape=0, depth=1):
 @pytest.fixture
 def dma_ctx(ctx, slr):
     yield ctx
+    ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, 0)
     _opts(ctx, slr, 0, 1, 1)
 
 
@@ -87,7 +88,7 @@ def test_dma_form_many_tiles_per_workgroup_and_whole_path(dma_ctx, slr, oracle, 
     the step-by-step oracle pipeline"""
     from util import calib_parts
     ctx = dma_ctx
-    monkeypatch.setenv("SLR_DEBUG_RECT_RESIDENT", resident)
+    ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, int(resident))
     W, H = 1280, 200
     calib, _ = synth.make_calibration(W, H)
     ctx.set_calibration(calib)
