@@ -116,8 +116,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
 #define SLR_OPT_ASYNC_HOST 4
 /* SLR_OPT_PROFILE_STRIDE: the built-in HIP-event profiler brackets every n-th launch of a kernel (default 1 = all) */
 #define SLR_OPT_PROFILE_STRIDE 5
-/* SLR_OPT_RECT_DMA_SHAPE: destination tile / workgroup size of form 7: 0 = 256x16 / 512 threads, 1 = 256x8 / 512 (default), 2 = 256x8 / 256,
- * 3 = 128x16 / 512, 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
+/* SLR_OPT_RECT_DMA_SHAPE: destination tile / workgroup size of form 7: 0 = 256x16 / 512 threads, 1 = 256x8 / 512, 2 = 256x8 / 256,
+ * 3 = 128x16 / 512 (default), 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
  * the decode, 1 (double buffer) or 2 (triple buffer). */
 #define SLR_OPT_RECT_DMA_SHAPE 6

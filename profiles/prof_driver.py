@@ -33,7 +33,16 @@ if "mf" in WHAT:
         ctx.mf_decode(st[0], 40, phase=ph[0], valid=vd[0])                     # K2 unfused
     for _ in range(REPS):
         for cam in range(2):
-            ctx.mf_decode(st[cam], 40, rectify_cam=cam, phase=ph[cam], valid=vd[cam])   # fused K1+K2
+            ctx.mf_decode(st[cam], 40, rectify_cam=cam, phase=ph[cam], valid=vd[cam])   # fused K1+K2 (auto: the LDS-DMA form)
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 5)
+    for _ in range(REPS):
+        for cam in range(2):
+            ctx.mf_decode(st[cam], 40, rectify_cam=cam, phase=ph[cam], valid=vd[cam])   # round 1's 128x8 register-staged form
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+    x2 = torch.empty((2, H, W, 3), dtype=torch.float32, device=dev); h2 = torch.empty((2, H, W), dtype=torch.uint8, device=dev)
+    st2 = torch.stack([st, torch.flip(st, dims=[0])]).contiguous()
+    for _ in range(REPS):
+        ctx.reconstruct_mf_batch(st2, 40, True, xyz=x2, has=h2)                # the pair launch (valid folded) + K4, as bench.py
     for _ in range(REPS):
         ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4 indexed
     tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)

@@ -16,24 +16,34 @@ REPO=$PWD
 cd /tmp
 
 # 1. kernel trace + stats of the bench command itself (the numbers bench.py's roofline must agree with)
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-baseline 0 --host-io 0 \
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-baseline 0 --host-io 0 --traffic off \
     > "$OUT/bench_stdout.log" 2>&1
 cp "$OUT"/bench/*kernel_stats.csv "$SUM/${TAG}_bench_kernel_stats.csv" 2>/dev/null
 grep '^{"metric"' "$OUT/bench_stdout.log" | tail -1 > "$SUM/${TAG}_bench_line.json"
 
 # 2. kernel trace + stats of the per-kernel driver
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1
+SLR_WHAT=mf,gray,ray rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1
 cp "$OUT"/drv/*kernel_stats.csv "$SUM/${TAG}_driver_kernel_stats.csv" 2>/dev/null
+for M in ge gray; do
+    rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench_$M" -o bench -- python "$REPO/bench.py" --mode $M --steps 5 --warmup 1 --cpu-baseline 0 --host-io 0 --traffic off \
+        > "$OUT/bench_${M}_stdout.log" 2>&1
+    cp "$OUT"/bench_$M/*kernel_stats.csv "$SUM/${TAG}_bench_${M}_kernel_stats.csv" 2>/dev/null
+    grep '^{"metric"' "$OUT/bench_${M}_stdout.log" | tail -1 > "$SUM/${TAG}_bench_${M}_line.json"
+done
 
-# 3. PMC passes (each its own run)
+# 3. PMC passes (each its own run), one driver group at a time so that a kernel that serves several plane counts (the Gray decode:
+#    26 planes in GRAY_EPI, 44+ in GRAY_ONLY) is summarised per group: the summary keys on <group>:<kernel>
+for GROUP in mf gray ray; do
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
     i=$((i+1))
-    rocprofv3 --kernel-trace --pmc $PMC -f csv -d "$OUT/pmc$i" -o pmc$i -- python "$REPO/profiles/prof_driver.py" > "$OUT/pmc${i}_stdout.log" 2>&1
-    cp "$OUT"/pmc$i/*counter_collection.csv "$OUT/pmc${i}_counters.csv" 2>/dev/null
+    SLR_WHAT=$GROUP rocprofv3 --kernel-trace --pmc $PMC -f csv -d "$OUT/pmc_${GROUP}_$i" -o pmc -- python "$REPO/profiles/prof_driver.py" > "$OUT/pmc_${GROUP}_${i}_stdout.log" 2>&1
+    cp "$OUT"/pmc_${GROUP}_$i/*counter_collection.csv "$OUT/pmc_${GROUP}_${i}_counters.csv" 2>/dev/null
+    rm -rf "$OUT/pmc_${GROUP}_$i"
+done
 done
 python "$REPO/profiles/summarize_pmc.py" "$OUT" "$SUM/${TAG}_pmc_summary.csv" "$SUM/pmc_traffic.json" > "$SUM/${TAG}_pmc_summary.txt" 2>&1
 ls -la "$SUM"

@@ -20,10 +20,14 @@ def main(out_dir, summary_csv):
     acc = defaultdict(lambda: defaultdict(list))
     meta = {}
     for path in sorted(glob.glob(os.path.join(out_dir, "pmc*_counters.csv"))):
+        # pmc_<group>_<pass>_counters.csv: one prof_driver group per file (run_profile.sh), so that a kernel that runs with several
+        # plane counts (gray_decode_kernel: 26 planes in the "gray" group, 44+ in "ray") gets one row per group, not an average
+        parts = os.path.basename(path).split("_")
+        group = parts[1] if len(parts) >= 4 else ""
         with open(path) as f:
             for row in csv.DictReader(f):
-                k = short(row.get("Kernel_Name", "?"))
-                if "slr" not in row.get("Kernel_Name", "") and not k.startswith(("mf_", "gray_", "ge_", "remap", "ray_", "pc_")):
+                k = (group + ":" if group else "") + short(row.get("Kernel_Name", "?"))
+                if "slr" not in row.get("Kernel_Name", "") and not k.split(":")[-1].startswith(("mf_", "gray_", "ge_", "remap", "ray_", "pc_")):
                     continue
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 meta[k] = (row.get("VGPR_Count", ""), row.get("LDS_Block_Size", ""), row.get("Grid_Size", ""))
@@ -46,9 +50,11 @@ def main(out_dir, summary_csv):
 
 # rocprof kernel name prefix -> the library's profiler name (slr_profile_kernel_name), for bench.py's roofline.traffic
 PROFILER_NAME = [
-    ("mf_rect_decode_lds_kernel", "slr_mf_rectify_decode"), ("mf_decode_kernel", "slr_mf_decode"),
+    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, true>", "slr_mf_rectify_decode"),
+    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, false>", "slr_mf_rectify_decode_pair"),
+    ("mf:mf_rect_decode_lds_kernel", "slr_mf_rectify_decode[round-1 form 5]"), ("mf_decode_kernel", "slr_mf_decode"),
     ("remap_kernel", "slr_remap_u8"), ("gray_rect_decode_lds_kernel", "slr_gray_rectify_decode"),
-    ("gray_decode_kernel<4, false>", "slr_gray_decode"), ("mf_match_binned_kernel", "slr_mf_match_triangulate"),
+    ("gray:gray_decode_kernel<4, false>", "slr_gray_decode"), ("ray:gray_decode_kernel<4, false>", "slr_gray_decode[columns+rows]"), ("mf_match_binned_kernel", "slr_mf_match_triangulate"),
     ("ge_match_kernel", "slr_ge_match_triangulate"), ("ray_count_kernel", "slr_ray_count"),
     ("ray_scatter_kernel", "slr_ray_scatter"), ("ray_triangulate_kernel", "slr_ray_triangulate"),
 ]
@@ -59,7 +65,7 @@ def traffic_json(summary_csv, out_json):
     out = {}
     for row in csv.DictReader(open(summary_csv)):
         for prefix, name in PROFILER_NAME:
-            if row["kernel"].startswith(prefix) and name not in out:
+            if (row["kernel"].startswith(prefix) or row["kernel"].split(":")[-1].startswith(prefix)) and name not in out:
                 rd, wr = float(row["hbm_read_bytes(2xFETCH)"]), float(row["hbm_write_bytes"])
                 if rd == rd and wr == wr:
                     out[name] = {"hbm_bytes_per_launch": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
