@@ -86,8 +86,9 @@ int          slr_synchronize(slr_ctx *ctx);
 const char  *slr_last_error(const slr_ctx *ctx);
 /* tuning / test knobs.  SLR_OPT_MF_MATCH_ALGO: 0 = auto, 1 = linear LDS sweep (the literal form of
  * mfreconstruct.cpp:289-331), 2 = indexed exact form built by an LDS radix sort (distinct phases), 3 = indexed exact form
- * built by an LDS counting sort (the default; rows wider than 4096 pixels are matched against the right row in chunks of
- * 4096 columns, up to 32768 pixels; wider rows take the sweep).  All give identical results. */
+ * built by an LDS counting sort (rows wider than 4096 pixels are matched against the right row in chunks of 4096 columns, up to
+ * 32768 pixels; wider rows take the sweep).  0 picks 3, in its lean variant (same index, fewer instructions) when the rows are
+ * aligned, 513..1024 or 2049..4096 pixels wide and Q has cv::stereoRectify's pattern.  All give identical results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2

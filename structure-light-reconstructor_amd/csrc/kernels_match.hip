@@ -444,6 +444,247 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K4 (exact indexed form, lean): mf_match_binned_kernel's index (phases A and B) with a query and a triangulation cut
+// down to what the usual call needs -- 4 pixels per thread, aligned rows, undistortion tables present, Q of
+// cv::stereoRectify's pattern.  Everything else takes the general kernel above.  K4 is bound by VALU issue (78 % busy, f64 at
+// half rate), so the changes are instruction-count changes that keep every bit:
+//   * the bin index is shifted by one bin and padded (bs[0] = 0, two copies of the total behind the last bin): one
+//     ds_read2_b32 returns both ends of a pixel's window [bin-1, bin+1], no clamping;
+//   * the candidate pairs end in NaN sentinels and every entry of the array is a genuine (phase, column) pair of the right row,
+//     so the exact predicate may be evaluated on ANY of them without changing the minimum: the loop reads two aligned
+//     16-byte words per step from the window's start rounded down to an even pair, without bound tests per candidate;
+//   * the general kernel carries both cameras' intrinsics and the whole Q in SGPRs (the table-less path needs them) and
+//     spills them to VGPR lanes; this one takes 5 + 12 doubles (K4Lean), T already widened;
+//   * matCoordTrans: a product of two floats is exact in f64, so fma(T, X, s) == T * X + s rounded once -- the same value as the
+//     reference's multiply-then-add, in half the instructions; s starts from fma(T0, X0, +0.0), which also reproduces 0 + (-0);
+//   * the table gathers, the f64 arithmetic and the stores of a thread's 4 pixels are branch-free (unmatched pixels compute on
+//     column 0's table entry and are replaced by zeros at the end).
+// ------------------------------------------------------------------------------------------------------
+struct K4Lean {
+    double q3, q7, q11, q14, q15;      // Q's five entries that are not structural zeros / ones
+    double T[12];                      // matCoordTrans widened to f64 (exact)
+};
+
+template <int BLOCK, bool HAS_T>
+__global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                              const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                              int W, int H, int row0, K4Lean kc, int stop,
+                                                              const float4 *__restrict__ undL, const float *__restrict__ undRx,
+                                                              float *__restrict__ xyz,
+                                                              uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int IPT = 4;
+    constexpr int N = BLOCK * IPT;
+    constexpr int TS = 2 * N;                            // hash slots (power of two, load factor <= 0.5)
+    constexpr int kPer = kBins / BLOCK;                  // bins per thread (kBins is a multiple of BLOCK)
+    constexpr unsigned kEmpty = 0xFFFFFFFFu;             // a NaN pattern: never a candidate's phase bits
+#if defined(SLR_K4_SCAN_RAKING)
+    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
+#else
+    typedef hipcub::BlockScan<unsigned, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanU;
+#endif
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ union {
+        struct { unsigned key[TS]; unsigned mink[TS]; } t;               // phase bits -> smallest column
+        struct { f32x4 pk2[N / 2 + 2]; unsigned bs[kBins + 3]; } b;      // pairs of (phi, column as bits) grouped by bin; bin index
+    } sh;
+    __shared__ typename ScanU::TempStorage scan_tmp;
+    static_assert(BLOCK != 1024 || sizeof(sh.b) <= sizeof(sh.t), "the index must fit the dead hash table (two workgroups per CU)");
+
+    const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)blockIdx.x * W;
+    const int k0 = tid * IPT;
+    const bool inrow = k0 < W;                           // W % 4 == 0: a thread's 4 pixels are all inside or all outside
+
+    float pr[IPT], pl[IPT];
+    unsigned vr[IPT], vl[IPT];
+    load_f32_blocked<IPT>(phaseR + base, k0, W, true, pr);
+    load_valid_blocked<IPT>(validR, base, k0, W, true, vr);
+    load_f32_blocked<IPT>(phaseL + base, k0, W, true, pl);
+    load_valid_blocked<IPT>(validL, base, k0, W, true, vl);
+    const size_t trow = (size_t)row * W;
+#pragma unroll
+    for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
+    __syncthreads();
+    if (stop == 1) return;
+
+    // A. distinct values and their smallest column (as mf_match_binned_kernel)
+    unsigned slot[IPT];                                  // hash slot of this pixel's value; kEmpty = not a candidate
+    bool prev_ok = false;
+    unsigned prev_bits = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const bool ok = inrow && vr[i] && (pr[i] == pr[i]);          // NaN can never satisfy the predicate
+        const unsigned bits = __float_as_uint(pr[i]);
+        const bool dup = prev_ok && ok && bits == prev_bits;         // same value one column to the left (flat regions)
+        slot[i] = kEmpty;
+        if (ok && !dup) {
+            unsigned h = (bits * 2654435761u) >> (32 - __builtin_ctz(TS));
+            for (;;) {
+                const unsigned old = atomicCAS(&sh.t.key[h], kEmpty, bits);
+                if (old == kEmpty || old == bits) break;
+                h = (h + 1) & (TS - 1);
+            }
+            atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
+            slot[i] = h;
+        }
+        prev_ok = ok; prev_bits = bits;
+    }
+    __syncthreads();
+    unsigned repmask = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (slot[i] != kEmpty && sh.t.mink[slot[i]] == (unsigned)(k0 + i)) repmask |= 1u << i;
+    __syncthreads();                                     // the table is dead from here on
+    if (stop == 2) return;
+
+    // B. counting sort of the representatives by phase bin; bs[1 + b] counts, then starts, bin b
+#pragma unroll
+    for (int q = 0; q < kPer; q++) sh.b.bs[1 + tid + q * BLOCK] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if (repmask & (1u << i)) {
+            const unsigned b = (unsigned)phase_bin(pr[i]);
+            slot[i] = (b << 16) | atomicAdd(&sh.b.bs[1 + b], 1u);
+        }
+    }
+    __syncthreads();
+    float2 *const pk = reinterpret_cast<float2 *>(sh.b.pk2);
+    {
+        unsigned c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = sh.b.bs[1 + tid * kPer + q]; sum += c[q]; }
+        unsigned excl, total;
+        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }   // own bins only: no hazard
+        if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
+        if (tid < 4) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (repmask & (1u << i))
+            pk[sh.b.bs[1 + (slot[i] >> 16)] + (slot[i] & 0xFFFFu)] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+    __syncthreads();
+    if (stop == 4) return;
+
+    // queries: the reference's predicate on the pairs of bins [b-1, b+1] (and a few neighbours), smallest column wins
+    int best[IPT];
+    unsigned qa[IPT], qe[IPT];                           // byte offsets into pk: first 16-byte word, end of the window
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const bool act = inrow && vl[i] && pl[i] == pl[i];
+        const int b = act ? phase_bin(pl[i]) : 0;
+        const unsigned i0 = sh.b.bs[b], i1 = sh.b.bs[b + 3];
+        qa[i] = (i0 & ~1u) * 8u;
+        qe[i] = act ? i1 * 8u : 0u;
+    }
+    const char *const pkb = reinterpret_cast<const char *>(sh.b.pk2);
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        unsigned bk = 0xFFFFFFFFu;
+        const float p = pl[i];
+        for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+            const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+            const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+            const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+            const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+            bk = min(min(bk, h0), min(h1, min(h2, h3)));
+        }
+        best[i] = (int)bk;                               // 0xFFFFFFFF == -1: no match
+    }
+    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
+    if (!inrow) return;
+
+    // triangulation (mfreconstruct.cpp:297-326), branch-free for the 4 pixels
+#if defined(SLR_K4_ABL) && (SLR_K4_ABL & 2)
+    const f32x4 ua = {pl[0], pl[1], pl[2], pl[3]}, ub = {pr[0], pr[1], pr[2], pr[3]};
+    float urx[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) urx[i] = (float)best[i];
+#else
+    const f32x4 ua = *reinterpret_cast<const f32x4 *>(undL + (trow + k0) / 2);
+    const f32x4 ub = *(reinterpret_cast<const f32x4 *>(undL + (trow + k0) / 2) + 1);
+    float urx[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) urx[i] = undRx[trow + (best[i] >= 0 ? best[i] : 0)];
+#endif
+    const float ulx[IPT] = {ua.x, ua.z, ub.x, ub.z}, uly[IPT] = {ua.y, ua.w, ub.y, ub.w};
+    float out[12];
+    unsigned hw = 0;
+    unsigned bad = 0;                                    // pixels whose quotients need the real divisions
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        // p3D = Q * [ulx, uly, ulx - urx, 1] with Q's structural zeros and ones dropped (reproject(): exact no-ops)
+        const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+        const double w = kc.q14 * (double)(float)(ulx[i] - urx[i]) + kc.q15;
+        // X = (float)(r / w), guarded by the exponents (anything unusual takes the real divisions below)
+        auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
+        const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
+        const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+        if (!(emin >= 1023u - 200u && emax < 1023u + 200u) && best[i] >= 0) bad |= 1u << i;
+        // The three quotients r/w exactly as three IEEE divisions compute them on this GPU: the compiler expands x/w into
+        // y = rcp(w) refined by two Newton steps, q = x*y, q' = fma(fma(-w, q, x), y, q) (plus operand scaling and a fix-up
+        // that are the identity inside the exponent guard) -- y depends on w alone, so it is computed once for the three.
+        double y = __builtin_amdgcn_rcp(w);
+        y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+        y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+        const double r[3] = {r0, r1, r2};
+        float X[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double q = r[c] * y;
+            const double e = __builtin_fma(-w, q, r[c]);
+            X[c] = (float)__builtin_fma(e, y, q);
+        }
+        out[3 * i] = X[0]; out[3 * i + 1] = X[1]; out[3 * i + 2] = X[2];
+    }
+    if (__builtin_expect(bad != 0, 0)) {                 // exact zeros, w == 0, NaN, extreme exponents: the three real divisions
+#pragma unroll 1
+        for (int i = 0; i < IPT; i++) {
+            if (!((bad >> i) & 1u)) continue;
+            const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+            const double w = kc.q14 * (double)(float)(ulx[i] - urx[i]) + kc.q15;
+            const float X0 = (float)(r0 / w), X1 = (float)(r1 / w), X2 = (float)(r2 / w);
+#pragma unroll
+            for (int j = 0; j < IPT; j++)
+                if (j == i) { out[3 * j] = X0; out[3 * j + 1] = X1; out[3 * j + 2] = X2; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if constexpr (HAS_T) {                           // matCoordTrans(3x4 f32) * [X;1]: f64 accumulate, narrow once
+            const double X0 = (double)out[3 * i], X1 = (double)out[3 * i + 1], X2 = (double)out[3 * i + 2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double s = __builtin_fma(kc.T[c * 4], X0, 0.0);
+                s = __builtin_fma(kc.T[c * 4 + 1], X1, s);
+                s = __builtin_fma(kc.T[c * 4 + 2], X2, s);
+                out[3 * i + c] = (float)(s + kc.T[c * 4 + 3]);
+            }
+        }
+        const bool m = best[i] >= 0;
+        out[3 * i] = m ? out[3 * i] : 0.0f; out[3 * i + 1] = m ? out[3 * i + 1] : 0.0f; out[3 * i + 2] = m ? out[3 * i + 2] : 0.0f;
+        hw |= (m ? 1u : 0u) << (8 * i);
+    }
+    const size_t o = base + k0;
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(xyz + 3 * o);  // streaming output: non-temporal stores
+    const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+#if defined(SLR_K4_ABL) && (SLR_K4_ABL & 1)
+    if (out[0] + out[5] + out[10] != 1.2345e-30f) return;
+#endif
+    __builtin_nontemporal_store(v0, d4);
+    __builtin_nontemporal_store(v1, d4 + 1);
+    __builtin_nontemporal_store(v2, d4 + 2);
+    __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
+    if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[0], best[1], best[2], best[3]);
+}
+
 // K4 for rows wider than 4096 pixels.  The hash table of a whole 8192-pixel right row needs 128 KB of LDS (one 1024-thread
 // workgroup per CU, 8 pixels and too many registers per thread: 2.3x the time per pixel of a 4096-wide row).  "Smallest
 // column k with |phiL - phiR[k]| < 0.1" decomposes over CHUNKS of the right row: the answer lies in the first chunk
@@ -779,8 +1020,8 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
     return hipGetLastError();
 }
 
-// algo: 0 = auto (binned indexed form when the row fits 8192 items, else the sweep), 1 = sweep, 2 = sorted indexed form,
-// 3 = binned indexed form
+// algo: 0 = auto (lean binned form when it applies, else the general binned form, the chunked form for wide rows, the sweep
+// beyond), 1 = sweep, 2 = sorted indexed form, 3 = general binned indexed form
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, int row0, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
                            int algo, const float *undL_xy, const float *undRx, hipStream_t s)
@@ -804,6 +1045,24 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             SLR_LAUNCH((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
                                phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
     } while (0)
+        // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
+        if (algo == 0 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+            (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
+            K4Lean kc;
+            kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
+            for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
+            const float4 *undL4 = (const float4 *)undL_xy;
+#define SLR_LEAN(BLOCK)                                                                                                          \
+    do {                                                                                                                         \
+        if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<BLOCK, true>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
+                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                     \
+        else SLR_LAUNCH((mf_match_lean_kernel<BLOCK, false>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR,         \
+                        W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                               \
+    } while (0)
+            if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);
+#undef SLR_LEAN
+            return hipGetLastError();
+        }
         // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
         if (W <= 256) SLR_SORTED(256, 1);
         else if (W <= 512) SLR_SORTED(256, 2);
