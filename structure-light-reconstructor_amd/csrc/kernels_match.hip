@@ -485,9 +485,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     typedef hipcub::BlockScan<unsigned, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanU;
 #endif
     typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr bool kCntInKey = TS >= kBins + BLOCK;        // the bin counters reuse the key half of the table when they fit it
     __shared__ union {
         struct { unsigned key[TS]; unsigned mink[TS]; } t;               // phase bits -> smallest column
-        struct { f32x4 pk2[N / 2 + 2]; unsigned bs[kBins + 3]; } b;      // pairs of (phi, column as bits) grouped by bin; bin index
+        struct { f32x4 pk2[N / 2 + 3]; unsigned bs[kBins + 3]; } b;      // pairs of (phi, column as bits) grouped by bin (+ sentinels, + a sink); bin index
+        struct { unsigned pad[kCntInKey ? 1 : 2 * TS]; unsigned cnt[kCntInKey ? 1 : kBins + BLOCK]; } c;   // (small rows: behind the table)
     } sh;
     __shared__ typename ScanU::TempStorage scan_tmp;
     static_assert(BLOCK != 1024 || sizeof(sh.b) <= sizeof(sh.t), "the index must fit the dead hash table (two workgroups per CU)");
@@ -497,77 +499,96 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     const int k0 = tid * IPT;
     const bool inrow = k0 < W;                           // W % 4 == 0: a thread's 4 pixels are all inside or all outside
 
-    float pr[IPT], pl[IPT];
-    unsigned vr[IPT], vl[IPT];
-    load_f32_blocked<IPT>(phaseR + base, k0, W, true, pr);
-    load_valid_blocked<IPT>(validR, base, k0, W, true, vr);
-    load_f32_blocked<IPT>(phaseL + base, k0, W, true, pl);
-    load_valid_blocked<IPT>(validL, base, k0, W, true, vl);
+    // a thread's 4 pixels are whole inside or outside the row (W % 4 == 0): plain vector loads, all issued up front
+    float pr[IPT] = {0, 0, 0, 0}, pl[IPT] = {0, 0, 0, 0};
+    unsigned vr[IPT] = {0, 0, 0, 0}, vl[IPT] = {0, 0, 0, 0};
+    if (inrow) {
+        load_f32_blocked<IPT>(phaseR + base, k0, k0 + IPT, true, pr);
+        load_valid_blocked<IPT>(validR, base, k0, k0 + IPT, true, vr);
+        load_f32_blocked<IPT>(phaseL + base, k0, k0 + IPT, true, pl);
+        load_valid_blocked<IPT>(validL, base, k0, k0 + IPT, true, vl);
+    }
     const size_t trow = (size_t)row * W;
 #pragma unroll
     for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
     __syncthreads();
     if (stop == 1) return;
 
-    // A. distinct values and their smallest column (as mf_match_binned_kernel)
-    unsigned slot[IPT];                                  // hash slot of this pixel's value; kEmpty = not a candidate
-    bool prev_ok = false;
-    unsigned prev_bits = 0;
+    // A. distinct values and their smallest column (as mf_match_binned_kernel; the four first probes are independent LDS
+    //    atomics in flight together, a collision continues in the loop)
+    unsigned slot[IPT], bits[IPT], old[IPT];             // hash slot of this pixel's value; kEmpty = not a candidate
+    bool cand[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
+        bits[i] = __float_as_uint(pr[i]);
         const bool ok = inrow && vr[i] && (pr[i] == pr[i]);          // NaN can never satisfy the predicate
-        const unsigned bits = __float_as_uint(pr[i]);
-        const bool dup = prev_ok && ok && bits == prev_bits;         // same value one column to the left (flat regions)
-        slot[i] = kEmpty;
-        if (ok && !dup) {
-            unsigned h = (bits * 2654435761u) >> (32 - __builtin_ctz(TS));
-            for (;;) {
-                const unsigned old = atomicCAS(&sh.t.key[h], kEmpty, bits);
-                if (old == kEmpty || old == bits) break;
+        // same value one column to the left (flat regions): that one is (or defers to) the representative
+        const bool dup = i > 0 && ok && vr[i - 1] && bits[i] == bits[i - 1];
+        cand[i] = ok && !dup;
+        slot[i] = (bits[i] * 2654435761u) >> (32 - __builtin_ctz(TS));
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) old[i] = cand[i] ? atomicCAS(&sh.t.key[slot[i]], kEmpty, bits[i]) : kEmpty;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if (cand[i]) {
+            unsigned h = slot[i], o = old[i];
+            while (o != kEmpty && o != bits[i]) {
                 h = (h + 1) & (TS - 1);
+                o = atomicCAS(&sh.t.key[h], kEmpty, bits[i]);
             }
             atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
             slot[i] = h;
         }
-        prev_ok = ok; prev_bits = bits;
     }
     __syncthreads();
+    // representatives: the pixels that are their value's smallest column.  The key half of the table is dead already and
+    // becomes the bin counters (cnt[kBins + tid] = a sink for the thread's non-representatives: the atomics below are
+    // unconditional and independent, and never pile up on one address)
+    unsigned *const cnt = kCntInKey ? sh.t.key : sh.c.cnt;
     unsigned repmask = 0;
+    unsigned mk4[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) mk4[i] = sh.t.mink[slot[i]];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) cnt[tid + q * BLOCK] = 0u;
 #pragma unroll
     for (int i = 0; i < IPT; i++)
-        if (slot[i] != kEmpty && sh.t.mink[slot[i]] == (unsigned)(k0 + i)) repmask |= 1u << i;
-    __syncthreads();                                     // the table is dead from here on
+        if (cand[i] && mk4[i] == (unsigned)(k0 + i)) repmask |= 1u << i;
+    __syncthreads();                                     // the whole table is dead from here on
     if (stop == 2) return;
 
-    // B. counting sort of the representatives by phase bin; bs[1 + b] counts, then starts, bin b
+    // B. counting sort of the representatives by phase bin
+    unsigned bin[IPT], rank[IPT];
 #pragma unroll
-    for (int q = 0; q < kPer; q++) sh.b.bs[1 + tid + q * BLOCK] = 0u;
-    __syncthreads();
+    for (int i = 0; i < IPT; i++) bin[i] = (repmask >> i) & 1u ? (unsigned)phase_bin(pr[i]) : (unsigned)(kBins + tid);
 #pragma unroll
-    for (int i = 0; i < IPT; i++) {
-        if (repmask & (1u << i)) {
-            const unsigned b = (unsigned)phase_bin(pr[i]);
-            slot[i] = (b << 16) | atomicAdd(&sh.b.bs[1 + b], 1u);
-        }
-    }
+    for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&cnt[bin[i]], 1u);
     __syncthreads();
     float2 *const pk = reinterpret_cast<float2 *>(sh.b.pk2);
     {
         unsigned c[kPer], sum = 0;
 #pragma unroll
-        for (int q = 0; q < kPer; q++) { c[q] = sh.b.bs[1 + tid * kPer + q]; sum += c[q]; }
+        for (int q = 0; q < kPer; q++) { c[q] = cnt[tid * kPer + q]; sum += c[q]; }
         unsigned excl, total;
-        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);  // (its barriers: every thread has read its counters)
 #pragma unroll
-        for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }   // own bins only: no hazard
+        for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }   // bs lies in the mink half
         if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
-        if (tid < 4) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
     }
     __syncthreads();
+    {
+        const unsigned total = sh.b.bs[kBins + 1];
+        if (tid < 4) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
+        unsigned st[IPT];
 #pragma unroll
-    for (int i = 0; i < IPT; i++)
-        if (repmask & (1u << i))
-            pk[sh.b.bs[1 + (slot[i] >> 16)] + (slot[i] & 0xFFFFu)] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+        for (int i = 0; i < IPT; i++) st[i] = sh.b.bs[1 + ((repmask >> i) & 1u ? bin[i] : (unsigned)kBins)];   // (non-representatives: the total, unused)
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const unsigned at = (repmask >> i) & 1u ? st[i] + rank[i] : (unsigned)N + 4u;
+            pk[at] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+        }
+    }
     __syncthreads();
     if (stop == 4) return;
 
@@ -577,7 +598,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         const bool act = inrow && vl[i] && pl[i] == pl[i];
-        const int b = act ? phase_bin(pl[i]) : 0;
+        const int b = phase_bin(pl[i]);                  // (a NaN lands in bin 0; its window is emptied below)
         const unsigned i0 = sh.b.bs[b], i1 = sh.b.bs[b + 3];
         qa[i] = (i0 & ~1u) * 8u;
         qe[i] = act ? i1 * 8u : 0u;
