@@ -1111,6 +1111,8 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
     return hipGetLastError();
 }
 
+constexpr uint8_t kGeDeferred = 0xFE;             // has[] marker: "row left to the general K5 kernel" (never a result value)
+
 // ------------------------------------------------------------------------------------------------------
 // K5: one workgroup per row.
 //   1. keys (code<<16 | k) of the valid right pixels are radix-sorted in LDS on the code bits (stable) -> for every
@@ -1130,8 +1132,11 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
                                                        int W, int H, int TC, DevCalib cal,
                                                        const uint8_t *__restrict__ whiteL, const uint8_t *__restrict__ whiteR,
                                                        float *__restrict__ xyz, uint8_t *__restrict__ has,
-                                                       uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
+                                                       uint8_t *__restrict__ color, int32_t *__restrict__ match_k,
+                                                       int deferred_only)
 {
+    // deferred_only: run behind ge_match_lean_kernel, for the rows it marked (has[first pixel of the row] == kGeDeferred)
+    if (deferred_only && has[(size_t)blockIdx.x * W] != kGeDeferred) return;
     constexpr int N = 256 * IPT;
     typedef hipcub::BlockRadixSort<unsigned, 256, IPT> Sort;
     typedef hipcub::BlockScan<int, 256> ScanI;
@@ -1241,14 +1246,223 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K5, lean form for the usual call (aligned rows of 2049..4096 pixels, codes below 8192, Q of cv::stereoRectify's pattern): the same
+// walk over per-code ascending column lists, but the lists come from a COUNTING sort in LDS instead of a block radix sort --
+// histogram with returning atomics (arrival rank), one scan over the 8192 counters, scatter, and an insertion sort of every
+// list by the thread that owns its code (a camera sees a projector column in a few pixels of a row: lists of 1-4 entries) --
+// on 1024 threads x 4 pixels (two workgroups per CU, 32 waves) instead of 256 x 16 (12 waves per CU).  Rows this form is not
+// made for -- a code >= 8192 or a list longer than 32 columns -- are marked in has[] and done by ge_match_kernel in a second
+// launch (deferred_only).  The triangulation is K4-lean's: one refined reciprocal for the three quotients, fma form of T.
+// Reference: Reconstruct::triangulation_ge Duke/reconstruct.cpp:555-611.
+// ------------------------------------------------------------------------------------------------------
+template <bool HAS_T>
+__global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
+                                                                const int32_t *__restrict__ codeR, const uint8_t *__restrict__ validR,
+                                                                int W, int H, K4Lean kc,
+                                                                const uint8_t *__restrict__ whiteL, const uint8_t *__restrict__ whiteR,
+                                                                float *__restrict__ xyz, uint8_t *__restrict__ has,
+                                                                uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
+{
+    constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, TC = 8192, kPer = TC / BLOCK, kMaxList = 32;
+    typedef hipcub::BlockScan<unsigned, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanU;
+    typedef hipcub::BlockScan<int, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanI;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ unsigned start[TC + BLOCK + 1];             // counters, then list starts (start[TC] = total); [TC + 1 + tid]: atomics' sinks
+    __shared__ unsigned short S[N];                        // the lists: columns grouped by code, ascending inside a code
+    __shared__ union { typename ScanU::TempStorage u; typename ScanI::TempStorage i; } scan_tmp;
+
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)row * W;
+    const int k0 = tid * IPT;
+    const bool inrow = k0 < W;                             // W % 4 == 0
+
+    int cr[IPT] = {-1, -1, -1, -1}, cl[IPT] = {-1, -1, -1, -1};
+    if (inrow) {
+        const i32x4 a = *reinterpret_cast<const i32x4 *>(codeR + base + k0), b = *reinterpret_cast<const i32x4 *>(codeL + base + k0);
+        unsigned va = 0x01010101u, vb = 0x01010101u;       // (null valid: the decode wrote code -1 for invalid pixels)
+        if (validR) va = *reinterpret_cast<const unsigned *>(validR + base + k0);
+        if (validL) vb = *reinterpret_cast<const unsigned *>(validL + base + k0);
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const int x = i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w, y = i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w;
+            // codes outside [0, 65535] cannot be packed next to a column by the general kernel and are "no code" there: same here
+            cr[i] = ((va >> (8 * i)) & 0xFFu) && (unsigned)x <= 0xFFFFu ? x : -1;
+            cl[i] = ((vb >> (8 * i)) & 0xFFu) && (unsigned)y <= 0xFFFFu ? y : -1;
+        }
+    }
+    bool defer = false;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) defer = defer || cr[i] >= TC || cl[i] >= TC;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) start[tid + q * BLOCK] = 0u;
+    if (__syncthreads_or(defer ? 1 : 0)) {                 // (also orders the zeroing before the atomics)
+        if (tid == 0) has[base] = kGeDeferred;
+        return;
+    }
+    // counting sort of the right row's columns by code
+    unsigned rank[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&start[cr[i] >= 0 ? cr[i] : TC + 1 + tid], 1u);
+    __syncthreads();
+    unsigned c[kPer], excl, total;
+    {
+        unsigned sum = 0, longest = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = start[tid * kPer + q]; sum += c[q]; longest = c[q] > longest ? c[q] : longest; }
+        ScanU(scan_tmp.u).ExclusiveSum(sum, excl, total);  // (its barriers: every thread has read its counters)
+        unsigned e = excl;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { start[tid * kPer + q] = e; e += c[q]; }
+        if (tid == 0) start[TC] = total;
+        defer = longest > (unsigned)kMaxList;
+    }
+    if (__syncthreads_or(defer ? 1 : 0)) {
+        if (tid == 0) has[base] = kGeDeferred;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++)
+        if (cr[i] >= 0) S[start[cr[i]] + rank[i]] = (unsigned short)(k0 + i);
+    __syncthreads();
+    {   // ascending columns inside every list (the arrival order of the atomics is arbitrary)
+        unsigned lo = excl;
+#pragma unroll 1
+        for (int q = 0; q < kPer; q++) {
+            const unsigned n = c[q];
+            for (unsigned i = lo + 1; i < lo + n; i++) {
+                const unsigned short v = S[i];
+                unsigned j = i;
+                while (j > lo && S[j - 1] > v) { S[j] = S[j - 1]; j--; }
+                S[j] = v;
+            }
+            lo += n;
+        }
+    }
+    __syncthreads();
+
+    // smallest column >= ks in code cc's list, or -1
+    auto find = [&](int cc, int ks) -> int {
+        unsigned lo = start[cc];
+        const unsigned hi = start[cc + 1];
+        while (lo < hi && (int)S[lo] < ks) lo++;
+        return lo < hi ? (int)S[lo] : -1;
+    };
+    int m[IPT];
+    int ks_in = 0, lm = -1, fm = 0x7FFFFFFF;               // incoming kstart, last and first match of this thread
+    bool dirty = true;
+    for (;;) {                                             // the fixed point of ge_match_kernel (see there)
+        if (dirty) {
+            int ks = ks_in;                                // reconstruct.cpp:556 / :604
+            lm = -1; fm = 0x7FFFFFFF;
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                m[i] = -1;
+                if (cl[i] >= 0) {
+                    m[i] = find(cl[i], ks);
+                    if (m[i] >= 0) { ks = m[i]; lm = m[i]; if (fm == 0x7FFFFFFF) fm = m[i]; }
+                }
+            }
+        }
+        int exc;
+        ScanI(scan_tmp.i).ExclusiveScan(lm, exc, -1, hipcub::Max());
+        const int new_in = exc > 0 ? exc : 0;
+        dirty = new_in > fm;                               // kstart passed this thread's first match: its walk must be redone
+        ks_in = new_in > ks_in ? new_in : ks_in;
+        if (!__syncthreads_or(dirty ? 1 : 0)) break;
+    }
+    if (!inrow) return;
+
+    // triangulation of the thread's 4 pixels (reconstruct.cpp:570-603), branch-free
+    float out[12];
+    unsigned hw = 0, cw = 0, bad = 0;
+    unsigned wl4 = 0;
+    if (color) wl4 = *reinterpret_cast<const unsigned *>(whiteL + base + k0);
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const int j = k0 + i, mm = m[i] >= 0 ? m[i] : 0;
+        const double r0 = (double)j + kc.q3, r1 = (double)row + kc.q7, r2 = kc.q11;
+        const double w = kc.q14 * (double)(j - mm) + kc.q15;
+        auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
+        const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
+        const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+        if (!(emin >= 1023u - 200u && emax < 1023u + 200u) && m[i] >= 0) bad |= 1u << i;
+        double y = __builtin_amdgcn_rcp(w);                // the three IEEE quotients from one refined reciprocal (mf_match_lean_kernel)
+        y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+        y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+        const double r[3] = {r0, r1, r2};
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const double q = r[cc] * y;
+            const double e = __builtin_fma(-w, q, r[cc]);
+            out[3 * i + cc] = (float)__builtin_fma(e, y, q);
+        }
+        if (color && m[i] >= 0) cw |= (unsigned)(((int)((wl4 >> (8 * i)) & 0xFFu) + (int)whiteR[base + mm]) / 2) << (8 * i);   // :598
+    }
+    if (__builtin_expect(bad != 0, 0)) {                   // exact zeros, w == 0, extreme exponents: the three real divisions
+#pragma unroll 1
+        for (int i = 0; i < IPT; i++) {
+            if (!((bad >> i) & 1u)) continue;
+            const int j = k0 + i;
+            const double r0 = (double)j + kc.q3, r1 = (double)row + kc.q7, r2 = kc.q11;
+            const double w = kc.q14 * (double)(j - m[i]) + kc.q15;
+            const float X0 = (float)(r0 / w), X1 = (float)(r1 / w), X2 = (float)(r2 / w);
+#pragma unroll
+            for (int jj = 0; jj < IPT; jj++)
+                if (jj == i) { out[3 * jj] = X0; out[3 * jj + 1] = X1; out[3 * jj + 2] = X2; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if constexpr (HAS_T) {                             // matCoordTrans(3x4 f32) * [X;1]: f64 accumulate, narrow once
+            const double X0 = (double)out[3 * i], X1 = (double)out[3 * i + 1], X2 = (double)out[3 * i + 2];
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                double sacc = __builtin_fma(kc.T[cc * 4], X0, 0.0);
+                sacc = __builtin_fma(kc.T[cc * 4 + 1], X1, sacc);
+                sacc = __builtin_fma(kc.T[cc * 4 + 2], X2, sacc);
+                out[3 * i + cc] = (float)(sacc + kc.T[cc * 4 + 3]);
+            }
+        }
+        const bool mt = m[i] >= 0;
+        out[3 * i] = mt ? out[3 * i] : 0.0f; out[3 * i + 1] = mt ? out[3 * i + 1] : 0.0f; out[3 * i + 2] = mt ? out[3 * i + 2] : 0.0f;
+        hw |= (mt ? 1u : 0u) << (8 * i);
+    }
+    const size_t o = base + k0;
+    f32x4 *d4 = reinterpret_cast<f32x4 *>(xyz + 3 * o);
+    const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+    __builtin_nontemporal_store(v0, d4);
+    __builtin_nontemporal_store(v1, d4 + 1);
+    __builtin_nontemporal_store(v2, d4 + 2);
+    __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
+    if (color) __builtin_nontemporal_store(cw, reinterpret_cast<unsigned *>(color + o));
+    if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(m[0], m[1], m[2], m[3]);
+}
+
 hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR, const uint8_t *validR,
                            int W, int H, const DevCalib &cal, const uint8_t *whiteL, const uint8_t *whiteR,
                            float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s)
 {
     const int TC = 8192;                           // codes below this use the direct list-head table (16 KB LDS)
+    int deferred_only = 0;
+    const bool a16 = ((uintptr_t)codeL | (uintptr_t)codeR | (uintptr_t)xyz | (uintptr_t)match_k) % 16 == 0;
+    const bool a4 = ((uintptr_t)validL | (uintptr_t)validR | (uintptr_t)has | (uintptr_t)whiteL | (uintptr_t)color) % 4 == 0;
+    if (W > 2048 && W <= 4096 && W % 4 == 0 && a16 && a4 && cal.q_simple && !tl_debug.no_ge_lean) {
+        K4Lean kc;
+        kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
+        for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
+        if (cal.has_T) SLR_LAUNCH(ge_match_lean_kernel<true>, dim3(H), dim3(1024), 0, s, codeL, validL, codeR, validR, W, H, kc, whiteL,
+                                  whiteR, xyz, has, color, match_k);
+        else SLR_LAUNCH(ge_match_lean_kernel<false>, dim3(H), dim3(1024), 0, s, codeL, validL, codeR, validR, W, H, kc, whiteL, whiteR,
+                        xyz, has, color, match_k);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        deferred_only = 1;                          // the rows it marked (codes >= 8192, long lists) follow in the general kernel
+    }
 #define SLR_GE(IPT)                                                                                                    \
     SLR_LAUNCH(ge_match_kernel<IPT>, dim3(H), dim3(256), (size_t)TC * 2, s, codeL, validL, codeR, validR, W, H, TC, \
-                       cal, whiteL, whiteR, xyz, has, color, match_k)
+                       cal, whiteL, whiteR, xyz, has, color, match_k, deferred_only)
     if (W <= 256) SLR_GE(1);
     else if (W <= 512) SLR_GE(2);
     else if (W <= 1024) SLR_GE(4);

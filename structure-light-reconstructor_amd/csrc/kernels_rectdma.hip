@@ -639,4 +639,350 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
     return e;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fused rectify + Gray decode, LDS-DMA form (K1+K3 / K1+K3').  The scheme of the multi-frequency kernel above with the
+// Gray stack's phases: (white, black) -> shadow mask, then one (pattern, inverse) pair per code bit, column bits first
+// (plane 2c + 2 / 2c + 3, reconstruct.cpp:390-391, 352-353), TWO plane pairs per phase: this kernel has no decode tables and its
+// registers (not its LDS) limit it to three workgroups per CU, so the LDS holds 4-plane buffers and a tile needs half the
+// barriers.  The pair count 1 + n_col_bits + n_row_bits is a run-time value, so a tile is phase 0 plus a loop over pairs of
+// phases (the two LDS buffers alternate; ODD = the phase count is odd and the buffer roles swap from tile to tile).  One DMA distance (A = 1): every phase starts by draining the vector-memory queue,
+// which also retires the previous tile's stores.  Same boxes and digest as the MF kernel (one set per camera and shape).
+//
+// Reference behaviour restated (never copied): stereoRect::doStereoRectify Duke/stereorect.cpp:26-34 fused with
+// Reconstruct::computeShadows Duke/reconstruct.cpp:210-227, getProjPixel_GE :381-407 / getProjPixel :325-370 and
+// GrayCodes::grayToDec Duke/graycodes.cpp:116-128.
+// ------------------------------------------------------------------------------------------------------
+struct GrayDmaJob {
+    const uint8_t *base;         // plane 0; plane p is base + p * pstride
+    unsigned pstride;
+    unsigned stack_bytes;        // (planes - 1) * pstride + H * pitch
+    const int4 *boxes;
+    const unsigned *digest;
+    unsigned digest_bytes;
+    int32_t *code_x, *code_y;    // code_y may be null
+    uint8_t *valid;              // may be null (the consumer reads validity off code_x == -1)
+};
+struct GrayDmaJobs { GrayDmaJob j[2]; };
+
+#ifndef SLR_GRAY_DMA_WAVES1
+#define SLR_GRAY_DMA_WAVES1 6
+#endif
+#ifndef SLR_GRAY_DMA_NPP
+#define SLR_GRAY_DMA_NPP 2
+#endif
+template <int TW, int TH, int NT, int NPP>
+struct GrayDma {
+    static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
+    typedef DmaGeom<TW, TH, NT> Gm;
+    static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS;
+    // dynamic LDS from address 0: 2 buffers of 4 plane images | scratch slot | digest of the tile | weight tables
+    static constexpr int SCRATCH_OFF = 4 * NPP * PS, DIG_OFF = SCRATCH_OFF + (Gm::NCH < NT ? 1024 : 0), DIG_BYTES = TW * TH * 4;
+    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4;
+    static constexpr int LDS_BYTES = WT_OFF + 2 * 1026 * 4;
+    static_assert(WT_OFF <= 65536, "DMA destinations are 16-bit LDS addresses (M0)");
+
+    const uint8_t *smem;
+    unsigned lds0, wave_off;
+    bool plane_wave, has_cy, has_valid;
+    __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_cx, rs_cy, rs_valid;
+    unsigned pstride;
+    int W, H, black_thr, white_thr, ncol, nrow, npairs, nq, scan_w, scan_h;
+    DmaTap tap[PX];
+    unsigned acc[PX], gxs[PX];           // Gray bits of the axis in flight (MSB first); the finished column word
+    unsigned flags;                      // bit q: shadow mask of pixel q, bit 8 + q: error
+    int out_x[PX], out_y[PX];
+    unsigned out_ok;
+    int out_ty, out_tx;
+    bool out_pending;
+
+    __device__ __forceinline__ void flush() const
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int row0 = out_ty * TH + wv / Gm::WPR, col = out_tx * TW + (wv % Gm::WPR) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < PX; q++) {
+            const int row = row0 + q * Gm::RPP;
+            const bool inb = row < H && col < W;
+            const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)out_x[q], rs_cx, inb ? m * 4u : kDmaInvalid, 0, 2);
+            if (has_cy) __builtin_amdgcn_raw_buffer_store_b32((unsigned)out_y[q], rs_cy, inb ? m * 4u : kDmaInvalid, 0, 2);
+            if (has_valid) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((out_ok >> q) & 1u), rs_valid, inb ? m : kDmaInvalid, 0, 0);
+        }
+    }
+    // the planes of phase k -- plane pairs NPP * k .. -- into buffer buf
+    __device__ __forceinline__ void issue_planes(int k, int buf, unsigned voff) const
+    {
+        const int n = NPP == 1 || 2 * k + 1 < npairs ? 2 * NPP : 2;
+        for (int g = 0; g < n; g++)
+            dma16(voff, rs_stack, plane_wave ? lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + wave_off : lds0 + (unsigned)SCRATCH_OFF,
+                  (unsigned)(2 * NPP * k + g) * pstride);
+    }
+    __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
+    {
+#pragma unroll
+        for (int r = 0; r < PX / 4; r++) {
+            const unsigned voff = live ? tile * (unsigned)DIG_BYTES + (threadIdx.x + (unsigned)(NT * r)) * 16u : kDmaInvalid;
+            dma16(voff, rs_dig, lds0 + (unsigned)(DIG_OFF + r * NT * 16) + wave_off, 0u);
+        }
+    }
+    // code bit from a pair's difference (reconstruct.cpp:387-400 / 349-360); move: the column word is complete behind this bit
+    __device__ __forceinline__ void bit_step(int q, int df, bool move)
+    {
+        flags |= ((df < 0 ? -df : df) < white_thr ? 0x100u : 0u) << q;
+        acc[q] = (acc[q] << 1) | (df > 0 ? 1u : 0u);
+        gxs[q] = move ? acc[q] : gxs[q];
+        acc[q] = move ? 0u : acc[q];
+    }
+    __device__ __forceinline__ void finish(int ty, int tx)
+    {
+        out_ok = 0;
+#pragma unroll
+        for (int q = 0; q < PX; q++) {
+            unsigned gx = gxs[q], gy = acc[q];                     // grayToDec: running XOR from the MSB == prefix XOR
+            gx ^= gx >> 1; gx ^= gx >> 2; gx ^= gx >> 4; gx ^= gx >> 8;
+            gy ^= gy >> 1; gy ^= gy >> 2; gy ^= gy >> 4; gy ^= gy >> 8;
+            const int x = (int)gx, y = (int)gy;
+            bool err = ((flags >> (8 + q)) & 1u) != 0;
+            if (nrow > 0) err = err || y > scan_h || x > scan_w;   // reconstruct.cpp:364 (Q9 '>')
+            else err = err || x > scan_w;                          // reconstruct.cpp:403
+            const bool ok = ((flags >> q) & 1u) != 0 && !err;
+            out_x[q] = ok ? x : -1;
+            out_y[q] = (ok && nrow > 0) ? y : -1;
+            out_ok |= (ok ? 1u : 0u) << q;
+        }
+        out_ty = ty; out_tx = tx; out_pending = true;
+    }
+    // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
+    // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
+    template <int B, bool FIRST>
+    __device__ __forceinline__ void phase(int k, int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    {
+        wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (k == 1) issue_digest(next_tile, has_next);      // (every wave is past its digest reads of phase 0; nq >= 2)
+        const bool last = k + 1 == nq;
+        issue_planes(last ? 0 : k + 1, B ^ 1, last ? voff_next : voff_cur);
+        if constexpr (FIRST) {
+            if (out_pending) flush();
+            const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
+#pragma unroll
+            for (int q = 0; q < PX; q++) {
+                const unsigned e = dg[q];
+                const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e >> 16));
+                tap[q].a0 = (e & 0x1FFCu) | lds0;
+                tap[q].sel = __umul24((e >> 13) & 3u, 0x10001u) + 0x0C010C00u;
+                tap[q].w0 = __builtin_bit_cast(u16x2, wt[WT_OFF / 4]);
+                tap[q].w1 = __builtin_bit_cast(u16x2, wt[WT1_OFF / 4]);
+                acc[q] = 0; gxs[q] = 0;
+            }
+            flags = 0;
+        }
+        constexpr unsigned i00 = (unsigned)(B * 2 * NPP * PS), i01 = i00 + PS, i10 = i00 + 2 * PS, i11 = i00 + 3 * PS;
+        DmaRd r[2];
+        dma_rd<i00, i01, (unsigned)RS>(r[0], tap[0].a0);
+        if constexpr (NPP == 2) {
+            const bool has1 = 2 * k + 1 < npairs;            // (a stack's last phase may hold one pair only)
+            const bool mv0 = 2 * k == ncol, mv1 = 2 * k + 1 == ncol;
+#pragma unroll
+            for (int q = 0; q < PX; q++) {
+                dma_rd<i10, i11, (unsigned)RS>(r[1], tap[q].a0);
+                dma_rd_wait<8>(r[0]);
+                const int d0 = (int)(dma_blend(r[0], 0, tap[q]) >> 16) - (int)(dma_blend(r[0], 1, tap[q]) >> 16);
+                if constexpr (FIRST) flags |= (d0 > black_thr ? 1u : 0u) << q;     // computeShadows, reconstruct.cpp:218-224
+                else bit_step(q, d0, mv0);
+                if (q + 1 < PX) { dma_rd<i00, i01, (unsigned)RS>(r[0], tap[q + 1].a0); dma_rd_wait<8>(r[1]); }
+                else dma_rd_wait<0>(r[1]);
+                const int d1 = (int)(dma_blend(r[1], 0, tap[q]) >> 16) - (int)(dma_blend(r[1], 1, tap[q]) >> 16);
+                if (has1) bit_step(q, d1, mv1);
+            }
+        } else {
+            const bool mv0 = k == ncol;
+#pragma unroll
+            for (int q = 0; q < PX; q++) {
+                if (q + 1 < PX) { dma_rd<i00, i01, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
+                else dma_rd_wait<0>(r[q & 1]);
+                const int d0 = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
+                if constexpr (FIRST) flags |= (d0 > black_thr ? 1u : 0u) << q;
+                else bit_step(q, d0, mv0);
+            }
+        }
+        if (last) finish(ty, tx);
+    }
+    template <int K>
+    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    {
+        const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
+        phase<K, true>(0, ty, tx, voff_cur, voff_next, next_tile, has_next);
+        int k = 1;
+        for (; k + 1 < nq; k += 2) {
+            phase<K ^ 1, false>(k, ty, tx, voff_cur, voff_next, next_tile, has_next);
+            phase<K, false>(k + 1, ty, tx, voff_cur, voff_next, next_tile, has_next);
+        }
+        if (k < nq) phase<K ^ 1, false>(k, ty, tx, voff_cur, voff_next, next_tile, has_next);
+    }
+};
+
+// the LDS would allow 8 waves per SIMD for the 512-thread shapes, 64 VGPRs do not hold a thread's state without spilling
+template <int LDS_BYTES, int NT, int NPP>
+constexpr int gray_dma_waves()
+{
+    constexpr int cap = NPP == 1 ? SLR_GRAY_DMA_WAVES1 : 6;
+    return dma_waves_per_simd<LDS_BYTES, NT>() > cap ? cap : dma_waves_per_simd<LDS_BYTES, NT>();
+}
+
+template <int TW, int TH, int NT, int NPP, bool ODD>
+__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP>::LDS_BYTES, NT, NPP>()))
+void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
+                                 int scan_w, int scan_h, int tiles_x, int tiles_y)
+{
+    typedef GrayDma<TW, TH, NT, NPP> Dec;
+    typedef DmaGeom<TW, TH, NT> Gm;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Dec d;
+    d.smem = smem;
+    d.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    if (d.lds0 & 0x1FFFu) __builtin_trap();                 // the tap addresses OR the buffer base in (no static LDS here: 0)
+    for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
+        unsigned w0, w1;
+        dma_weights(i, w0, w1);
+        *reinterpret_cast<unsigned *>(smem + Dec::WT_OFF + 4u * i) = w0;
+        *reinterpret_cast<unsigned *>(smem + Dec::WT1_OFF + 4u * i) = w1;
+    }
+    __syncthreads();
+    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
+    const bool second = blockIdx.x >= nblk;
+    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
+    const int ji = second ? 1 : 0;
+    const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
+    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
+    if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
+
+    d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
+    d.plane_wave = d.wave_off < (unsigned)Dec::PS;
+    d.pstride = jobs.j[ji].pstride;
+    d.W = W; d.H = H; d.black_thr = black_thr; d.white_thr = white_thr; d.ncol = ncol; d.nrow = nrow; d.npairs = 1 + ncol + nrow; d.nq = (d.npairs + NPP - 1) / NPP;
+    d.scan_w = scan_w; d.scan_h = scan_h;
+    d.has_cy = jobs.j[ji].code_y != nullptr; d.has_valid = jobs.j[ji].valid != nullptr;
+    const int n4 = (int)((unsigned)W * (unsigned)H * 4u);
+    d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
+    d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
+    d.rs_cx = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_x, 0, n4, 0x00020000);
+    d.rs_cy = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_y, 0, d.has_cy ? n4 : 0, 0x00020000);
+    d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, d.has_valid ? n4 / 4 : 0, 0x00020000);
+    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
+
+    const int crow = (int)threadIdx.x / Gm::CMAX, ccol = (int)threadIdx.x - crow * Gm::CMAX;
+    auto box_voff = [&](const int4 b) -> unsigned {
+        const int gx = b.x + 16 * ccol, gy = b.y + crow;
+        const bool in = (int)threadIdx.x < Gm::NCH && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
+    };
+
+    int cur = xcd * per + lb;
+    unsigned voff_cur = box_voff(boxes[cur]);
+    d.out_pending = false;
+    d.issue_digest((unsigned)cur, true);                    // prologue = what the last phase of a previous tile would have issued
+    d.issue_planes(0, 0, voff_cur);
+
+    int it = 1;
+    for (;;) {
+#define SLR_GDMA_TILE(K0)                                                                                      \
+        {                                                                                                      \
+            const int nl = lb + it * nbx;                                                                      \
+            const bool has_next = nl < per && xcd * per + nl < T;                                              \
+            const int nxt = has_next ? xcd * per + nl : cur;                                                   \
+            const unsigned voff_next = has_next ? box_voff(boxes[nxt]) : kDmaInvalid;                          \
+            d.template tile<K0>(cur, tiles_x, voff_cur, voff_next, (unsigned)nxt, has_next);                   \
+            if (!has_next) break;                                                                              \
+            cur = nxt; voff_cur = voff_next; it++;                                                             \
+        }
+        SLR_GDMA_TILE(0)
+        if constexpr (ODD) SLR_GDMA_TILE(1)
+#undef SLR_GDMA_TILE
+    }
+    d.flush();
+    wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
+}
+
+static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, int32_t *cx, int32_t *cy, uint8_t *valid, const void *tiles,
+                         int shape, GrayDmaJob &j)
+{
+    if (!tiles || W % 16 != 0 || pitch % 16 != 0 || ((uintptr_t)pl.p[0] % 16) != 0 || ((uintptr_t)cx % 4) != 0 || ((uintptr_t)cy % 4) != 0)
+        return false;
+    const long long st = (long long)(pl.p[1] - pl.p[0]);
+    if (st < (long long)H * pitch || st % 16 != 0) return false;
+    for (int i = 2; i < np; i++) if ((long long)(pl.p[i] - pl.p[0]) != st * i) return false;
+    const long long bytes = st * (np - 1) + (long long)H * pitch;
+    if (bytes >= (1ll << 31) || (long long)W * H * 4 >= (1ll << 31)) return false;
+    const char *b = reinterpret_cast<const char *>(tiles);
+    j.base = pl.p[0]; j.pstride = (unsigned)st; j.stack_bytes = (unsigned)bytes;
+    j.boxes = reinterpret_cast<const int4 *>(b);
+    j.digest = reinterpret_cast<const unsigned *>(b + dma_digest_offset(W, H, shape));
+    const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+    if (dg >= (1ull << 31)) return false;
+    j.digest_bytes = (unsigned)dg;
+    j.code_x = cx; j.code_y = cy; j.valid = valid;
+    return true;
+}
+
+template <int TW, int TH, int NT, int NPP, bool ODD>
+static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol,
+                                          int nrow, int scan_w, int scan_h, hipStream_t s)
+{
+    typedef GrayDma<TW, TH, NT, NPP> Dec;
+    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD>;
+    static int resident[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int &res = resident[dev & 63];
+    if (!res) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        res = per_cu * cus;
+    }
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int T = tiles_x * tiles_y, per = (T + 7) / 8;
+    const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
+    int nbx = r / 8 < per ? r / 8 : per;
+    if (nbx < 1) nbx = 1;
+    SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, white_thr,
+               ncol, nrow, scan_w, scan_h, tiles_x, tiles_y);
+    return hipGetLastError();
+}
+
+// one camera (n == 1) or both cameras of a stereo frame (n == 2) in one launch; *done = false: the form does not apply (stack
+// layout, image width, a tile shape without a Gray instantiation), nothing was launched
+hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
+                                       int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
+                                       uint8_t *const *valid, const void *const *tiles, int shape, bool *done, hipStream_t s)
+{
+    *done = false;
+    if (shape != 1 && shape != 3 && shape != 4 && shape != 5) return hipSuccess;      // the 4-pixels-per-thread shapes
+    if (ncol + nrow < 2) return hipSuccess;                 // (a tile needs two phases: the next digest arrives during the second)
+    const int np = 2 + 2 * ncol + 2 * nrow;
+    GrayDmaJobs j;
+    for (int c = 0; c < n; c++)
+        if (!gray_dma_job(pl[c], np, pitch, W, H, code_x[c], code_y[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
+    if (n == 1) j.j[1] = j.j[0];
+    *done = true;
+    constexpr int NPP = SLR_GRAY_DMA_NPP;
+    const bool odd = ((((1 + ncol + nrow) + NPP - 1) / NPP) & 1) != 0;   // phases (of NPP plane pairs) per tile
+    hipError_t e = hipSuccess;
+#define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
+    e = odd ? launch_gray_dma_variant<TW, TH, NT, NPP, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, s)    \
+            : launch_gray_dma_variant<TW, TH, NT, NPP, false>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, s)
+    switch (shape) {
+    case 1:  SLR_GDMA_X(256, 8, 512); break;
+    case 4:  SLR_GDMA_X(128, 8, 256); break;
+    case 5:  SLR_GDMA_X(256, 4, 256); break;
+    default: SLR_GDMA_X(128, 16, 512); break;
+    }
+#undef SLR_GDMA_X
+    return e;
+}
+
+
 }  // namespace slr

@@ -336,6 +336,19 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
     const int n = 2 + 2 * ncol + 2 * nrow;
     for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) gp.p[i] = i < n ? pl[i] : nullptr;
     ProfScope ps(c, rectify ? K_GRAY_RECT_DECODE : K_GRAY_DECODE, true);
+    if (rectify && dma_form_wanted(c, cam, cam)) {          // the LDS-DMA form (kernels_rectdma.hip), when the maps and the stack allow
+        bool done = false;
+        int32_t *const xs[1] = {cx}, *const ys[1] = {cy};
+        uint8_t *const vd[1] = {valid};
+        const void *const tl[1] = {c->d_dma_tiles[cam]};
+        SLR_HIP(c, launch_gray_rect_decode_dma(&gp, 1, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, xs, ys, vd, tl,
+                                               c->opt_dma_shape, &done, c->stream));
+        if (done) return SLR_OK;
+    }
+    if (rectify && c->opt_rect_algo == 7)
+        return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_RECT_DECODE_ALGO = 7 (LDS-DMA form) does not apply: it needs equally spaced planes in one "
+                                            "allocation, 16-byte aligned rows, W % 16 == 0, at least two code bits, a 4-pixel tile shape "
+                                            "(SLR_OPT_RECT_DMA_SHAPE 1, 3, 4 or 5) and maps whose tile boxes fit");
     SLR_HIP(c, launch_gray_decode(gp, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, cx, cy, valid,
                                   rectify ? c->d_map_xy[cam] : nullptr, rectify ? c->d_map_frac[cam] : nullptr,
                                   rectify ? c->d_tile_box[cam] : nullptr, c->opt_rect_algo, c->stream));
@@ -1234,9 +1247,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..3");
+            if (value < 0 || value > 7) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..7");
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
+            c->debug.no_ge_lean = (value & 4) != 0;
             return SLR_OK;
 #ifdef SLR_DEBUG_HOOKS
         case SLR_OPT_DEBUG_K4_STOP:

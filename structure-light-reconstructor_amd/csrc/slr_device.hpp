@@ -54,6 +54,7 @@ struct DebugKnobs {
     int rect_resident = 0;       // > 0: resident workgroups of the persistent fused decodes (tests: many tiles per workgroup)
     bool no_tiled_map = false;   // fused decode: read the caller's 6-byte map entries instead of the digest
     bool no_buffer_form = false; // fused decode: per-plane pointers instead of one buffer descriptor
+    bool no_ge_lean = false;     // K5: the general kernel for every row
     int k4_stop = 0;
 };
 extern thread_local DebugKnobs tl_debug;
@@ -109,6 +110,9 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
                                      bool *done, hipStream_t s);
 
+hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
+                                       int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
+                                       uint8_t *const *valid, const void *const *tiles, int shape, bool *done, hipStream_t s);
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,
