@@ -53,6 +53,7 @@ ALG_BYTES = {
     "slr_remap_u8": 8.0,
     # Gray modes (per cam-px / per st-px), 4096-wide projector: 2 + 2 x 12 planes
     "slr_gray_rectify_decode": 36.0,   # 26 src + 6 map + 4 code (inside slr_reconstruct_ge the valid flag is code -1)
+    "slr_gray_rectify_decode_pair": 72.0,  # both cameras of the frame in one launch, per st-px
     "slr_ge_match_triangulate": 21.0,  # 2 x 4 code read + 12 xyz + 1 mask write
 }
 
@@ -60,11 +61,12 @@ ALG_BYTES = {
 DEVICE_KERNEL = {
     "slr_mf_rectify_decode_pair": ("mf_rect_decode_dma_kernel", "mf_rect_decode_lds_kernel"),
     "slr_mf_rectify_decode": ("mf_rect_decode_dma_kernel", "mf_rect_decode_lds_kernel"),
-    "slr_mf_match_triangulate": ("mf_match_binned_kernel", "mf_match_chunked_kernel"),
+    "slr_mf_match_triangulate": ("mf_match_lean_kernel", "mf_match_binned_kernel", "mf_match_chunked_kernel"),
     "slr_mf_decode": ("mf_decode_kernel",),
-    "slr_gray_rectify_decode": ("gray_rect_decode_lds_kernel",),
+    "slr_gray_rectify_decode": ("gray_rect_decode_dma_kernel", "gray_rect_decode_lds_kernel"),
+    "slr_gray_rectify_decode_pair": ("gray_rect_decode_dma_kernel", "gray_rect_decode_lds_kernel"),
     "slr_gray_decode": ("gray_decode_kernel",),
-    "slr_ge_match_triangulate": ("ge_match_kernel",),
+    "slr_ge_match_triangulate": ("ge_match_lean_kernel", "ge_match_kernel"),
     "slr_ray_triangulate": ("ray_triangulate_kernel",),
     "slr_ray_count": ("ray_count_kernel",),
 }

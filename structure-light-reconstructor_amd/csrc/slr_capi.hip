@@ -22,7 +22,8 @@ const char *kKernelNames[K_COUNT] = {
     "slr_remap_u8", "slr_mf_decode", "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode",
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
     "slr_ray_triangulate",
-    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair", "slr_mfn_decode"};
+    "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair", "slr_mfn_decode",
+    "slr_gray_rectify_decode_pair"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -1008,10 +1009,23 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
     SLR_TRY(st.out(have_color ? color : nullptr, n, &dc));
     SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl));
     SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr));
-    SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
-                             (int32_t *)cxl, nullptr, (uint8_t *)vl));
-    SLR_TRY(core_gray_decode(c, 1, rectify != 0, dr, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
-                             (int32_t *)cxr, nullptr, (uint8_t *)vr));
+    bool paired = false;
+    if (rectify && dma_form_wanted(c, 0, 1)) {               // both cameras' fused decodes in one launch (LDS-DMA form)
+        GrayPlanes gp[2];
+        for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) { gp[0].p[i] = i < np ? dl[i] : nullptr; gp[1].p[i] = i < np ? dr[i] : nullptr; }
+        int32_t *const xs[2] = {(int32_t *)cxl, (int32_t *)cxr}, *const ys[2] = {nullptr, nullptr};
+        uint8_t *const vd[2] = {(uint8_t *)vl, (uint8_t *)vr};
+        const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
+        ProfScope ps(c, K_GRAY_RECT_DECODE_PAIR, true);
+        SLR_HIP(c, launch_gray_rect_decode_dma(gp, 2, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, xs, ys, vd, tl,
+                                               c->opt_dma_shape, &paired, c->stream));
+    }
+    if (!paired) {
+        SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
+                                 (int32_t *)cxl, nullptr, (uint8_t *)vl));
+        SLR_TRY(core_gray_decode(c, 1, rectify != 0, dr, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,
+                                 (int32_t *)cxr, nullptr, (uint8_t *)vr));
+    }
     // colour uses the RECTIFIED white images (reconstruct.cpp:193 color = camImgs[0])
     const uint8_t *wl = nullptr, *wr = nullptr;
     if (have_color) {

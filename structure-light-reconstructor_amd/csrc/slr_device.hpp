@@ -37,7 +37,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_GRAY_RECT_DECODE_PAIR, K_COUNT
 };
 
 // Every kernel launch goes through SLR_LAUNCH.  When the C-ABI layer's profiler has armed a pair of events for the
