@@ -44,7 +44,11 @@ if "mf" in WHAT:
     for _ in range(REPS):
         ctx.reconstruct_mf_batch(st2, 40, True, xyz=x2, has=h2)                # the pair launch (valid folded) + K4, as bench.py
     for _ in range(REPS):
-        ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4 indexed
+        ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4 indexed (lean form)
+    ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 3)
+    for _ in range(REPS):
+        ctx.mf_triangulate(ph[0], vd[0], ph[1], vd[1], want_match=False)       # K4, round 1's general binned form
+    ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
     tmp = torch.empty((H, W), dtype=torch.uint8, device=dev)
     for _ in range(REPS):
         ctx.remap_u8(0, st[0, 3], out=tmp)                                     # K1
@@ -61,7 +65,17 @@ if "gray" in WHAT:
     for _ in range(REPS):
         dec = [ctx.gray_decode(g[cam], ncol, 0, 40, 0, W, 0, rectify_cam=cam) for cam in range(2)]   # fused K1+K3
     for _ in range(REPS):
-        ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False)   # K5
+        ctx.ge_triangulate(dec[0][0], dec[0][2], dec[1][0], dec[1][2], want_match=False)   # K5 (lean form)
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 5)
+    for _ in range(REPS):
+        ctx.gray_decode(g[0], ncol, 0, 40, 0, W, 0, rectify_cam=0)                          # round 1's register-staged fused form
+    ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+if "ge" in WHAT:
+    g = synth.render_gray_stack(W, H, W, seed=1234, device=dev)
+    ncol = synth.gray_num_bits(W)
+    torch.cuda.synchronize()
+    for _ in range(REPS):
+        ctx.reconstruct_ge(g[0], g[1], ncol, 40, 0, W, True, False)                                # GRAY_EPI as bench.py --mode ge: pair launch + K5
 if "ray" in WHAT:
     # GRAY_ONLY: column + row bits, counting sort by projector cell, ray-ray triangulation (scan area = camera area)
     calib2, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)

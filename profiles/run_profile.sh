@@ -22,7 +22,7 @@ cp "$OUT"/bench/*kernel_stats.csv "$SUM/${TAG}_bench_kernel_stats.csv" 2>/dev/nu
 grep '^{"metric"' "$OUT/bench_stdout.log" | tail -1 > "$SUM/${TAG}_bench_line.json"
 
 # 2. kernel trace + stats of the per-kernel driver
-SLR_WHAT=mf,gray,ray rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1
+SLR_WHAT=mf,gray,ge,ray rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1
 cp "$OUT"/drv/*kernel_stats.csv "$SUM/${TAG}_driver_kernel_stats.csv" 2>/dev/null
 for M in ge gray; do
     rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench_$M" -o bench -- python "$REPO/bench.py" --mode $M --steps 5 --warmup 1 --cpu-baseline 0 --host-io 0 --traffic off \
@@ -33,7 +33,7 @@ done
 
 # 3. PMC passes (each its own run), one driver group at a time so that a kernel that serves several plane counts (the Gray decode:
 #    26 planes in GRAY_EPI, 44+ in GRAY_ONLY) is summarised per group: the summary keys on <group>:<kernel>
-for GROUP in mf gray ray; do
+for GROUP in mf gray ge ray; do
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

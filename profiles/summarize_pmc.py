@@ -53,9 +53,12 @@ PROFILER_NAME = [
     ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, true>", "slr_mf_rectify_decode"),
     ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, false>", "slr_mf_rectify_decode_pair"),
     ("mf:mf_rect_decode_lds_kernel", "slr_mf_rectify_decode[round-1 form 5]"), ("mf_decode_kernel", "slr_mf_decode"),
-    ("remap_kernel", "slr_remap_u8"), ("gray_rect_decode_lds_kernel", "slr_gray_rectify_decode"),
-    ("gray:gray_decode_kernel<4, false>", "slr_gray_decode"), ("ray:gray_decode_kernel<4, false>", "slr_gray_decode[columns+rows]"), ("mf_match_binned_kernel", "slr_mf_match_triangulate"),
-    ("ge_match_kernel", "slr_ge_match_triangulate"), ("ray_count_kernel", "slr_ray_count"),
+    ("remap_kernel", "slr_remap_u8"),
+    ("gray:gray_rect_decode_dma_kernel", "slr_gray_rectify_decode"), ("ge:gray_rect_decode_dma_kernel", "slr_gray_rectify_decode_pair"),
+    ("gray_rect_decode_lds_kernel", "slr_gray_rectify_decode[round-1 form]"),
+    ("mf_match_lean_kernel", "slr_mf_match_triangulate"), ("ge_match_lean_kernel", "slr_ge_match_triangulate"),
+    ("gray:gray_decode_kernel<4, false>", "slr_gray_decode"), ("ray:gray_decode_kernel<4, false>", "slr_gray_decode[columns+rows]"), ("mf_match_binned_kernel", "slr_mf_match_triangulate[general binned form]"),
+    ("ge_match_kernel", "slr_ge_match_triangulate[general form]"), ("ray_count_kernel", "slr_ray_count"),
     ("ray_scatter_kernel", "slr_ray_scatter"), ("ray_triangulate_kernel", "slr_ray_triangulate"),
 ]
 

@@ -33,18 +33,36 @@ __global__ __launch_bounds__(256) void ray_count_kernel(const int32_t *__restric
                                                         uint32_t *__restrict__ cell_of, uint32_t *__restrict__ rank_of)
 {
     const unsigned nb = (unsigned)scan_w * (unsigned)scan_h;
-    for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+    const unsigned lane = threadIdx.x & 63u;
+    // (the trip count is wave-uniform: the loop body uses wave-wide operations)
+    for (unsigned p0 = blockIdx.x * 256u + (threadIdx.x & ~63u); p0 < npix; p0 += gridDim.x * 256u) {
+        const unsigned p = p0 + lane;
         unsigned cell = kNoBucket, rank = 0;
-        if (valid[p]) {
+        if (p < npix && valid[p]) {
             const unsigned long long k = (unsigned long long)code_x[p] * (unsigned)scan_h + (unsigned)code_y[p];
             if (k < nb) {                                      // Q9: ac >= scan_w*scan_h is an OOB write -> dropped
                 const unsigned i = (unsigned)k / (unsigned)scan_h, j = (unsigned)k - i * (unsigned)scan_h;
                 cell = j * (unsigned)scan_w + i;               // (a code_y >= scan_h aliases into column i+1.., as ac does)
-                rank = atomicAdd(&cnt[cell], 1u);
             }
         }
-        cell_of[p] = cell;
-        rank_of[p] = rank;
+        // A camera sees a projector pixel in a run of adjacent pixels of a row, i.e. in adjacent lanes: one atomic per RUN of
+        // equal cells (its first lane adds the run's length and hands the others their places) instead of one per pixel.
+        // The order inside a bucket is arbitrary here (ray_triangulate sorts it), only the ranks must be a permutation.
+        const unsigned prev = __shfl_up(cell, 1);
+        const bool head = lane == 0 || cell != prev;
+        const unsigned long long H = __ballot(head);
+        const unsigned long long upto = H & (~0ull >> (63u - lane));                  // heads at or below this lane
+        const unsigned start = 63u - (unsigned)__builtin_clzll(upto);                 // (lane 0 is a head: never empty)
+        const unsigned long long above = start == 63u ? 0ull : H & ~((2ull << start) - 1ull);
+        const unsigned len = (above ? (unsigned)__builtin_ctzll(above) : 64u) - start;
+        unsigned first = 0;
+        if (head && cell != kNoBucket) first = atomicAdd(&cnt[cell], len);
+        first = __shfl(first, (int)start);
+        rank = first + (lane - start);
+        if (p < npix) {
+            cell_of[p] = cell;
+            rank_of[p] = cell != kNoBucket ? rank : 0u;
+        }
     }
 }
 
@@ -215,6 +233,10 @@ __global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__
                                                               const float *__restrict__ raysL, const float *__restrict__ raysR,
                                                               float *__restrict__ xyz_sum, uint8_t *__restrict__ count)
 {
+    // the right bucket's rays are read once per LEFT pixel of the bucket: the first kRayCap of them wait in LDS ([ray][thread]:
+    // conflict-free), fetched once per bucket, instead of being gathered from the table (len_L x len_R) times
+    constexpr unsigned kRayCap = 12;
+    __shared__ float stage[kRayCap][3][256];
     float posL[3] = {0, 0, 0}, posR[3] = {0, 0, 0};
     cam2world(cal.cam[0], posL);                   // reconstruct.cpp:239-240
     cam2world(cal.cam[1], posR);
@@ -226,12 +248,20 @@ __global__ __launch_bounds__(256) void ray_triangulate_kernel(const uint32_t *__
         if (l1 > l0 && r1 > r0) {
             if (l1 - l0 > 1) sort_bucket(items, l0, l1);
             if (r1 - r0 > 1) sort_bucket(items, r0, r1);
+            const unsigned nst = r1 - r0 < kRayCap ? r1 - r0 : kRayCap;
+            for (unsigned k = 0; k < nst; k++) {
+                float ry[3];
+                load_ray(raysR, items[r0 + k], W, ry);
+                stage[k][0][threadIdx.x] = ry[0]; stage[k][1][threadIdx.x] = ry[1]; stage[k][2][threadIdx.x] = ry[2];
+            }
             for (unsigned c1 = l0; c1 < l1; c1++) {
                 float ray1[3];
                 load_ray(raysL, items[c1], W, ray1);
                 for (unsigned c2 = r0; c2 < r1; c2++) {
                     float ray2[3], X[3];
-                    load_ray(raysR, items[c2], W, ray2);
+                    if (c2 - r0 < kRayCap) {
+                        ray2[0] = stage[c2 - r0][0][threadIdx.x]; ray2[1] = stage[c2 - r0][1][threadIdx.x]; ray2[2] = stage[c2 - r0][2][threadIdx.x];
+                    } else load_ray(raysR, items[c2], W, ray2);
                     if (!line_line(posL, ray1, posR, ray2, X)) continue;
                     if (cal.has_T) {
                         float Y[3];
