@@ -420,13 +420,29 @@ struct DmaDecode {
         }
 #else
         DmaRd r[2];
+        // A wave in its tap loop outranks the waves that are not: without it the SIMD's waves advance through the loop in
+        // lockstep (all reading, then all blending); with it one runs ahead and the LDS and VALU work of different waves
+        // overlap (157 -> 150 us per pair launch; priority by wave or by workgroup, or only around the read issue: 154-156)
+#ifndef SLR_DMA_PRIO
+#define SLR_DMA_PRIO 1
+#endif
+#ifndef SLR_DMA_PRIO_MODE
+#define SLR_DMA_PRIO_MODE 1
+#endif
+        if (SLR_DMA_PRIO_MODE != 3) __builtin_amdgcn_s_setprio(SLR_DMA_PRIO);
         dma_rd<img0, img1, (unsigned)RS>(r[0], tap[0].a0);
 #pragma unroll
         for (int q = 0; q < PX; q++) {
-            if (q + 1 < PX) { dma_rd<img0, img1, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
+            if (q + 1 < PX) {
+                if (SLR_DMA_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(SLR_DMA_PRIO);
+                dma_rd<img0, img1, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0);
+                if (SLR_DMA_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
+                dma_rd_wait<8>(r[q & 1]);
+            }
             else dma_rd_wait<0>(r[q & 1]);
             sd[q] = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
         }
+        __builtin_amdgcn_s_setprio(SLR_DMA_PRIO_MODE == 3 ? SLR_DMA_PRIO : 0);
 #endif
         if constexpr (P == 0) {
 #pragma unroll
@@ -458,6 +474,9 @@ struct DmaDecode {
             }
             if constexpr (P == 6) { out_ok = ok; out_ty = ty; out_tx = tx; out_pending = true; }
         }
+#if !defined(SLR_DMA_ABL)
+        if (SLR_DMA_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
+#endif
     }
 
     template <int K0>
@@ -516,6 +535,12 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
 
     d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
+#if defined(SLR_DMA_STATIC_PRIO)
+    {   // static priorities: 1 = by wave, 2 = by workgroup
+        const unsigned w = __builtin_amdgcn_readfirstlane(SLR_DMA_STATIC_PRIO == 1 ? (threadIdx.x >> 6) & 3u : (blockIdx.x >> 3) & 3u);
+        if (w == 0) __builtin_amdgcn_s_setprio(0); else if (w == 1) __builtin_amdgcn_s_setprio(1); else if (w == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
+    }
+#endif
     d.plane_wave = d.wave_off < (unsigned)Dec::PS;
     d.pstride = jobs.j[ji].pstride;
     d.W = W; d.H = H; d.black_thr = black_thr;
@@ -779,6 +804,9 @@ struct GrayDma {
         }
         constexpr unsigned i00 = (unsigned)(B * 2 * NPP * PS), i01 = i00 + PS, i10 = i00 + 2 * PS, i11 = i00 + 3 * PS;
         DmaRd r[2];
+#if !defined(SLR_GRAY_NO_PRIO)
+        __builtin_amdgcn_s_setprio(1);                       // (see the MF kernel: a wave in its tap loop outranks the others)
+#endif
         dma_rd<i00, i01, (unsigned)RS>(r[0], tap[0].a0);
         if constexpr (NPP == 2) {
             const bool has1 = 2 * k + 1 < npairs;            // (a stack's last phase may hold one pair only)
@@ -806,6 +834,7 @@ struct GrayDma {
                 else bit_step(q, d0, mv0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (last) finish(ty, tx);
     }
     template <int K>
