@@ -55,6 +55,9 @@ ALG_BYTES = {
     "slr_gray_rectify_decode": 36.0,   # 26 src + 6 map + 4 code (inside slr_reconstruct_ge the valid flag is code -1)
     "slr_gray_rectify_decode_pair": 72.0,  # both cameras of the frame in one launch, per st-px
     "slr_ge_match_triangulate": 21.0,  # 2 x 4 code read + 12 xyz + 1 mask write
+    # GRAY_ONLY, per st-px of the CAMERA image (the projector's 1280x1024 cells add 29 B each = 3 B per camera pixel here)
+    "slr_ray_triangulate": 35.0,       # 2 x (4 item + 12 ray) read + per cell 16 offsets read + 13 sum/count write
+    "slr_ray_count": 34.0,             # both cameras: 2 x (4 + 4 code + 1 valid read, 4 cell + 4 rank write)
 }
 
 # rocprofv3 kernel-name prefixes of the profiler names above (roofline.traffic)
