@@ -27,14 +27,17 @@ namespace slr {
 
 constexpr unsigned kDmaInvalid = 0x80000000u;    // buffer offset beyond every descriptor's range: loads 0, stores nothing
 
-// destination tile TW x TH decoded by a workgroup of NT threads: pixel (row, col) of the tile belongs to pass q, wave w, lane l
-// with row = q * RPP + w / WPR, col = (w % WPR) * 64 + l.
+// destination tile TW x TH decoded by a workgroup of NT threads.  A thread owns QUADS of 4 horizontally adjacent pixels (one or
+// two per tile): quad g = pass * NT + thread lies in tile row g / (TW / 4) at columns 4 * (g % (TW / 4)) .. + 3.  The four pixels of
+// a quad almost always take their taps from the same 8 source bytes of two (or three) source rows -- see the digest below.
 template <int TW, int TH, int NT>
 struct DmaGeom {
     static constexpr int NWAVES = NT / 64;
-    static constexpr int PX = TW * TH / NT;                     // pixels per thread (= passes)
-    static constexpr int WPR = TW / 64;                         // waves per tile row
-    static constexpr int RPP = NWAVES / WPR;                    // tile rows per pass
+    static constexpr int PX = TW * TH / NT;                     // pixels per thread
+    static constexpr int NQ = PX / 4;                           // quads per thread (= passes)
+    static constexpr int QPR = TW / 4;                          // quads per tile row
+    static constexpr int WPR = TW / 64;                         // (waves per tile row of the chunk ownership, unchanged)
+    static constexpr int RPP = NWAVES / WPR;
     static constexpr int CMAX = TW / 16 + 2;                    // 16-byte chunks per source row held in LDS
     static constexpr int BHMAX = (TH + 8) * CMAX <= NT ? TH + 8 : NT / CMAX;   // source rows held (one chunk per thread)
     static constexpr int RS = CMAX * 16;                        // LDS row stride (bytes)
@@ -61,11 +64,19 @@ static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape ==
     default: X(256, 16, 512); break;                    \
     }
 
-// map digest, one dword per destination pixel, [tile][thread][pass] (a thread's PX entries are contiguous):
+// map digest, one dword per destination pixel, [tile][thread][pass][pixel of the quad] (a thread's PX entries are contiguous):
 //   [12:2]  dword index of the tap's upper left byte in a plane's LDS image: (sy - y0) * (CMAX * 4) + ((sx - x0) >> 2)
 //   [14:13] (sx - x0) & 3
 //   [31:16] 4 * (fy << 5 | fx)  (cv::remap's 5-bit fractions: the byte offset of the pixel's entry in the weight tables), or
 //           4 * 1024: the sample is 0 (pixel beyond the ragged image edge, or footprint completely outside the source)
+// and the QUAD's class, from which the kernel picks a wave-uniform way of reading the taps:
+//   class 0: all four pixels' taps lie in source rows r0, r0+1 and in the two dwords c0, c0+1 of those rows -> 4 dword reads per
+//            plane serve the whole quad (instead of 4 per pixel); class 1: the same with rows r0 .. r0+2 (the quad straddles a
+//            step of sy); class 2: anything else (the per-pixel reads).  With a scale near 1 a quad spans source bytes
+//            x .. x+4 -- always inside two dwords -- so class 2 is borders and strongly distorting maps.
+//   bit 0   the pixel's dword column minus c0 (0 / 1), bit 1: its sy minus r0 (0 / 1); classes 0 and 1 only
+//   bit 15  entry 0: class & 1, entry 1: class >> 1
+//   A zero-sample pixel inside a class 0 / 1 quad carries the quad's base address (r0, c0) in [12:2]: entry 0 always yields it.
 // box table: int4 per tile = x0 (multiple of 16, may be negative), y0, chunks per row, rows; z == 0: nothing to fetch
 constexpr unsigned kDmaZeroEntry = 1024u << 18;
 template <int TW, int TH, int NT>
@@ -83,7 +94,8 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
 #pragma unroll
     for (int q = 0; q < Gm::PX; q++) {
-        const int row = ty * TH + q * Gm::RPP + wv / Gm::WPR, col = tx * TW + (wv % Gm::WPR) * 64 + lane;
+        const int g = (q >> 2) * NT + (int)threadIdx.x;
+        const int row = ty * TH + g / Gm::QPR, col = tx * TW + (g % Gm::QPR) * 4 + (q & 3);
         sxs[q] = 0x7FFFFFFF; sys[q] = 0; frs[q] = 0;
         if (row < H && col < W) {
             const size_t m = (size_t)row * W + col;
@@ -126,13 +138,41 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     __syncthreads();
     const int x0 = sbox[0], y0 = sbox[1], fits = sbox[2];
 #pragma unroll
-    for (int q = 0; q < Gm::PX; q++) {
-        unsigned e = kDmaZeroEntry;
-        if (fits && sxs[q] != 0x7FFFFFFF) {
-            const int bx = sxs[q] - x0, r0 = sys[q] - y0;
-            e = (unsigned)(r0 * (Gm::CMAX * 4) + (bx >> 2)) << 2 | ((unsigned)bx & 3u) << 13 | frs[q] << 18;
+    for (int p = 0; p < Gm::NQ; p++) {
+        // the quad's class and base (r0, c0) over its pixels that sample anything
+        int r0 = 0x7FFFFFFF, r1 = -0x7FFFFFFF, c0 = 0x7FFFFFFF, c1 = -0x7FFFFFFF;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = 4 * p + i;
+            if (fits && sxs[q] != 0x7FFFFFFF) {
+                const int rr = sys[q] - y0, cc = (sxs[q] - x0) >> 2;
+                r0 = rr < r0 ? rr : r0; r1 = rr > r1 ? rr : r1; c0 = cc < c0 ? cc : c0; c1 = cc > c1 ? cc : c1;
+            }
         }
-        digest[(size_t)blockIdx.x * (TW * TH) + threadIdx.x * Gm::PX + q] = e;
+        const bool none = r0 == 0x7FFFFFFF;
+        if (none) { r0 = r1 = c0 = c1 = 0; }
+        bool wide = r1 - r0 > 1 || c1 - c0 > 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                       // the RIGHT tap too must lie inside the 8 bytes c0*4 .. c0*4+7
+            const int q = 4 * p + i;
+            if (fits && sxs[q] != 0x7FFFFFFF && (sxs[q] - x0) - 4 * c0 > 6) wide = true;
+        }
+        const unsigned cls = wide ? 2u : (r1 > r0 ? 1u : 0u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = 4 * p + i;
+            unsigned e = kDmaZeroEntry;
+            if (fits && sxs[q] != 0x7FFFFFFF) {
+                const int bx = sxs[q] - x0, rr = sys[q] - y0;
+                e = (unsigned)(rr * (Gm::CMAX * 4) + (bx >> 2)) << 2 | ((unsigned)bx & 3u) << 13 | frs[q] << 18;
+                if (cls < 2u) e |= (unsigned)((bx >> 2) - c0) | (unsigned)(rr - r0) << 1;
+            } else if (cls < 2u) {
+                e |= (unsigned)(r0 * (Gm::CMAX * 4) + c0) << 2;          // zero sample, but the quad's base address
+            }
+            if (i == 0) e |= (cls & 1u) << 15;
+            if (i == 1) e |= (cls >> 1) << 15;
+            digest[(size_t)blockIdx.x * (TW * TH) + threadIdx.x * Gm::PX + q] = e;
+        }
     }
 }
 
@@ -263,6 +303,129 @@ __device__ __forceinline__ unsigned dma_blend(const DmaRd &r, int g, const DmaTa
     return acc;
 }
 
+// three source rows of the two planes of a phase (quads of class 1): rows 0, 1 as DmaRd's v[0..7], row 2 in x[0..3]
+struct DmaRd3 { DmaRd a; unsigned x[4]; };
+template <unsigned IMG0, unsigned IMG1, unsigned RS>
+__device__ __forceinline__ void dma_rd_row2(DmaRd3 &r, unsigned addr)
+{
+    asm volatile("ds_read_b32 %0, %4 offset:%5\n\t"
+                 "ds_read_b32 %1, %4 offset:%6\n\t"
+                 "ds_read_b32 %2, %4 offset:%7\n\t"
+                 "ds_read_b32 %3, %4 offset:%8"
+                 : "=&v"(r.x[0]), "=&v"(r.x[1]), "=&v"(r.x[2]), "=&v"(r.x[3])
+                 : "v"(addr), "n"(IMG0 + 2 * RS), "n"(IMG0 + 2 * RS + 4), "n"(IMG1 + 2 * RS), "n"(IMG1 + 2 * RS + 4)
+                 : "memory");
+}
+__device__ __forceinline__ void dma_rd3_wait(DmaRd3 &r)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r.a.v[0]), "+v"(r.a.v[1]), "+v"(r.a.v[2]), "+v"(r.a.v[3]), "+v"(r.a.v[4]), "+v"(r.a.v[5]), "+v"(r.a.v[6]), "+v"(r.a.v[7]),
+                   "+v"(r.x[0]), "+v"(r.x[1]), "+v"(r.x[2]), "+v"(r.x[3])
+                 :: "memory");
+}
+// blended sample of plane g over THREE rows (read mode 1): the pixel's two weight pairs sit in the row slots its sy selects, the
+// third slot is zero -- an exact no-op in the integer dot product, and no per-register selects
+__device__ __forceinline__ unsigned dma_blend3(const DmaRd3 &r, int g, const DmaTap &k)
+{
+    const unsigned p0 = __builtin_amdgcn_perm(r.a.v[4 * g + 1], r.a.v[4 * g], k.sel);
+    const unsigned p1 = __builtin_amdgcn_perm(r.a.v[4 * g + 3], r.a.v[4 * g + 2], k.sel);
+    const unsigned p2 = __builtin_amdgcn_perm(r.x[2 * g + 1], r.x[2 * g], k.sel);
+    unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p0), k.w0, 512u << 6, false);
+    acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p1), k.w1, acc, false);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, p2), __builtin_bit_cast(u16x2, k.a0), acc, false);   // (a0: row 2's weights)
+}
+
+// How a wave reads the taps of its quads in a tile (wave-uniform, from the quads' classes in the digest): 0 = every quad from its
+// 8 bytes x 2 rows, 1 = 8 bytes x 3 rows, 2 = per pixel.  Sets the per-pixel tap state and the quads' base addresses.
+template <int PX, int RS, int WT_OFF, int WT1_OFF>
+__device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0, const unsigned *dg, DmaTap tap[PX], unsigned qbase[PX / 4],
+                                             unsigned &second)
+{
+    unsigned e[PX];
+    unsigned cls = 0;
+#pragma unroll
+    for (int q = 0; q < PX; q++) e[q] = dg[q];
+#pragma unroll
+    for (int p = 0; p < PX / 4; p++) {
+        const unsigned c = ((e[4 * p] >> 15) & 1u) | ((e[4 * p + 1] >> 14) & 2u);
+        cls = c > cls ? c : cls;
+        qbase[p] = ((e[4 * p] & 0x1FFCu) - ((e[4 * p] >> 1) & 1u) * (unsigned)RS - (e[4 * p] & 1u) * 4u) | lds0;
+    }
+#if defined(SLR_DMA_FORCE_MODE) && SLR_DMA_FORCE_MODE == 10      // timing probe: every wave takes mode 0, all three paths compiled
+    const int mode = __builtin_amdgcn_readfirstlane(__ballot(cls == 7u) != 0ull ? 2 : (__ballot(cls == 6u) != 0ull ? 1 : 0));
+#elif defined(SLR_DMA_FORCE_MODE)
+    const int mode = SLR_DMA_FORCE_MODE == 1 ? __builtin_amdgcn_readfirstlane(__ballot(cls == 2u) != 0ull ? 2 : 1) : SLR_DMA_FORCE_MODE;
+#else
+    const int mode = __builtin_amdgcn_readfirstlane(__ballot(cls == 2u) != 0ull ? 2 : (__ballot(cls == 1u) != 0ull ? 1 : 0));
+#endif
+    second = 0;
+#pragma unroll
+    for (int q = 0; q < PX; q++) {
+        const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e[q] >> 16));
+        const unsigned sh = (e[q] >> 13) & 3u;
+        const unsigned o = mode == 2 ? sh : sh + ((e[q] & 1u) << 2);           // byte offset of the left tap in the 8 bytes read
+        tap[q].sel = __umul24(o, 0x10001u) + 0x0C010C00u;
+        const unsigned w0 = wt[WT_OFF / 4], w1 = wt[WT1_OFF / 4];
+        if (mode == 1) {                                     // weights of rows 0, 1, 2 of the quad (the pixel's own rows: st, st + 1)
+            const bool st = ((e[q] >> 1) & 1u) != 0;
+#if !defined(SLR_DMA_NO_SECOND)
+            if (__ballot(st) != 0ull) second |= 1u << q;     // (wave-uniform: does ANY lane's pixel q reach into row 2?)
+#endif
+            tap[q].w0 = __builtin_bit_cast(u16x2, st ? 0u : w0);
+            tap[q].w1 = __builtin_bit_cast(u16x2, st ? w0 : w1);
+            tap[q].a0 = st ? w1 : 0u;
+        } else {
+            tap[q].a0 = (e[q] & 0x1FFCu) | lds0;
+            tap[q].w0 = __builtin_bit_cast(u16x2, w0);
+            tap[q].w1 = __builtin_bit_cast(u16x2, w1);
+        }
+    }
+    return mode;
+}
+
+// sd[q] = blended sample of plane image IMG0 minus IMG1 for the thread's PX pixels, by the tile's read mode
+template <int PX, unsigned IMG0, unsigned IMG1, unsigned RS>
+__device__ __forceinline__ void dma_differences(int mode, const DmaTap tap[PX], const unsigned qbase[PX / 4], unsigned second, int sd[PX])
+{
+    if (mode == 0) {
+        DmaRd r[2];
+        dma_rd<IMG0, IMG1, RS>(r[0], qbase[0]);
+#pragma unroll
+        for (int p = 0; p < PX / 4; p++) {
+            if (p + 1 < PX / 4) { dma_rd<IMG0, IMG1, RS>(r[(p + 1) & 1], qbase[p + 1]); dma_rd_wait<8>(r[p & 1]); }
+            else dma_rd_wait<0>(r[p & 1]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                sd[4 * p + i] = (int)(dma_blend(r[p & 1], 0, tap[4 * p + i]) >> 16) - (int)(dma_blend(r[p & 1], 1, tap[4 * p + i]) >> 16);
+        }
+    } else if (mode == 1) {
+#pragma unroll
+        for (int p = 0; p < PX / 4; p++) {
+            DmaRd3 r;
+            dma_rd<IMG0, IMG1, RS>(r.a, qbase[p]);
+            dma_rd_row2<IMG0, IMG1, RS>(r, qbase[p]);
+            dma_rd3_wait(r);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // a quad that straddles a step of sy does so from some pixel on: the pixels before it never need row 2
+                if ((second >> (4 * p + i)) & 1u)
+                    sd[4 * p + i] = (int)(dma_blend3(r, 0, tap[4 * p + i]) >> 16) - (int)(dma_blend3(r, 1, tap[4 * p + i]) >> 16);
+                else
+                    sd[4 * p + i] = (int)(dma_blend(r.a, 0, tap[4 * p + i]) >> 16) - (int)(dma_blend(r.a, 1, tap[4 * p + i]) >> 16);
+            }
+        }
+    } else {
+        DmaRd r[2];
+        dma_rd<IMG0, IMG1, RS>(r[0], tap[0].a0);
+#pragma unroll
+        for (int q = 0; q < PX; q++) {
+            if (q + 1 < PX) { dma_rd<IMG0, IMG1, RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
+            else dma_rd_wait<0>(r[q & 1]);
+            sd[q] = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
+        }
+    }
+}
+
 // LDS-DMA operations a wave issues per tile, in program order (the static sequence the counted waits rely on):
 //   start of phase p:  [p == 1: PX/4 digest DMAs of the next tile]  2 plane DMAs of phase p + A
 // The wait at the top of phase p lets everything issued after the plane DMAs of phase p itself stay in flight.  Only DMAs
@@ -302,6 +465,9 @@ struct DmaDecode {
     int W, H, black_thr;
     // per-tile state
     DmaTap tap[PX];
+    unsigned qbase[PX / 4];              // LDS address of the 8-byte window of each quad (read modes 0 and 1)
+    unsigned second;                     // bit q (wave-uniform): some lane's pixel q blends rows 1, 2 of its quad's three (read mode 1)
+    int mode;                            // the wave's read mode for this tile (dma_tap_setup)
     // validity.  HASVALID: bit q of ok = pixel q passed the shadow mask and every (n | d) != 0 so far, bit 16 + q = the mask
     // alone.  Folded mode (the flag travels in the phase as a NaN): pm[q] = max over "masked out ? sentinel : INT_MIN" and
     // the wrapped phases so far -- the table returns the sentinel for the undefined case -- so one compare decides at the end.
@@ -318,16 +484,20 @@ struct DmaDecode {
 
     __device__ __forceinline__ void flush() const
     {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int row0 = out_ty * TH + wv / Gm::WPR, col = out_tx * TW + (wv % Gm::WPR) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < PX; q++) {
-            const int row = row0 + q * Gm::RPP;
-            const bool inb = row < H && col < W;
+        for (int p = 0; p < PX / 4; p++) {
+            const int g = p * NT + (int)threadIdx.x;
+            const int row = out_ty * TH + g / Gm::QPR, col = out_tx * TW + (g % Gm::QPR) * 4;
+            const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
-            if constexpr (HASVALID)
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((out_ok >> q) & 1u), rs_valid, inb ? m : kDmaInvalid, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, outv[q]), rs_phase, inb ? m * 4u : kDmaInvalid, 0, 2);
+            if constexpr (HASVALID) {
+                const unsigned ok4 = (out_ok >> (4 * p)) & 0xFu;
+                __builtin_amdgcn_raw_buffer_store_b32(__umul24(ok4, 0x204081u) & 0x01010101u, rs_valid, inb ? m : kDmaInvalid, 0, 0);
+            }
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t v = {__builtin_bit_cast(unsigned, outv[4 * p]), __builtin_bit_cast(unsigned, outv[4 * p + 1]),
+                               __builtin_bit_cast(unsigned, outv[4 * p + 2]), __builtin_bit_cast(unsigned, outv[4 * p + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_phase, inb ? m * 4u : kDmaInvalid, 0, 2);
         }
     }
 
@@ -381,21 +551,12 @@ struct DmaDecode {
         issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? voff_next : voff_cur);
         if constexpr (P == 0) {
             if (out_pending) flush();
-        }
-        constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
-        if constexpr (P == 0) {                                    // tap state of the tile's pixels from the digest
+            // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-#pragma unroll
-            for (int q = 0; q < PX; q++) {
-                const unsigned e = dg[q];
-                const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e >> 16));
-                tap[q].a0 = (e & 0x1FFCu) | lds0;
-                tap[q].sel = __umul24((e >> 13) & 3u, 0x10001u) + 0x0C010C00u;
-                tap[q].w0 = __builtin_bit_cast(u16x2, wt[WT_OFF / 4]);
-                tap[q].w1 = __builtin_bit_cast(u16x2, wt[WT1_OFF / 4]);
-            }
+            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
             ok = 0;
         }
+        constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
         // sd[q] = sample of the phase's first plane minus its second plane (white - black, G1 - G3, G2 - G4), reads one pixel ahead
         int sd[PX];
 #if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 2 || SLR_DMA_ABL == 6)
@@ -419,30 +580,12 @@ struct DmaDecode {
             sd[q] = (int)(r[q & 1].v[0] ^ r[q & 1].v[1] ^ r[q & 1].v[2] ^ r[q & 1].v[3] ^ r[q & 1].v[4] ^ r[q & 1].v[5] ^ r[q & 1].v[6] ^ r[q & 1].v[7]) & 255;
         }
 #else
-        DmaRd r[2];
         // A wave in its tap loop outranks the waves that are not: without it the SIMD's waves advance through the loop in
         // lockstep (all reading, then all blending); with it one runs ahead and the LDS and VALU work of different waves
         // overlap (157 -> 150 us per pair launch; priority by wave or by workgroup, or only around the read issue: 154-156)
-#ifndef SLR_DMA_PRIO
-#define SLR_DMA_PRIO 1
-#endif
-#ifndef SLR_DMA_PRIO_MODE
-#define SLR_DMA_PRIO_MODE 1
-#endif
-        if (SLR_DMA_PRIO_MODE != 3) __builtin_amdgcn_s_setprio(SLR_DMA_PRIO);
-        dma_rd<img0, img1, (unsigned)RS>(r[0], tap[0].a0);
-#pragma unroll
-        for (int q = 0; q < PX; q++) {
-            if (q + 1 < PX) {
-                if (SLR_DMA_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(SLR_DMA_PRIO);
-                dma_rd<img0, img1, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0);
-                if (SLR_DMA_PRIO_MODE == 2) __builtin_amdgcn_s_setprio(0);
-                dma_rd_wait<8>(r[q & 1]);
-            }
-            else dma_rd_wait<0>(r[q & 1]);
-            sd[q] = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
-        }
-        __builtin_amdgcn_s_setprio(SLR_DMA_PRIO_MODE == 3 ? SLR_DMA_PRIO : 0);
+        __builtin_amdgcn_s_setprio(1);
+        dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
+        __builtin_amdgcn_s_setprio(0);
 #endif
         if constexpr (P == 0) {
 #pragma unroll
@@ -474,9 +617,6 @@ struct DmaDecode {
             }
             if constexpr (P == 6) { out_ok = ok; out_ty = ty; out_tx = tx; out_pending = true; }
         }
-#if !defined(SLR_DMA_ABL)
-        if (SLR_DMA_PRIO_MODE == 3) __builtin_amdgcn_s_setprio(0);
-#endif
     }
 
     template <int K0>
@@ -713,6 +853,8 @@ struct GrayDma {
     unsigned pstride;
     int W, H, black_thr, white_thr, ncol, nrow, npairs, nq, scan_w, scan_h;
     DmaTap tap[PX];
+    unsigned qbase[PX / 4], second;      // (the quad read modes of the MF kernel: dma_tap_setup)
+    int mode;
     unsigned acc[PX], gxs[PX];           // Gray bits of the axis in flight (MSB first); the finished column word
     unsigned flags;                      // bit q: shadow mask of pixel q, bit 8 + q: error
     int out_x[PX], out_y[PX];
@@ -722,16 +864,22 @@ struct GrayDma {
 
     __device__ __forceinline__ void flush() const
     {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int row0 = out_ty * TH + wv / Gm::WPR, col = out_tx * TW + (wv % Gm::WPR) * 64 + lane;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int q = 0; q < PX; q++) {
-            const int row = row0 + q * Gm::RPP;
-            const bool inb = row < H && col < W;
+        for (int p = 0; p < PX / 4; p++) {
+            const int g = p * NT + (int)threadIdx.x;
+            const int row = out_ty * TH + g / Gm::QPR, col = out_tx * TW + (g % Gm::QPR) * 4;
+            const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
-            __builtin_amdgcn_raw_buffer_store_b32((unsigned)out_x[q], rs_cx, inb ? m * 4u : kDmaInvalid, 0, 2);
-            if (has_cy) __builtin_amdgcn_raw_buffer_store_b32((unsigned)out_y[q], rs_cy, inb ? m * 4u : kDmaInvalid, 0, 2);
-            if (has_valid) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((out_ok >> q) & 1u), rs_valid, inb ? m : kDmaInvalid, 0, 0);
+            const u32x4_t vx = {(unsigned)out_x[4 * p], (unsigned)out_x[4 * p + 1], (unsigned)out_x[4 * p + 2], (unsigned)out_x[4 * p + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(vx, rs_cx, inb ? m * 4u : kDmaInvalid, 0, 2);
+            if (has_cy) {
+                const u32x4_t vy = {(unsigned)out_y[4 * p], (unsigned)out_y[4 * p + 1], (unsigned)out_y[4 * p + 2], (unsigned)out_y[4 * p + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(vy, rs_cy, inb ? m * 4u : kDmaInvalid, 0, 2);
+            }
+            if (has_valid)
+                __builtin_amdgcn_raw_buffer_store_b32(__umul24((out_ok >> (4 * p)) & 0xFu, 0x204081u) & 0x01010101u, rs_valid,
+                                                      inb ? m : kDmaInvalid, 0, 0);
         }
     }
     // the planes of phase k -- plane pairs NPP * k .. -- into buffer buf
@@ -790,48 +938,30 @@ struct GrayDma {
         if constexpr (FIRST) {
             if (out_pending) flush();
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
+            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
 #pragma unroll
-            for (int q = 0; q < PX; q++) {
-                const unsigned e = dg[q];
-                const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e >> 16));
-                tap[q].a0 = (e & 0x1FFCu) | lds0;
-                tap[q].sel = __umul24((e >> 13) & 3u, 0x10001u) + 0x0C010C00u;
-                tap[q].w0 = __builtin_bit_cast(u16x2, wt[WT_OFF / 4]);
-                tap[q].w1 = __builtin_bit_cast(u16x2, wt[WT1_OFF / 4]);
-                acc[q] = 0; gxs[q] = 0;
-            }
+            for (int q = 0; q < PX; q++) { acc[q] = 0; gxs[q] = 0; }
             flags = 0;
         }
         constexpr unsigned i00 = (unsigned)(B * 2 * NPP * PS), i01 = i00 + PS, i10 = i00 + 2 * PS, i11 = i00 + 3 * PS;
-        DmaRd r[2];
-#if !defined(SLR_GRAY_NO_PRIO)
         __builtin_amdgcn_s_setprio(1);                       // (see the MF kernel: a wave in its tap loop outranks the others)
-#endif
-        dma_rd<i00, i01, (unsigned)RS>(r[0], tap[0].a0);
-        if constexpr (NPP == 2) {
-            const bool has1 = 2 * k + 1 < npairs;            // (a stack's last phase may hold one pair only)
-            const bool mv0 = 2 * k == ncol, mv1 = 2 * k + 1 == ncol;
+        {
+            int sd[PX];
+            dma_differences<PX, i00, i01, (unsigned)RS>(mode, tap, qbase, second, sd);
+            const bool mv0 = NPP * k == ncol;
 #pragma unroll
             for (int q = 0; q < PX; q++) {
-                dma_rd<i10, i11, (unsigned)RS>(r[1], tap[q].a0);
-                dma_rd_wait<8>(r[0]);
-                const int d0 = (int)(dma_blend(r[0], 0, tap[q]) >> 16) - (int)(dma_blend(r[0], 1, tap[q]) >> 16);
-                if constexpr (FIRST) flags |= (d0 > black_thr ? 1u : 0u) << q;     // computeShadows, reconstruct.cpp:218-224
-                else bit_step(q, d0, mv0);
-                if (q + 1 < PX) { dma_rd<i00, i01, (unsigned)RS>(r[0], tap[q + 1].a0); dma_rd_wait<8>(r[1]); }
-                else dma_rd_wait<0>(r[1]);
-                const int d1 = (int)(dma_blend(r[1], 0, tap[q]) >> 16) - (int)(dma_blend(r[1], 1, tap[q]) >> 16);
-                if (has1) bit_step(q, d1, mv1);
+                if constexpr (FIRST) flags |= (sd[q] > black_thr ? 1u : 0u) << q;     // computeShadows, reconstruct.cpp:218-224
+                else bit_step(q, sd[q], mv0);
             }
-        } else {
-            const bool mv0 = k == ncol;
+        }
+        if constexpr (NPP == 2) {
+            if (2 * k + 1 < npairs) {                        // (a stack's last phase may hold one pair only)
+                int sd[PX];
+                dma_differences<PX, i10, i11, (unsigned)RS>(mode, tap, qbase, second, sd);
+                const bool mv1 = 2 * k + 1 == ncol;
 #pragma unroll
-            for (int q = 0; q < PX; q++) {
-                if (q + 1 < PX) { dma_rd<i00, i01, (unsigned)RS>(r[(q + 1) & 1], tap[q + 1].a0); dma_rd_wait<8>(r[q & 1]); }
-                else dma_rd_wait<0>(r[q & 1]);
-                const int d0 = (int)(dma_blend(r[q & 1], 0, tap[q]) >> 16) - (int)(dma_blend(r[q & 1], 1, tap[q]) >> 16);
-                if constexpr (FIRST) flags |= (d0 > black_thr ? 1u : 0u) << q;
-                else bit_step(q, d0, mv0);
+                for (int q = 0; q < PX; q++) bit_step(q, sd[q], mv1);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -851,7 +981,6 @@ struct GrayDma {
     }
 };
 
-// the LDS would allow 8 waves per SIMD for the 512-thread shapes, 64 VGPRs do not hold a thread's state without spilling
 template <int LDS_BYTES, int NT, int NPP>
 constexpr int gray_dma_waves()
 {
