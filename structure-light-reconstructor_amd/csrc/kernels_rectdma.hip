@@ -28,14 +28,22 @@ namespace slr {
 constexpr unsigned kDmaInvalid = 0x80000000u;    // buffer offset beyond every descriptor's range: loads 0, stores nothing
 
 // destination tile TW x TH decoded by a workgroup of NT threads.  A thread owns QUADS of 4 horizontally adjacent pixels (one or
-// two per tile): quad g = pass * NT + thread lies in tile row g / (TW / 4) at columns 4 * (g % (TW / 4)) .. + 3.  The four pixels of
-// a quad almost always take their taps from the same 8 source bytes of two (or three) source rows -- see the digest below.
+// two per tile; quad g = pass * NT + thread, see quad_row / quad_col).  The four pixels of a quad almost always take their taps
+// from the same 8 source bytes of two (or three) source rows -- see the digest below.
 template <int TW, int TH, int NT>
 struct DmaGeom {
     static constexpr int NWAVES = NT / 64;
     static constexpr int PX = TW * TH / NT;                     // pixels per thread
     static constexpr int NQ = PX / 4;                           // quads per thread (= passes)
     static constexpr int QPR = TW / 4;                          // quads per tile row
+    // A wave's 64 quads form a block of BR tile rows x BC quads (8 x 8 where the tile is 8 rows high): steps of sy run down the
+    // image, so a compact block meets fewer of them than a 256-pixel row segment would (more waves in the cheap read mode), and
+    // its 8 rows x 8 dwords fall on 64 different LDS banks (row stride 40 or 72 dwords).
+    static constexpr int BR = TH >= 8 ? 8 : TH, BC = 64 / BR;
+    static_assert(QPR % BC == 0 && TH % BR == 0, "quad blocks");
+    // quad g = pass * NT + thread -> tile row, first tile column
+    static __device__ __host__ constexpr int quad_row(int g) { return (g / 64) / (QPR / BC) * BR + (g % 64) / BC; }
+    static __device__ __host__ constexpr int quad_col(int g) { return ((g / 64) % (QPR / BC) * BC + (g % 64) % BC) * 4; }
     static constexpr int WPR = TW / 64;                         // (waves per tile row of the chunk ownership, unchanged)
     static constexpr int RPP = NWAVES / WPR;
     static constexpr int CMAX = TW / 16 + 2;                    // 16-byte chunks per source row held in LDS
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
 #pragma unroll
     for (int q = 0; q < Gm::PX; q++) {
         const int g = (q >> 2) * NT + (int)threadIdx.x;
-        const int row = ty * TH + g / Gm::QPR, col = tx * TW + (g % Gm::QPR) * 4 + (q & 3);
+        const int row = ty * TH + Gm::quad_row(g), col = tx * TW + Gm::quad_col(g) + (q & 3);
         sxs[q] = 0x7FFFFFFF; sys[q] = 0; frs[q] = 0;
         if (row < H && col < W) {
             const size_t m = (size_t)row * W + col;
@@ -380,6 +388,7 @@ __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0,
             tap[q].w1 = __builtin_bit_cast(u16x2, w1);
         }
     }
+    second = __builtin_amdgcn_readfirstlane(second);          // (what the ballots imply: wave-uniform, the branches on it are scalar)
     return mode;
 }
 
@@ -487,7 +496,7 @@ struct DmaDecode {
 #pragma unroll
         for (int p = 0; p < PX / 4; p++) {
             const int g = p * NT + (int)threadIdx.x;
-            const int row = out_ty * TH + g / Gm::QPR, col = out_tx * TW + (g % Gm::QPR) * 4;
+            const int row = out_ty * TH + Gm::quad_row(g), col = out_tx * TW + Gm::quad_col(g);
             const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             if constexpr (HASVALID) {
@@ -868,7 +877,7 @@ struct GrayDma {
 #pragma unroll
         for (int p = 0; p < PX / 4; p++) {
             const int g = p * NT + (int)threadIdx.x;
-            const int row = out_ty * TH + g / Gm::QPR, col = out_tx * TW + (g % Gm::QPR) * 4;
+            const int row = out_ty * TH + Gm::quad_row(g), col = out_tx * TW + Gm::quad_col(g);
             const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             const u32x4_t vx = {(unsigned)out_x[4 * p], (unsigned)out_x[4 * p + 1], (unsigned)out_x[4 * p + 2], (unsigned)out_x[4 * p + 3]};
