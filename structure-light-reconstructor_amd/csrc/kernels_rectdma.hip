@@ -373,7 +373,9 @@ __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0,
         const unsigned sh = (e[q] >> 13) & 3u;
         const unsigned o = mode == 2 ? sh : sh + ((e[q] & 1u) << 2);           // byte offset of the left tap in the 8 bytes read
         tap[q].sel = __umul24(o, 0x10001u) + 0x0C010C00u;
-        const unsigned w0 = wt[WT_OFF / 4], w1 = wt[WT1_OFF / 4];
+        unsigned w0, w1;
+        if constexpr (WT_OFF < 0) { dma_weights(e[q] >> 18, w0, w1); (void)wt; }   // no weight tables in this kernel's LDS
+        else { w0 = wt[WT_OFF / 4]; w1 = wt[WT1_OFF / 4]; }
         if (mode == 1) {                                     // weights of rows 0, 1, 2 of the quad (the pixel's own rows: st, st + 1)
             const bool st = ((e[q] >> 1) & 1u) != 0;
 #if !defined(SLR_DMA_NO_SECOND)
@@ -459,10 +461,11 @@ struct DmaDecode {
     // (waves beyond a plane image's chunks issue their DMAs all the same -- the counted waits need one sequence for every
     // wave -- with an out-of-range source into a 1 KiB scratch slot)
     static constexpr int SCRATCH_OFF = D * 2 * PS, DIG_OFF = SCRATCH_OFF + (Gm::NCH < NT ? 1024 : 0), DIG_BYTES = TW * TH * 4;
-    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4, WT_BYTES = 2 * 1026 * 4;   // two tables: w0[1025], w1[1025]
-    static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
+    // (the blend weights are computed per pixel and tile, 8 VALU instructions: a weight table would be 8 KB, and without it
+    //  the triple buffer of DMA depth 2 still fits three workgroups per CU)
+    static constexpr int LUT_OFF = DIG_OFF + DIG_BYTES;
     static constexpr int LDS_BYTES = LUT_OFF + (kLutWords + 1) * 4;
-    static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
+    static_assert(LUT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
     static constexpr int kSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
 
     const uint8_t *smem;
@@ -562,7 +565,7 @@ struct DmaDecode {
             if (out_pending) flush();
             // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, -1, -1>(smem, lds0, dg, tap, qbase, second);
             ok = 0;
         }
         constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
@@ -650,8 +653,12 @@ constexpr int dma_waves_per_simd()
     return w > 8 ? 8 : w < 1 ? 1 : w;
 }
 
+// (a thread's state does not fit the 64 VGPRs of 8 waves per SIMD without spilling: capped at 6 like the Gray kernel)
+template <int LDS_BYTES, int NT>
+constexpr int mf_dma_waves() { return dma_waves_per_simd<LDS_BYTES, NT>() > 6 ? 6 : dma_waves_per_simd<LDS_BYTES, NT>(); }
+
 template <int TW, int TH, int NT, int A, bool HASVALID>
-__global__ __launch_bounds__(NT, (dma_waves_per_simd<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
+__global__ __launch_bounds__(NT, (mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
 void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
                                int tiles_x, int tiles_y)
 {
@@ -665,12 +672,6 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
     d.lut = lut;
     for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
-    for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
-        unsigned w0, w1;
-        dma_weights(i, w0, w1);
-        *reinterpret_cast<unsigned *>(smem + Dec::WT_OFF + 4u * i) = w0;
-        *reinterpret_cast<unsigned *>(smem + Dec::WT1_OFF + 4u * i) = w1;
-    }
     __syncthreads();
     if (!HASVALID && threadIdx.x == 0)                      // the undefined wrapped phase (n == d == 0: lutR -> S = 9, s = 0, sgn 0)
         reinterpret_cast<int *>(lut)[kLutP + (9 << 8)] = Dec::kSentinel;

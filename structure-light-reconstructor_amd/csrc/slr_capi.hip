@@ -57,7 +57,7 @@ struct slr_ctx {
     unsigned dma_nofit[2] = {0, 0};             // tiles whose box does not fit that form
     int dma_shape_built[2] = {-1, -1};          // SLR_OPT_RECT_DMA_SHAPE the tables were built for
     DebugKnobs debug;              // SLR_OPT_DEBUG_*
-    int opt_dma_shape = 3, opt_dma_depth = 1;   // SLR_OPT_RECT_DMA_SHAPE / _DEPTH (128x16 tiles on 512 threads measured best)
+    int opt_dma_shape = 3, opt_dma_depth = 2;   // SLR_OPT_RECT_DMA_SHAPE / _DEPTH (128x16 tiles on 512 threads, two phases of DMA in flight: measured best)
     int map_w = 0, map_h = 0;
     int opt_mf_match_algo = 0;     // SLR_OPT_MF_MATCH_ALGO
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
