@@ -120,7 +120,7 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_RECT_DMA_SHAPE: destination tile / workgroup size of form 7: 0 = 256x16 / 512 threads, 1 = 256x8 / 512, 2 = 256x8 / 256,
  * 3 = 128x16 / 512 (default), 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
- * the decode, 1 (double buffer) or 2 (triple buffer). */
+ * the decode, 1 (double buffer) or 2 (triple buffer, the default). */
 #define SLR_OPT_RECT_DMA_SHAPE 6
 #define SLR_OPT_RECT_DMA_DEPTH 7
 /* Test knobs (results never change).  SLR_OPT_DEBUG_RECT_RESIDENT: n > 0 = run the persistent fused decodes on n workgroups

@@ -50,8 +50,8 @@ def main(out_dir, summary_csv):
 
 # rocprof kernel name prefix -> the library's profiler name (slr_profile_kernel_name), for bench.py's roofline.traffic
 PROFILER_NAME = [
-    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, true>", "slr_mf_rectify_decode"),
-    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 1, false>", "slr_mf_rectify_decode_pair"),
+    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 2, true>", "slr_mf_rectify_decode"),
+    ("mf:mf_rect_decode_dma_kernel<128, 16, 512, 2, false>", "slr_mf_rectify_decode_pair"),
     ("mf:mf_rect_decode_lds_kernel", "slr_mf_rectify_decode[round-1 form 5]"), ("mf_decode_kernel", "slr_mf_decode"),
     ("remap_kernel", "slr_remap_u8"),
     ("gray:gray_rect_decode_dma_kernel", "slr_gray_rectify_decode"), ("ge:gray_rect_decode_dma_kernel", "slr_gray_rectify_decode_pair"),

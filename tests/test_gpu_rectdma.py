@@ -28,7 +28,7 @@ def _opts(ctx, slr, algo=7, shape=0, depth=1):
 def dma_ctx(ctx, slr):
     yield ctx
     ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, 0)
-    _opts(ctx, slr, 0, 3, 1)
+    _opts(ctx, slr, 0, 3, 2)                                 # the defaults: auto, 128x16 tiles, depth 2
 
 
 @pytest.mark.parametrize("W,H,strength", [(640, 480, 1.0), (1024, 100, 2.0), (4096, 40, 1.0), (400, 77, 2.0), (16, 5, 1.0),
