@@ -457,15 +457,15 @@ struct DmaDecode {
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS, D = A + 1;
     // dynamic LDS (the kernel has no static LDS, so it starts at LDS address 0 and the tap addresses are 13-bit ORs):
-    // D buffers of 2 plane images | digest of the tile | weight table | decode tables (slr_create's, kLutWords)
-    // (waves beyond a plane image's chunks issue their DMAs all the same -- the counted waits need one sequence for every
-    // wave -- with an out-of-range source into a 1 KiB scratch slot)
-    static constexpr int SCRATCH_OFF = D * 2 * PS, DIG_OFF = SCRATCH_OFF + (Gm::NCH < NT ? 1024 : 0), DIG_BYTES = TW * TH * 4;
-    // (the blend weights are computed per pixel and tile, 8 VALU instructions: a weight table would be 8 KB, and without it
-    //  the triple buffer of DMA depth 2 still fits three workgroups per CU)
-    static constexpr int LUT_OFF = DIG_OFF + DIG_BYTES;
+    // D buffers of 2 plane images | digest of the tile | weight tables | decode tables (slr_create's, kLutWords).
+    // Waves beyond a plane image's chunks (128 x 16 tiles: waves 4-7) issue no plane DMAs and wait for none -- a wave's counted
+    // waits concern its own DMAs only, the barrier behind them covers everybody else's -- so there is no scratch slot for dummy
+    // transfers: with it the triple buffer of DMA depth 2 plus the 8 KB weight tables would miss three workgroups per CU by 1 KB.
+    static constexpr int DIG_OFF = D * 2 * PS, DIG_BYTES = TW * TH * 4;
+    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4, WT_BYTES = 2 * 1026 * 4;   // two tables: w0[1025], w1[1025]
+    static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
     static constexpr int LDS_BYTES = LUT_OFF + (kLutWords + 1) * 4;
-    static_assert(LUT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
+    static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
     static constexpr int kSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
 
     const uint8_t *smem;
@@ -518,10 +518,10 @@ struct DmaDecode {
 #if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 1 || SLR_DMA_ABL == 6)
         voff = kDmaInvalid;              // ablation: no source traffic (the DMA instructions still issue and zero-fill)
 #endif
+        if (!plane_wave) return;         // (wave-uniform)
 #pragma unroll
         for (int g = 0; g < 2; g++)
-            dma16(voff, rs_stack, plane_wave ? lds0 + (unsigned)((buf * 2 + g) * PS) + wave_off : lds0 + (unsigned)SCRATCH_OFF,
-                  (unsigned)dma_phase_plane(p, g) * pstride);
+            dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 + g) * PS) + wave_off, (unsigned)dma_phase_plane(p, g) * pstride);
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -555,7 +555,8 @@ struct DmaDecode {
     template <int K0, int P>
     __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
     {
-        wait_vm<dma_wait_count<PX, A>(P)>();
+        if (plane_wave) wait_vm<dma_wait_count<PX, A>(P)>();
+        else if (P == 0) wait_vm<0>();   // (its share of the tile's digest, issued six phases ago)
 #if !defined(SLR_DMA_ABL) || SLR_DMA_ABL != 3
         asm volatile("s_barrier" ::: "memory");
 #endif
@@ -565,7 +566,7 @@ struct DmaDecode {
             if (out_pending) flush();
             // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, -1, -1>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
             ok = 0;
         }
         constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
@@ -672,6 +673,12 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
     d.lut = lut;
     for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
+    for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
+        unsigned w0, w1;
+        dma_weights(i, w0, w1);
+        *reinterpret_cast<unsigned *>(smem + Dec::WT_OFF + 4u * i) = w0;
+        *reinterpret_cast<unsigned *>(smem + Dec::WT1_OFF + 4u * i) = w1;
+    }
     __syncthreads();
     if (!HASVALID && threadIdx.x == 0)                      // the undefined wrapped phase (n == d == 0: lutR -> S = 9, s = 0, sgn 0)
         reinterpret_cast<int *>(lut)[kLutP + (9 << 8)] = Dec::kSentinel;
@@ -850,8 +857,8 @@ struct GrayDma {
     static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS;
-    // dynamic LDS from address 0: 2 buffers of 4 plane images | scratch slot | digest of the tile | weight tables
-    static constexpr int SCRATCH_OFF = 4 * NPP * PS, DIG_OFF = SCRATCH_OFF + (Gm::NCH < NT ? 1024 : 0), DIG_BYTES = TW * TH * 4;
+    // dynamic LDS from address 0: 2 buffers of 2 * NPP plane images | digest of the tile | weight tables
+    static constexpr int DIG_OFF = 4 * NPP * PS, DIG_BYTES = TW * TH * 4;     // (no scratch slot: waves without chunks issue no DMAs)
     static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4;
     static constexpr int LDS_BYTES = WT_OFF + 2 * 1026 * 4;
     static_assert(WT_OFF <= 65536, "DMA destinations are 16-bit LDS addresses (M0)");
@@ -895,10 +902,10 @@ struct GrayDma {
     // the planes of phase k -- plane pairs NPP * k .. -- into buffer buf
     __device__ __forceinline__ void issue_planes(int k, int buf, unsigned voff) const
     {
+        if (!plane_wave) return;         // (wave-uniform)
         const int n = NPP == 1 || 2 * k + 1 < npairs ? 2 * NPP : 2;
         for (int g = 0; g < n; g++)
-            dma16(voff, rs_stack, plane_wave ? lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + wave_off : lds0 + (unsigned)SCRATCH_OFF,
-                  (unsigned)(2 * NPP * k + g) * pstride);
+            dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + wave_off, (unsigned)(2 * NPP * k + g) * pstride);
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -940,7 +947,7 @@ struct GrayDma {
     template <int B, bool FIRST>
     __device__ __forceinline__ void phase(int k, int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
     {
-        wait_vm<0>();
+        if (plane_wave || FIRST) wait_vm<0>();              // (a wave without chunks only waits for its share of the digest)
         asm volatile("s_barrier" ::: "memory");
         if (k == 1) issue_digest(next_tile, has_next);      // (every wave is past its digest reads of phase 0; nq >= 2)
         const bool last = k + 1 == nq;
