@@ -444,11 +444,11 @@ __device__ __forceinline__ void dma_differences(int mode, const DmaTap tap[PX], 
 // included the output stores let the wait pass with the DMA still pending -- found the hard way), so the stores of a tile
 // are issued at the start of the NEXT tile's phase 0, a whole phase before the following wait, and a wave that still has
 // one of them outstanding there merely waits a little longer.
-template <int PX, int A>
+template <int PX, int A, int PLANE_DMAS = 2>
 __device__ __host__ constexpr int dma_wait_count(int p)
 {
     int n = 0;
-    for (int j = 1; j < A; j++) { const int ph = ((p - A + j) % 7 + 7) % 7; n += 2 + (ph == 1 ? PX / 4 : 0); }
+    for (int j = 1; j < A; j++) { const int ph = ((p - A + j) % 7 + 7) % 7; n += PLANE_DMAS + (ph == 1 ? PX / 4 : 0); }
     return n;
 }
 
@@ -456,6 +456,10 @@ template <int TW, int TH, int NT, int A, bool HASVALID>
 struct DmaDecode {
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS, D = A + 1;
+    // SPLIT: the workgroup has twice as many threads as a plane image has chunks (128 x 16 tiles on 512 threads): waves 0-3 fetch
+    // the first plane of a phase's pair, waves 4-7 the second -- ONE plane DMA per wave and phase instead of two for half the waves
+    static constexpr bool SPLIT = 2 * Gm::NCH <= NT;
+    static constexpr int PLANE_DMAS = SPLIT ? 1 : 2;
     // dynamic LDS (the kernel has no static LDS, so it starts at LDS address 0 and the tap addresses are 13-bit ORs):
     // D buffers of 2 plane images | digest of the tile | weight tables | decode tables (slr_create's, kLutWords).
     // Waves beyond a plane image's chunks (128 x 16 tiles: waves 4-7) issue no plane DMAs and wait for none -- a wave's counted
@@ -471,6 +475,8 @@ struct DmaDecode {
     const uint8_t *smem;
     const float *lut;
     unsigned lds0, wave_off;
+    unsigned pslot_off;                  // this wave's 1 KiB slot inside a plane image
+    unsigned plane_g;                    // SPLIT: which plane of a phase's pair this wave fetches (wave-uniform)
     bool plane_wave;                     // this wave owns chunks of the plane images (wave-uniform)
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_phase, rs_valid;
     unsigned pstride;
@@ -519,9 +525,14 @@ struct DmaDecode {
         voff = kDmaInvalid;              // ablation: no source traffic (the DMA instructions still issue and zero-fill)
 #endif
         if (!plane_wave) return;         // (wave-uniform)
+        if constexpr (SPLIT) {
+            const unsigned plane = (unsigned)dma_phase_plane(p, 0) + (p == 0 ? plane_g : 2u * plane_g);
+            dma16(voff, rs_stack, lds0 + (unsigned)(buf * 2 * PS) + plane_g * (unsigned)PS + pslot_off, plane * pstride);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 2; g++)
-            dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 + g) * PS) + wave_off, (unsigned)dma_phase_plane(p, g) * pstride);
+            for (int g = 0; g < 2; g++)
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 + g) * PS) + pslot_off, (unsigned)dma_phase_plane(p, g) * pstride);
+        }
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -555,7 +566,7 @@ struct DmaDecode {
     template <int K0, int P>
     __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
     {
-        if (plane_wave) wait_vm<dma_wait_count<PX, A>(P)>();
+        if (plane_wave) wait_vm<dma_wait_count<PX, A, PLANE_DMAS>(P)>();
         else if (P == 0) wait_vm<0>();   // (its share of the tile's digest, issued six phases ago)
 #if !defined(SLR_DMA_ABL) || SLR_DMA_ABL != 3
         asm volatile("s_barrier" ::: "memory");
@@ -698,7 +709,13 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         if (w == 0) __builtin_amdgcn_s_setprio(0); else if (w == 1) __builtin_amdgcn_s_setprio(1); else if (w == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     }
 #endif
-    d.plane_wave = d.wave_off < (unsigned)Dec::PS;
+    {
+        const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        constexpr unsigned wpp = (unsigned)Gm::NCH / 64u;    // waves per plane image
+        d.plane_g = Dec::SPLIT ? wv / wpp : 0u;
+        d.pslot_off = (Dec::SPLIT ? wv % wpp : wv) * 1024u;
+        d.plane_wave = Dec::SPLIT ? wv < 2u * wpp : wv < wpp;
+    }
     d.pstride = jobs.j[ji].pstride;
     d.W = W; d.H = H; d.black_thr = black_thr;
     d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
@@ -708,10 +725,11 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     const int4 *__restrict__ boxes = jobs.j[ji].boxes;
 
     // this thread's chunk of a box: row crow, 16-byte column ccol
-    const int crow = (int)threadIdx.x / Gm::CMAX, ccol = (int)threadIdx.x - crow * Gm::CMAX;
+    const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
+    const int crow = chunk / Gm::CMAX, ccol = chunk - crow * Gm::CMAX;
     auto box_voff = [&](const int4 b) -> unsigned {
         const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = (int)threadIdx.x < Gm::NCH && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const bool in = (Dec::SPLIT || chunk < Gm::NCH) && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     };
 
@@ -857,6 +875,9 @@ struct GrayDma {
     static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS;
+    // SPLIT (twice as many threads as a plane image has chunks): the waves' first half fetches the first half of a phase's
+    // 2 * NPP planes, the second half the rest
+    static constexpr bool SPLIT = 2 * Gm::NCH <= NT;
     // dynamic LDS from address 0: 2 buffers of 2 * NPP plane images | digest of the tile | weight tables
     static constexpr int DIG_OFF = 4 * NPP * PS, DIG_BYTES = TW * TH * 4;     // (no scratch slot: waves without chunks issue no DMAs)
     static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4;
@@ -864,7 +885,7 @@ struct GrayDma {
     static_assert(WT_OFF <= 65536, "DMA destinations are 16-bit LDS addresses (M0)");
 
     const uint8_t *smem;
-    unsigned lds0, wave_off;
+    unsigned lds0, wave_off, pslot_off, plane_g;             // (pslot_off, plane_g: see DmaDecode)
     bool plane_wave, has_cy, has_valid;
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_cx, rs_cy, rs_valid;
     unsigned pstride;
@@ -904,8 +925,13 @@ struct GrayDma {
     {
         if (!plane_wave) return;         // (wave-uniform)
         const int n = NPP == 1 || 2 * k + 1 < npairs ? 2 * NPP : 2;
-        for (int g = 0; g < n; g++)
-            dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + wave_off, (unsigned)(2 * NPP * k + g) * pstride);
+        if constexpr (SPLIT) {
+            for (int g = (int)plane_g * NPP; g < (int)(plane_g + 1) * NPP && g < n; g++)
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)(2 * NPP * k + g) * pstride);
+        } else {
+            for (int g = 0; g < n; g++)
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)(2 * NPP * k + g) * pstride);
+        }
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -1033,7 +1059,13 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
 
     d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
-    d.plane_wave = d.wave_off < (unsigned)Dec::PS;
+    {
+        const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        constexpr unsigned wpp = (unsigned)Gm::NCH / 64u;    // waves per plane image
+        d.plane_g = Dec::SPLIT ? wv / wpp : 0u;
+        d.pslot_off = (Dec::SPLIT ? wv % wpp : wv) * 1024u;
+        d.plane_wave = Dec::SPLIT ? wv < 2u * wpp : wv < wpp;
+    }
     d.pstride = jobs.j[ji].pstride;
     d.W = W; d.H = H; d.black_thr = black_thr; d.white_thr = white_thr; d.ncol = ncol; d.nrow = nrow; d.npairs = 1 + ncol + nrow; d.nq = (d.npairs + NPP - 1) / NPP;
     d.scan_w = scan_w; d.scan_h = scan_h;
@@ -1046,10 +1078,11 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, d.has_valid ? n4 / 4 : 0, 0x00020000);
     const int4 *__restrict__ boxes = jobs.j[ji].boxes;
 
-    const int crow = (int)threadIdx.x / Gm::CMAX, ccol = (int)threadIdx.x - crow * Gm::CMAX;
+    const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
+    const int crow = chunk / Gm::CMAX, ccol = chunk - crow * Gm::CMAX;
     auto box_voff = [&](const int4 b) -> unsigned {
         const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = (int)threadIdx.x < Gm::NCH && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const bool in = (Dec::SPLIT || chunk < Gm::NCH) && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     };
 
