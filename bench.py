@@ -318,6 +318,20 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # what the collective leg actually ran on: the backend torch.distributed reports, its rank count and every rank's device
+    # (a SCALE run is checked against this: "nccl" = RCCL; distinct UUIDs = distinct physical GPUs)
+    collective = None
+    if world > 1:
+        try:
+            uuid = str(torch.cuda.get_device_properties(local).uuid)
+        except Exception:
+            uuid = None
+        mine = {"rank": rank, "local_device": local, "uuid": uuid, "name": torch.cuda.get_device_name(local)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": allr,
+                      "distinct_devices": len({(r or {}).get("uuid") or ("rank%d" % i) for i, r in enumerate(allr)})}
+
     slr = importlib.import_module("structure-light-reconstructor_amd")
     synth = importlib.import_module("structure-light-reconstructor_amd.synth")
     W, H = args.width, args.height
@@ -351,11 +365,11 @@ def main():
         if rectify:
             for cam in range(2):
                 c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
-    # F distinct synthetic stereo frames per rank (seeds 1234 + 100 rank + f), resident in HBM
+    # F distinct synthetic stereo frames per rank (seeds 1234 + F rank + f), resident in HBM
     pitch = W + max(0, args.pitch_pad)
     stack = torch.zeros((F, 2, ppc, H, pitch), dtype=torch.uint8, device=dev)      # rows padded: see --pitch-pad
     for f in range(F):
-        seed = 1234 + 100 * rank + f
+        seed = 1234 + F * rank + f                         # config 4: 64 frames over 8 GPUs = seeds 1234 .. 1297
         if mode == "mf":
             rendered = synth.render_mf_stack(W, H, seed=seed, noise=2, device=dev)
         elif mode == "ge":
@@ -567,6 +581,9 @@ def main():
                             (", one RCCL all-gather of the final XYZ+mask right after the timed steps (final_allgather_ms)"
                              if after_gather else "")))},
             "device": _device_info(torch, local),
+            "collective_backend": None if collective is None else collective["backend"],
+            "collective_ranks": None if collective is None else collective["ranks"],
+            "collective": collective,
             "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,

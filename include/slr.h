@@ -79,6 +79,7 @@ typedef struct slr_ctx slr_ctx;
 /* ---- lifecycle -------------------------------------------------------------------------------------- */
 int          slr_version(void);
 const char  *slr_status_string(int status);
+int          slr_current_device(int *device_id);                  /* the calling thread's current HIP device (hipGetDevice) */
 int          slr_create(int device_id, slr_ctx **out);           /* replaces `new MFReconstruct()/Reconstruct()` mainwindow.cpp:577-582 */
 int          slr_destroy(slr_ctx *ctx);                          /* Reconstruct::~Reconstruct reconstruct.cpp:24-31 */
 int          slr_set_stream(slr_ctx *ctx, void *hip_stream);     /* borrow a caller stream (NULL -> ctx-owned stream) */
@@ -162,6 +163,14 @@ int slr_mf_decode(slr_ctx *ctx, const uint8_t *const planes[SLR_MF_PLANES], int 
 /* fused K1+K2: loadCamImgs' 14x doStereoRectify (mfreconstruct.cpp:119-134) + the above, raw planes in */
 int slr_mf_rectify_decode(slr_ctx *ctx, int cam, const uint8_t *const planes[SLR_MF_PLANES], int pitch,
                           int W, int H, int black_thr, float *phase, uint8_t *valid, slr_mem mem);
+
+/* the same for BOTH cameras of a stereo frame -- one kernel launch when the LDS-tiled fused forms apply (what the whole-path
+ * entries run): MFReconstruct::loadCamImgs + decodePatterns for camera 0 and 1 (mfreconstruct.cpp:119-134, 210-269).  validL and
+ * validR both NULL: the flag travels inside the phase -- an invalid pixel's phase is a quiet NaN (0x7FC00000) instead of 0, which
+ * slr_mf_triangulate* never matches and which lets them be called with NULL valid arrays too. */
+int slr_mf_rectify_decode_pair(slr_ctx *ctx, const uint8_t *const planesL[SLR_MF_PLANES],
+                               const uint8_t *const planesR[SLR_MF_PLANES], int pitch, int W, int H, int black_thr,
+                               float *phaseL, uint8_t *validL, float *phaseR, uint8_t *validR, slr_mem mem);
 
 /* ---- BUILD EXTENSION, no reference counterpart (the reference is hard-wired to 3 frequencies x 4 steps of u8,
  * mfreconstruct.cpp:21-22,237-242; BASELINE config 5; parity unpinned): n_freq x n_step phase-shift decode of fp16
@@ -286,10 +295,25 @@ int slr_reconstruct_batch(slr_ctx *ctx, const slr_batch_desc *desc, const uint8_
  *   gather_ctx >= 0: xyz_all [n_frames][H][W][3] and has_all [n_frames][H][W] on ctxs[gather_ctx]'s device receive every frame
  *   in job order by direct peer copies (hipMemcpyPeerAsync on the producing stream: one xGMI hop per source); -1: no assembly.
  * All devices run concurrently; the call returns when every stream is idle (the same calibration / maps / options must have
- * been installed on every ctx).  MFReconstruct::runReconstruction x n_frames (mfreconstruct.cpp:160-187). */
+ * been installed on every ctx).  Every context's arguments are validated before any of them is given work, and after a HIP
+ * runtime error the call returns only once every stream already started has drained (the caller may free its buffers).
+ * MFReconstruct::runReconstruction x n_frames (mfreconstruct.cpp:160-187). */
 int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W,
                              int H, int black_thr, int rectify, float *const *xyz, uint8_t *const *has, int gather_ctx,
                              float *xyz_all, uint8_t *has_all);
+
+/* north_star's exchange step ("all-gather ... only to assemble the final point cloud") from one process: EVERY device ends with
+ * the assembled cloud.  ctxs[k] computes its frames (f % n_ctx == k) straight into their slots of ITS OWN xyz_all[k] /
+ * has_all[k] ([n_frames][H][W][3] / [n_frames][H][W] on its device); its stream then pushes each finished frame into the same
+ * slot on every other device (hipMemcpyPeerAsync: n_ctx - 1 concurrent one-hop copies per frame over the point-to-point xGMI
+ * mesh, no ring, no staging buffer).  Every argument of every context is validated before any work is enqueued; if a HIP
+ * runtime error interrupts the call, it returns only after every stream already started has drained.
+ *   *peer_direct (may be NULL) = 1: every destination was directly addressable from every source (same device or peer access),
+ *                                0: the runtime stages at least one pair through the host (results are the same, only slower);
+ *   require_peer != 0 turns that case into SLR_ERR_UNSUPPORTED (nothing enqueued). */
+int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W,
+                                 int H, int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all,
+                                 int require_peer, int *peer_direct);
 
 /* Ordered prefix index of a u8 flag image [h][w] (nonzero = flagged), enumerated row-major (column_major = 0) or in the
  * column-outer / row-inner order in which MeshCreator numbers the vertices of a PointCloudImage (meshcreator.cpp:21-33,

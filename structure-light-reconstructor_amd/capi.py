@@ -33,13 +33,14 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED
 
 # every symbol include/slr.h declares (checked by tests/test_capi_symbols.py without a GPU)
 SYMBOLS = [
-    "slr_version", "slr_status_string", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
+    "slr_version", "slr_status_string", "slr_current_device", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
     "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_init_rectify_maps",
     "slr_get_rectify_maps", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
-    "slr_mf_rectify_decode", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
+    "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_prefix_index", "slr_compact_points",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather",
+    "slr_prefix_index", "slr_compact_points",
     "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
@@ -310,6 +311,21 @@ class Context:
         self._chk(st)
         return phase, valid
 
+    def mf_rectify_decode_pair(self, planesL, planesR, black_thr, W=None, want_valid=True):
+        """slr_mf_rectify_decode_pair: both cameras of a frame (ONE launch when the LDS-tiled fused forms apply).
+        want_valid=False: no valid arrays, invalid pixels carry a NaN phase (what the whole-path entries run)."""
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert n == MF_PLANES and n2 == MF_PLANES and (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = self._mem(_flat(planesL) + _flat(planesR))
+        like = _flat(planesL)[0]
+        ph = [self._new(mem, (H, W), np.float32, like) for _ in range(2)]
+        vd = [self._new(mem, (H, W), np.uint8, like) if want_valid else None for _ in range(2)]
+        self._chk(self.lib.slr_mf_rectify_decode_pair(self.h, pl, pr, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
+                                                      _ptr(ph[0]), _ptr(vd[0]), _ptr(ph[1]), _ptr(vd[1]), C.c_int(mem)))
+        return ph, vd
+
     # -- build extension (no reference counterpart): n_freq x n_step fp16 decode
     def mfn_decode(self, planes, n_freq, n_step, black_thr, W=None, phase=None, valid=None):
         """planes: [2 + n_freq*n_step][H][pitch] float16 (numpy = host, torch.cuda = device)."""
@@ -421,6 +437,21 @@ class Context:
                                               C.c_int(black_thr), C.c_int(1 if rectify else 0), _ptr(xyz), _ptr(has),
                                               C.c_int(mem)))
         return xyz, has
+
+    def reconstruct_mf_cloud(self, planesL, planesR, black_thr, rectify, scan_w, scan_h, W=None):
+        """slr_reconstruct_mf_cloud: the whole MF path + the PointCloudImage adaptor -> (pc_sum [scan_h][scan_w][3], pc_count)."""
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert n == MF_PLANES and n2 == MF_PLANES and (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = self._mem(_flat(planesL) + _flat(planesR))
+        like = _flat(planesL)[0]
+        s = self._new(mem, (scan_h, scan_w, 3), np.float32, like)
+        c = self._new(mem, (scan_h, scan_w), np.uint8, like)
+        self._chk(self.lib.slr_reconstruct_mf_cloud(self.h, pl, pr, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
+                                                    C.c_int(1 if rectify else 0), C.c_int(scan_w), C.c_int(scan_h), _ptr(s), _ptr(c),
+                                                    C.c_int(mem)))
+        return s, c
 
     def reconstruct_mf_batch(self, stack, black_thr, rectify, W=None, xyz=None, has=None):
         """stack: torch.cuda u8 [n_frames][2][14][H][pitch]."""
@@ -549,19 +580,32 @@ class Context:
         return out
 
 
+def _sync_devices(tensors):
+    """the ctx streams are not torch streams: everything torch has queued on ANY stream of EVERY device involved (inputs being
+    produced, reused allocator blocks still in use) must be complete before the library reads or writes those buffers"""
+    import torch
+    for d in sorted({t.device.index for t in tensors if t is not None}):
+        torch.cuda.synchronize(d)
+
+
+def _multi_args(ctxs, stacks):
+    n = len(ctxs)
+    nf = sum(int(s.shape[0]) for s in stacks)
+    _, two, npl, H, pitch = stacks[0].shape
+    assert two == 2 and npl == MF_PLANES and len(stacks) == n
+    for k, s in enumerate(stacks):
+        assert s.is_cuda and s.is_contiguous() and int(s.shape[0]) == (nf - k + n - 1) // n
+        assert s.device.index == ctxs[k].device_id, "stacks[k] must live on ctxs[k]'s device"
+    return n, nf, H, pitch
+
+
 def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0):
     """slr_reconstruct_mf_multi: one Context per device (or several on one device), stacks[k] = torch.cuda u8
     [frames of k][2][14][H][pitch] on ctxs[k]'s device; frame f of the job is stacks[f % n][f // n].
     Returns (xyz_all, has_all) on ctxs[gather_ctx]'s device (or the per-ctx lists when gather_ctx < 0)."""
     import torch
-    n = len(ctxs)
-    nf = sum(int(s.shape[0]) for s in stacks)
-    _, two, npl, H, pitch = stacks[0].shape
-    assert two == 2 and npl == MF_PLANES
+    n, nf, H, pitch = _multi_args(ctxs, stacks)
     W = pitch if W is None else W
-    for k, s in enumerate(stacks):
-        assert s.is_cuda and s.is_contiguous() and int(s.shape[0]) == (nf - k + n - 1) // n
-    torch.cuda.synchronize()                               # inputs made by torch on any stream / device are complete
     xyz = [torch.empty((int(s.shape[0]), H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
     has = [torch.empty((int(s.shape[0]), H, W), dtype=torch.uint8, device=s.device) for s in stacks]
     xa = ha = None
@@ -569,6 +613,7 @@ def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0)
         gdev = stacks[gather_ctx].device
         xa = torch.empty((nf, H, W, 3), dtype=torch.float32, device=gdev)
         ha = torch.empty((nf, H, W), dtype=torch.uint8, device=gdev)
+    _sync_devices(list(stacks) + xyz + has + [xa, ha])
     arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
     arr_s = (C.c_void_p * n)(*[s.data_ptr() for s in stacks])
     arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xyz])
@@ -578,3 +623,24 @@ def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0)
                                               _ptr(xa), _ptr(ha))
     ctxs[0]._chk(st)
     return (xa, ha) if gather_ctx >= 0 else (xyz, has)
+
+
+def reconstruct_mf_allgather(ctxs, stacks, black_thr, rectify, W=None, require_peer=False):
+    """slr_reconstruct_mf_allgather: as reconstruct_mf_multi, but EVERY device ends with the assembled cloud.
+    Returns (xyz_all[k], has_all[k], peer_direct): per-ctx lists of [n_frames][H][W][3] / [n_frames][H][W] tensors."""
+    import torch
+    n, nf, H, pitch = _multi_args(ctxs, stacks)
+    W = pitch if W is None else W
+    xa = [torch.empty((nf, H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
+    ha = [torch.empty((nf, H, W), dtype=torch.uint8, device=s.device) for s in stacks]
+    _sync_devices(list(stacks) + xa + ha)
+    arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
+    arr_s = (C.c_void_p * n)(*[s.data_ptr() for s in stacks])
+    arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xa])
+    arr_h = (C.c_void_p * n)(*[t.data_ptr() for t in ha])
+    direct = C.c_int(-1)
+    st = ctxs[0].lib.slr_reconstruct_mf_allgather(arr_c, C.c_int(n), C.c_int(nf), arr_s, C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                                  C.c_int(black_thr), C.c_int(1 if rectify else 0), arr_x, arr_h,
+                                                  C.c_int(1 if require_peer else 0), C.byref(direct))
+    ctxs[0]._chk(st)
+    return xa, ha, direct.value

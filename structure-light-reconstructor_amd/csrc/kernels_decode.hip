@@ -1077,11 +1077,14 @@ static unsigned pick_blocks(size_t groups)
 // keep the old back-filling grid (see above); from 4 sweeps on the uneven last sweep costs less than the tables.
 static unsigned pick_blocks_k2(size_t groups)
 {
-    static int cus_of[64];
+    static DevSlots cus_of;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &cus = cus_of[dev & 63];
-    if (cus == 0 && (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)) cus = 256;
+    int cus = cus_of.get(dev);
+    if (cus == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cus_of.put(dev, cus);
+    }
     const unsigned b = pick_blocks(groups), resident = (unsigned)cus * 8u;
     return b >= 4 * resident ? resident : b;
 }
@@ -1108,16 +1111,18 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         const size_t off8 = tile_count(W, H, kTileH) + tile_count(W, H, kGrayTileH);
         jr.j[0].boxes += off8; jr.j[1].boxes += off8;
         const size_t lds = (size_t)kRingRows * kRingBW * SLR_MF_PLANES * 4 + 16;
-        static int ring_cache[64] = {};
+        static DevSlots ring_cache;
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (!ring_cache[dev & 63]) {
+        int ring_res = ring_cache.get(dev);
+        if (!ring_res) {
             int per_cu = 0, cus = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_ring_kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-            ring_cache[dev & 63] = per_cu * cus;
+            ring_res = per_cu * cus;
+            ring_cache.put(dev, ring_res);
         }
-        const int res = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : ring_cache[dev & 63]) / njobs;
+        const int res = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : ring_res) / njobs;
         int nbx = res / 8 > 0 ? res / 8 : 1;
         const int R = (tiles_y8 + 7) / 8;                    // tile rows per XCD band
         if (nbx > R * tiles_x) nbx = R * tiles_x;
@@ -1158,10 +1163,11 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         strided = strided && ok;
     }
     if (tl_debug.no_buffer_form) strided = false;         // tests: force the pointer form
-    static int resident_cache[64][4][2] = {};
+    static DevSlots resident_cache[4][2];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &resident_slot = resident_cache[dev & 63][wide8 ? 3 : wide ? 2 : mid][strided];
+    DevSlots &resident_of = resident_cache[wide8 ? 3 : wide ? 2 : mid][strided];
+    int resident_slot = resident_of.get(dev);
     if (!resident_slot) {
         int per_cu = 0, cus = 0;
         const size_t dyn = (size_t)budget + 16;
@@ -1177,6 +1183,7 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident_slot = per_cu * cus;
+        resident_of.put(dev, resident_slot);
     }
     const int resident_blocks = resident_slot;
     const int T = tiles_x * tiles_yy, per = (T + 7) / 8;

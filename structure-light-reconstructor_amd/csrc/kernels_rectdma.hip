@@ -791,10 +791,10 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
 {
     typedef DmaDecode<TW, TH, NT, A, HV> Dec;
     auto kern = mf_rect_decode_dma_kernel<TW, TH, NT, A, HV>;
-    static int resident[64] = {};
+    static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &res = resident[dev & 63];
+    int res = resident.get(dev);
     if (!res) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -802,6 +802,7 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         res = per_cu * cus;
+        resident.put(dev, res);
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int T = tiles_x * tiles_y, per = (T + 7) / 8;
@@ -1139,10 +1140,10 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
 {
     typedef GrayDma<TW, TH, NT, NPP> Dec;
     auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD>;
-    static int resident[64] = {};
+    static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
-    int &res = resident[dev & 63];
+    int res = resident.get(dev);
     if (!res) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -1150,6 +1151,7 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         res = per_cu * cus;
+        resident.put(dev, res);
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int T = tiles_x * tiles_y, per = (T + 7) / 8;

@@ -421,6 +421,14 @@ const char *slr_status_string(int s)
     }
 }
 
+int slr_current_device(int *device_id)
+{
+    if (!device_id) return SLR_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SLR_ERR_NO_DEVICE;
+    return hipGetDevice(device_id) == hipSuccess ? SLR_OK : SLR_ERR_HIP;
+}
+
 int slr_create(int device_id, slr_ctx **out)
 {
     if (!out) return SLR_ERR_INVALID_ARG;
@@ -876,22 +884,17 @@ int slr_pointcloud_get(slr_ctx *c, const float *pc_sum, const uint8_t *pc_count,
 }
 
 // ---- whole-path drop-ins ----------------------------------------------------------------------------------
-static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int pitch, int W, int H,
-                              int black_thr, int rectify, float *xyz, uint8_t *has)
+// both cameras' (rectifying) decode of one stereo frame: ONE launch when an LDS-tiled fused form applies, else one per camera.
+// vL / vR null: the valid flag travels INSIDE the phase (invalid pixels carry a NaN, which K4 never matches).
+static int decode_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int pitch, int W, int H, int black_thr,
+                           int rectify, float *phL, uint8_t *vL, float *phR, uint8_t *vR)
 {
-    const size_t n = (size_t)W * H;
-    // the phase images between the decode and K4 are internal: the valid flag travels INSIDE the phase (invalid pixels
-    // carry a NaN, which K4 never matches -- the decode kernels do that when their valid pointer is null), so neither
-    // side touches separate valid bytes (the decode's 64-byte partial-line stores, 2 B per stereo pixel each way)
-    void *phL, *phR, *vL = nullptr, *vR = nullptr;
-    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL));
-    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR));
     bool paired = false;
     if (rectify) {                                       // both cameras in one launch when the LDS-tiled form applies
         MfPlanes mp[2];
         for (int i = 0; i < SLR_MF_PLANES; i++) { mp[0].p[i] = pL[i]; mp[1].p[i] = pR[i]; }
-        float *const ph[2] = {(float *)phL, (float *)phR};
-        uint8_t *const vd[2] = {(uint8_t *)vL, (uint8_t *)vR};
+        float *const ph[2] = {phL, phR};
+        uint8_t *const vd[2] = {vL, vR};
         const int16_t *const mxy[2] = {c->d_map_xy[0], c->d_map_xy[1]};
         const uint16_t *const mfr[2] = {c->d_map_frac[0], c->d_map_frac[1]};
         const void *const box[2] = {c->d_tile_box[0], c->d_tile_box[1]};
@@ -906,11 +909,60 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
                                               &paired, c->stream));
     }
     if (!paired) {
-        SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, (float *)phL, (uint8_t *)vL));
-        SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, (float *)phR, (uint8_t *)vR));
+        SLR_TRY(core_mf_decode(c, 0, rectify != 0, pL, pitch, W, H, black_thr, phL, vL));
+        SLR_TRY(core_mf_decode(c, 1, rectify != 0, pR, pitch, W, H, black_thr, phR, vR));
     }
-    return core_mf_match(c, (const float *)phL, (const uint8_t *)vL, (const float *)phR, (const uint8_t *)vR, W, H, xyz,
-                         has, nullptr);
+    return SLR_OK;
+}
+
+static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int pitch, int W, int H,
+                              int black_thr, int rectify, float *xyz, uint8_t *has)
+{
+    const size_t n = (size_t)W * H;
+    // the phase images between the decode and K4 are internal: the valid flag travels INSIDE the phase (invalid pixels
+    // carry a NaN, which K4 never matches -- the decode kernels do that when their valid pointer is null), so neither
+    // side touches separate valid bytes (the decode's 64-byte partial-line stores, 2 B per stereo pixel each way)
+    void *phL, *phR;
+    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL));
+    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR));
+    SLR_TRY(decode_pair_dev(c, pL, pR, pitch, W, H, black_thr, rectify, (float *)phL, nullptr, (float *)phR, nullptr));
+    return core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz, has, nullptr);
+}
+
+// the checks slr_reconstruct_mf_batch applies to its arguments (also run for EVERY context of a multi-GPU call before any of
+// them is given work)
+static int mf_batch_check(slr_ctx *c, int pitch, int W, int H, int rectify)
+{
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_calib(c));
+    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    return SLR_OK;
+}
+
+// fused K1+K2 of BOTH cameras of a stereo frame (one launch when the LDS-tiled forms apply): loadCamImgs' 2 x 14 doStereoRectify
+// + decodePatterns of both cameras (mfreconstruct.cpp:119-134, 190-269)
+int slr_mf_rectify_decode_pair(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
+                               int pitch, int W, int H, int black_thr, float *phaseL, uint8_t *validL, float *phaseR, uint8_t *validR,
+                               slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !phaseL || !phaseR) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if ((validL == nullptr) != (validR == nullptr)) return fail(c, SLR_ERR_INVALID_ARG, "validL and validR must both be given or both be NULL");
+    for (int i = 0; i < SLR_MF_PLANES; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H));
+    Stage st(c, mem);
+    const uint8_t *dl[SLR_MF_PLANES], *dr[SLR_MF_PLANES];
+    void *pl, *vl, *pr, *vr;
+    const size_t n = (size_t)W * H;
+    SLR_TRY(st.planes(planesL, SLR_MF_PLANES, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, SLR_MF_PLANES, pitch, H, dr));
+    SLR_TRY(st.out(phaseL, n * 4, &pl)); SLR_TRY(st.out(validL, n, &vl));
+    SLR_TRY(st.out(phaseR, n * 4, &pr)); SLR_TRY(st.out(validR, n, &vr));
+    SLR_TRY(decode_pair_dev(c, dl, dr, pitch, W, H, black_thr, 1, (float *)pl, (uint8_t *)vl, (float *)pr, (uint8_t *)vr));
+    return st.finish();
 }
 
 int slr_reconstruct_mf(slr_ctx *c, const uint8_t *const planesL[SLR_MF_PLANES], const uint8_t *const planesR[SLR_MF_PLANES],
@@ -969,11 +1021,7 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
                              int rectify, float *xyz, uint8_t *has)
 {
     if (!c || !stack || !xyz || !has || n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
-    SLR_TRY(check_dims(c, W, H, pitch));
-    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
-    SLR_TRY(use_device(c));
-    SLR_TRY(need_calib(c));
-    if (rectify) { SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H)); }
+    SLR_TRY(mf_batch_check(c, pitch, W, H, rectify));
     const size_t plane = (size_t)pitch * H, n = (size_t)W * H;
     for (int f = 0; f < n_frames; f++) {
         const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
@@ -1122,8 +1170,65 @@ int slr_compact_points(slr_ctx *c, const float *xyz, const uint8_t *has, size_t 
 
 // ---- several GPUs in one process -------------------------------------------------------------------------------------------------
 // Frame f of the job runs on ctxs[f % n_ctx] (its shard index is f / n_ctx); every ctx works through its shard on its own
-// stream, so the devices run concurrently; afterwards the shards are assembled on ctxs[gather_ctx] by direct peer copies
-// (one hop over xGMI per source device; a frame's XYZ + mask go straight to their slot of the assembled [n_frames] arrays).
+// stream, so the devices run concurrently; afterwards the cloud is assembled by direct peer copies on the PRODUCING streams
+// (one hop over xGMI per source-destination pair; a frame's XYZ + mask go straight to their slot of the assembled [n_frames]
+// arrays): on one device (slr_reconstruct_mf_multi, a gather) or on every device (slr_reconstruct_mf_allgather).
+namespace {
+
+int multi_share(int n_frames, int n_ctx, int k) { return (n_frames - k + n_ctx - 1) / n_ctx; }   // frames k, k + n_ctx, ...
+
+// EVERYTHING that can be refused is checked here, for every context, before any of them is given work: a call fails as a whole
+// or only a HIP runtime error can interrupt it (and then multi_drain waits for what was already started)
+int multi_check(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H, int rectify)
+{
+    slr_ctx *c0 = ctxs[0];
+    for (int k = 0; k < n_ctx; k++) {
+        if (!ctxs[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null context");
+        if (multi_share(n_frames, n_ctx, k) > 0 && !stacks[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null shard");
+        const int st = mf_batch_check(ctxs[k], pitch, W, H, rectify);
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "a context refused the job", slr_last_error(ctxs[k])); return st; }
+    }
+    return SLR_OK;
+}
+
+// after a failure in the middle of a multi-GPU call: nothing may still be running (and writing the caller's buffers) when
+// the error is returned
+void multi_drain(slr_ctx *const *ctxs, int n_ctx)
+{
+    for (int k = 0; k < n_ctx; k++) {
+        if (hipSetDevice(ctxs[k]->device) == hipSuccess) (void)hipStreamSynchronize(ctxs[k]->stream);
+        (void)hipGetLastError();
+    }
+}
+
+#define SLR_MULTI_HIP(c, expr)                                                                                     \
+    do {                                                                                                           \
+        hipError_t e__ = (expr);                                                                                   \
+        if (e__ != hipSuccess) {                                                                                   \
+            const int st__ = fail((c), e__ == hipErrorOutOfMemory ? SLR_ERR_OOM : SLR_ERR_HIP, #expr, hipGetErrorString(e__)); \
+            if ((c) != ctxs[0]) fail(ctxs[0], st__, "a context failed", slr_last_error(c));                        \
+            multi_drain(ctxs, n_ctx);                                                                              \
+            return st__;                                                                                           \
+        }                                                                                                          \
+    } while (0)
+
+// is dst's memory directly addressable from src's device (same device, or peer access enabled now / before)?
+int peer_direct(slr_ctx *src, slr_ctx *dst, bool *direct)
+{
+    *direct = true;
+    if (src->device == dst->device) return SLR_OK;
+    int can = 0;
+    SLR_HIP(src, hipDeviceCanAccessPeer(&can, src->device, dst->device));
+    if (!can) { *direct = false; return SLR_OK; }
+    SLR_HIP(src, hipSetDevice(src->device));
+    const hipError_t e = hipDeviceEnablePeerAccess(dst->device, 0);
+    (void)hipGetLastError();
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) *direct = false;
+    return SLR_OK;
+}
+
+}  // namespace
+
 int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
                              int black_thr, int rectify, float *const *xyz, uint8_t *const *has, int gather_ctx,
                              float *xyz_all, uint8_t *has_all)
@@ -1132,41 +1237,89 @@ int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, cons
     slr_ctx *c0 = ctxs[0];
     if (!stacks || !xyz || !has || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
     if (gather_ctx >= n_ctx || (gather_ctx >= 0 && (!xyz_all || !has_all))) return fail(c0, SLR_ERR_INVALID_ARG, "gather target");
-    for (int k = 0; k < n_ctx; k++) {
-        const int share = (n_frames - k + n_ctx - 1) / n_ctx;            // frames k, k + n_ctx, ...
-        if (!ctxs[k] || (share > 0 && (!stacks[k] || !xyz[k] || !has[k]))) return fail(c0, SLR_ERR_INVALID_ARG, "null shard");
-    }
+    SLR_TRY(multi_check(ctxs, n_ctx, n_frames, stacks, pitch, W, H, rectify));
+    for (int k = 0; k < n_ctx; k++)
+        if (multi_share(n_frames, n_ctx, k) > 0 && (!xyz[k] || !has[k])) return fail(c0, SLR_ERR_INVALID_ARG, "null shard");
+    if (gather_ctx >= 0)                                        // peer access (idempotent); without it the runtime stages the copies
+        for (int k = 0; k < n_ctx; k++) { bool d; SLR_TRY(peer_direct(ctxs[k], ctxs[gather_ctx], &d)); }
     const size_t n = (size_t)W * H;
     // 1. every device starts on its shard (asynchronous on its own stream)
     for (int k = 0; k < n_ctx; k++) {
-        const int share = (n_frames - k + n_ctx - 1) / n_ctx;
+        const int share = multi_share(n_frames, n_ctx, k);
         if (share <= 0) continue;
         const int st = slr_reconstruct_mf_batch(ctxs[k], share, stacks[k], pitch, W, H, black_thr, rectify, xyz[k], has[k]);
-        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "shard failed", slr_last_error(ctxs[k])); return st; }
+        if (st != SLR_OK) {                                     // (only a HIP runtime error can get here: see multi_check)
+            if (ctxs[k] != c0) fail(c0, st, "shard failed", slr_last_error(ctxs[k]));
+            multi_drain(ctxs, n_ctx);
+            return st;
+        }
     }
     // 2. assembly: each source stream pushes its frames to the target device as soon as they are done
     if (gather_ctx >= 0) {
         slr_ctx *g = ctxs[gather_ctx];
         for (int k = 0; k < n_ctx; k++) {
-            const int share = (n_frames - k + n_ctx - 1) / n_ctx;
+            const int share = multi_share(n_frames, n_ctx, k);
             slr_ctx *c = ctxs[k];
-            SLR_TRY(use_device(c));
-            if (c->device != g->device) {                                    // one-hop peer access (idempotent)
-                int can = 0;
-                SLR_HIP(c, hipDeviceCanAccessPeer(&can, c->device, g->device));
-                if (can) { const hipError_t e = hipDeviceEnablePeerAccess(g->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SLR_HIP(c, e); (void)hipGetLastError(); }
-            }
+            SLR_MULTI_HIP(c, hipSetDevice(c->device));
             for (int j = 0; j < share; j++) {
                 const size_t f = (size_t)j * n_ctx + k;
-                SLR_HIP(c, hipMemcpyPeerAsync(xyz_all + f * n * 3, g->device, xyz[k] + (size_t)j * n * 3, c->device, n * 12, c->stream));
-                SLR_HIP(c, hipMemcpyPeerAsync(has_all + f * n, g->device, has[k] + (size_t)j * n, c->device, n, c->stream));
+                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(xyz_all + f * n * 3, g->device, xyz[k] + (size_t)j * n * 3, c->device, n * 12, c->stream));
+                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(has_all + f * n, g->device, has[k] + (size_t)j * n, c->device, n, c->stream));
             }
         }
     }
     // 3. the call returns when every device is done (the assembled cloud is complete)
     for (int k = 0; k < n_ctx; k++) {
-        SLR_TRY(use_device(ctxs[k]));
-        SLR_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+        SLR_MULTI_HIP(ctxs[k], hipSetDevice(ctxs[k]->device));
+        SLR_MULTI_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
+    }
+    return SLR_OK;
+}
+
+// north_star's exchange step from one process: EVERY device ends with the assembled cloud.  ctxs[k] computes its frames straight
+// into their slots of its own xyz_all[k] / has_all[k] ([n_frames][H][W][3] / [n_frames][H][W] on its device) and its stream then
+// pushes each of them into the same slot on every other device -- n_ctx - 1 concurrent one-hop copies per frame over the
+// point-to-point xGMI mesh, no staging buffer and no ring.  *peer_direct (may be NULL) = 1 when every destination was directly
+// addressable from every source (same device or peer access), 0 when the runtime had to stage at least one pair through the
+// host; require_peer != 0 turns that case into SLR_ERR_UNSUPPORTED before any work is enqueued.
+int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
+                                 int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all, int require_peer,
+                                 int *peer_direct_out)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c0 = ctxs[0];
+    if (!stacks || !xyz_all || !has_all || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
+    SLR_TRY(multi_check(ctxs, n_ctx, n_frames, stacks, pitch, W, H, rectify));
+    for (int k = 0; k < n_ctx; k++) if (!xyz_all[k] || !has_all[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null destination");
+    bool all_direct = true;
+    for (int k = 0; k < n_ctx; k++)
+        for (int j = 0; j < n_ctx; j++) {
+            bool d = true;
+            if (j != k) SLR_TRY(peer_direct(ctxs[k], ctxs[j], &d));
+            all_direct = all_direct && d;
+        }
+    if (peer_direct_out) *peer_direct_out = all_direct ? 1 : 0;
+    if (!all_direct && require_peer) return fail(c0, SLR_ERR_UNSUPPORTED, "peer access between two of the devices is not available");
+    const size_t n = (size_t)W * H, plane = (size_t)pitch * H;
+    for (int k = 0; k < n_ctx; k++) {
+        const int share = multi_share(n_frames, n_ctx, k);
+        slr_ctx *c = ctxs[k];
+        for (int j = 0; j < share; j++) {
+            const size_t f = (size_t)j * n_ctx + k;
+            // frame f of the job = frame j of this shard, computed in place
+            const int st = slr_reconstruct_mf_batch(c, 1, stacks[k] + (size_t)j * 2 * SLR_MF_PLANES * plane, pitch, W, H, black_thr, rectify,
+                                                    xyz_all[k] + f * n * 3, has_all[k] + f * n);
+            if (st != SLR_OK) { if (c != c0) fail(c0, st, "shard failed", slr_last_error(c)); multi_drain(ctxs, n_ctx); return st; }
+            for (int d = 0; d < n_ctx; d++) {
+                if (d == k || (xyz_all[d] == xyz_all[k] && ctxs[d]->device == c->device)) continue;
+                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(xyz_all[d] + f * n * 3, ctxs[d]->device, xyz_all[k] + f * n * 3, c->device, n * 12, c->stream));
+                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(has_all[d] + f * n, ctxs[d]->device, has_all[k] + f * n, c->device, n, c->stream));
+            }
+        }
+    }
+    for (int k = 0; k < n_ctx; k++) {
+        SLR_MULTI_HIP(ctxs[k], hipSetDevice(ctxs[k]->device));
+        SLR_MULTI_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
     }
     return SLR_OK;
 }

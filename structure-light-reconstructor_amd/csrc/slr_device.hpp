@@ -5,6 +5,8 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "slr.h"
 
 namespace slr {
@@ -15,6 +17,14 @@ constexpr float kTwoPI = 2 * kPI;          // f32 expression, as in the referenc
 constexpr float kThreeHalfPI = 3 * kPI / 2;
 constexpr float kHalfPI = kPI / 2;
 constexpr int kDecodeLutWords = 512 + 10 * 256 + 1;   // 511 reciprocal/sign words + the wrapped-phase table (kernels_decode.hip)
+
+// Per-device cache of a launch constant (resident workgroups of a kernel, CU count), filled on first use.  Host threads driving
+// different contexts may race to fill a slot: they store the same value.  Devices beyond the table are looked up on every launch.
+struct DevSlots {
+    std::atomic<int> v[64];
+    int get(int dev) const { return (unsigned)dev < 64u ? v[dev].load(std::memory_order_relaxed) : 0; }
+    void put(int dev, int x) { if ((unsigned)dev < 64u) v[dev].store(x, std::memory_order_relaxed); }
+};
 
 struct MfPlanes { const uint8_t *p[SLR_MF_PLANES]; };
 struct GrayPlanes { const uint8_t *p[SLR_MAX_GRAY_PLANES]; };
@@ -98,8 +108,9 @@ size_t     tile_boxes_bytes(int W, int H);
 hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, int4 *boxes, unsigned nofit_host[2],
                              hipStream_t s);
 
-// LDS-DMA form of the fused rectify + multi-frequency decode (kernels_rectdma.hip).  shape: destination tile 0 = 256x16,
-// 1 = 256x8, 2 = 512x8, 3 = 128x16.  launch_dma_tiles builds the per-tile source boxes + the map digest of one shape into
+// LDS-DMA form of the fused rectify + multi-frequency decode (kernels_rectdma.hip).  shape (SLR_OPT_RECT_DMA_SHAPE): destination
+// tile / threads 0 = 256x16 / 512, 1 = 256x8 / 512, 2 = 256x8 / 256, 3 = 128x16 / 512, 4 = 128x8 / 256, 5 = 256x4 / 256,
+// 6 = 128x16 / 256.  launch_dma_tiles builds the per-tile source boxes + the map digest of one shape into
 // `buf` (dma_tiles_bytes) and copies the number of tiles whose box does not fit the form to *nofit_host (valid after the
 // stream is synchronised).  launch_mf_rect_decode_dma: one camera (n == 1) or both cameras of a frame (n == 2) in one
 // launch; *done = false -> the stack layout / image width does not allow this form, nothing was launched.

@@ -167,6 +167,7 @@ public:
     int scanSN = 0;
     std::string imgSuffix = ".png";
     std::string lastError;
+    slr_ctx *context() const { return ctx; }             // (for MeshCreator: export on the device the scan ran on)
 private:
     bool EPI;
     stereoRect *sr = nullptr;
@@ -193,6 +194,7 @@ public:
     std::string imgSuffix = ".png";
     std::string lastError;
     bool camerasLoaded = false;
+    slr_ctx *context() const { return ctx; }             // (for MeshCreator: export on the device the scan ran on)
 private:
     bool loadCameras();
     void setScan(int sn);
@@ -209,11 +211,15 @@ private:
 // ---- MeshCreator (meshcreator.cpp:16-172; vertex numbering by slr_prefix_index on the GPU) ----------------------------
 class MeshCreator {
 public:
-    explicit MeshCreator(PointCloudImage *in);
+    // numbering_ctx: the context the vertex numbering runs on -- normally the reconstructor's (Reconstruct::context()), so the export
+    // uses the device the scan was reconstructed on.  nullptr: a context is created for the export on the calling thread's
+    // current HIP device.
+    explicit MeshCreator(PointCloudImage *in, slr_ctx *numbering_ctx = nullptr);
     bool exportObjMesh(const std::string &path);     // false: no GPU context for the vertex numbering, or the file cannot be written
     bool exportPlyMesh(const std::string &path);
 private:
     PointCloudImage *cloud;
+    slr_ctx *ctx;
     int w, h;
 };
 

@@ -68,7 +68,7 @@ int duke_run_project(const char *project, int mode, int sn, int scan_w, int scan
         if (pc_count) memcpy(pc_count, cloud->numOfPointsForPixel.data(), cloud->numOfPointsForPixel.size());
         if (pc_color && !cloud->color.empty()) memcpy(pc_color, cloud->color.data(), cloud->color.size());
         if (out_ply && *out_ply) {
-            MeshCreator mc(cloud);
+            MeshCreator mc(cloud, reconstructor ? reconstructor->context() : mfr->context());
             if (!mc.exportPlyMesh(out_ply)) { ok = false; msg = "cannot write the mesh"; }
         }
     }
@@ -103,6 +103,8 @@ int duke_run_series(const char *project, int sn_first, int n_scans, int scan_w, 
         if (pc_sum) memcpy(pc_sum + i * cells * 3, pc->points.data(), cells * 12);
         if (pc_count) memcpy(pc_count + i * cells, pc->numOfPointsForPixel.data(), cells);
         if (ply_prefix && *ply_prefix) {
+            // (not mfr.context(): the series' contexts run with SLR_OPT_ASYNC_HOST and have the next scan in flight; the export
+            //  takes its own context on this thread's current device, which is the one the series runs on)
             MeshCreator mc(pc);
             if (!mc.exportPlyMesh(std::string(ply_prefix) + std::to_string(sn) + ".ply")) return false;
         }

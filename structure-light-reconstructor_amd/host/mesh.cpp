@@ -31,15 +31,19 @@ struct Numbering {
     bool ok = false;
 };
 
-Numbering number_vertices(const PointCloudImage &cloud, uint32_t first)
+Numbering number_vertices(const PointCloudImage &cloud, uint32_t first, slr_ctx *ctx)
 {
     Numbering n;
     const int w = cloud.getWidth(), h = cloud.getHeight();
     n.id.assign((size_t)w * h, kNoVertex);
-    slr_ctx *ctx = nullptr;
-    if (slr_create(0, &ctx) != SLR_OK) return n;         // no GPU: the caller reports it (no CPU fallback in this library)
+    slr_ctx *own = nullptr;
+    if (!ctx) {                                          // no reconstructor context handed over: one on the current device
+        int dev = 0;
+        if (slr_current_device(&dev) != SLR_OK || slr_create(dev, &own) != SLR_OK) return n;   // no GPU: the caller reports it
+        ctx = own;
+    }
     n.ok = slr_prefix_index(ctx, cloud.numOfPointsForPixel.data(), w, h, 1, first, kNoVertex, n.id.data(), &n.count, SLR_MEM_HOST) == SLR_OK;
-    slr_destroy(ctx);
+    if (own) slr_destroy(own);
     return n;
 }
 
@@ -69,11 +73,11 @@ size_t triangles(const Numbering &n, int w, int h, uint32_t first, F emit)
 
 }  // namespace
 
-MeshCreator::MeshCreator(PointCloudImage *in) : cloud(in), w(in->getWidth()), h(in->getHeight()) {}
+MeshCreator::MeshCreator(PointCloudImage *in, slr_ctx *numbering_ctx) : cloud(in), ctx(numbering_ctx), w(in->getWidth()), h(in->getHeight()) {}
 
 bool MeshCreator::exportPlyMesh(const std::string &path)
 {
-    const Numbering n = number_vertices(*cloud, 0);
+    const Numbering n = number_vertices(*cloud, 0, ctx);
     if (!n.ok) return false;
     const size_t faces = triangles(n, w, h, 0, [](uint32_t, uint32_t, uint32_t) {});
     std::string s;
@@ -101,7 +105,7 @@ bool MeshCreator::exportPlyMesh(const std::string &path)
 
 bool MeshCreator::exportObjMesh(const std::string &path)
 {
-    const Numbering n = number_vertices(*cloud, 1);
+    const Numbering n = number_vertices(*cloud, 1, ctx);
     if (!n.ok) return false;
     std::string s;
     s.reserve((size_t)n.count * 40 + 512);

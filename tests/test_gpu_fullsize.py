@@ -22,6 +22,81 @@ def scene(synth):
     return st, maps, calib, info
 
 
+@pytest.fixture(scope="module")
+def oracle_dec(oracle, scene):
+    """the oracle's remap + decode of BOTH cameras of the scene (28 full-size remaps: computed once per module)"""
+    st, maps, _, _ = scene
+    out = []
+    for cam in range(2):
+        raw = st[cam].cpu().numpy()
+        mx, mf = maps[cam][0].cpu().numpy(), maps[cam][1].cpu().numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+        out.append(oracle.mf_decode(rect, BLACK))
+    return out
+
+
+def test_fullsize_shipped_pair_launch_both_cameras_vs_oracle(ctx, oracle, scene, oracle_dec, slr):
+    """What the product runs at its DEFAULT options -- both cameras' fused rectify + decode in ONE launch with the valid flag
+    folded into the phase as a NaN, then the lean K4 -- against a pure-oracle chain (remap -> decode -> triangulation), for
+    both cameras directly: the pair launch's phases, then the whole-path XYZ / mask.  Then the same launch with separate valid
+    bytes, and the other pair-launch shapes / depths."""
+    st, maps, calib, _ = scene
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    nan = np.float32(np.nan)
+    folded = [np.where(oracle_dec[cam][1] != 0, oracle_dec[cam][0], nan).astype(np.float32) for cam in range(2)]
+    assert np.isnan(folded[0]).any() and (oracle_dec[0][1] != 0).mean() > 0.5
+    ph, _ = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=False)      # defaults: auto -> form 7, shape 3, depth 2
+    ctx.synchronize()
+    for cam in range(2):
+        assert bits_equal(np_of(ph[cam]), folded[cam]), cam
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    exyz, ehas, _ = oracle.mf_triangulate(oracle_dec[0][0], oracle_dec[0][1], oracle_dec[1][0], oracle_dec[1][1], camL, camR, Q, T)
+    xyz, has = ctx.reconstruct_mf(st[0], st[1], BLACK, True)
+    ctx.synchronize()
+    assert bits_equal(np_of(has), ehas) and bits_equal(np_of(xyz), exyz)
+    assert 0.2 < ehas.mean() < 1.0
+    cap = slr.capi
+    try:
+        for shape, depth, want_valid in [(3, 2, True), (3, 1, False), (0, 2, False), (1, 2, True), (1, 1, False)]:
+            ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 7)                            # explicit 7: an inapplicable form fails loudly
+            ctx.set_option(cap.OPT_RECT_DMA_SHAPE, shape)
+            ctx.set_option(cap.OPT_RECT_DMA_DEPTH, depth)
+            ph, vd = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=want_valid)
+            ctx.synchronize()
+            for cam in range(2):
+                if want_valid:
+                    assert bits_equal(np_of(vd[cam]), oracle_dec[cam][1]) and bits_equal(np_of(ph[cam]), oracle_dec[cam][0]), (shape, depth, cam)
+                else:
+                    assert bits_equal(np_of(ph[cam]), folded[cam]), (shape, depth, cam)
+    finally:
+        ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 0)
+        ctx.set_option(cap.OPT_RECT_DMA_SHAPE, 3)
+        ctx.set_option(cap.OPT_RECT_DMA_DEPTH, 2)
+
+
+def test_fullsize_mf_cloud_entry_vs_oracle(ctx, oracle, scene, oracle_dec):
+    """slr_reconstruct_mf_cloud (the whole MF path + the PointCloudImage adaptor, the XYZ grid never leaving the device) against
+    the oracle chain, with device buffers at two scan sizes and with host buffers (staged, SLR_MEM_HOST)"""
+    st, maps, calib, _ = scene
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    exyz, ehas, _ = oracle.mf_triangulate(oracle_dec[0][0], oracle_dec[0][1], oracle_dec[1][0], oracle_dec[1][1], camL, camR, Q, T)
+    for scan_w, scan_h in ((1280, 1024), (3000, 4096)):
+        es, ec, _ = oracle.pointcloud_from_grid(exyz, ehas, scan_w, scan_h, None)
+        s, c = ctx.reconstruct_mf_cloud(st[0], st[1], BLACK, True, scan_w, scan_h)
+        ctx.synchronize()
+        assert bits_equal(np_of(c), ec) and bits_equal(np_of(s), es), (scan_w, scan_h)
+        assert (ec > 0).mean() > 0.1
+    hl, hr = st[0].cpu().numpy(), st[1].cpu().numpy()
+    es, ec, _ = oracle.pointcloud_from_grid(exyz, ehas, 1280, 1024, None)
+    s, c = ctx.reconstruct_mf_cloud(hl, hr, BLACK, True, 1280, 1024)
+    assert bits_equal(c, ec) and bits_equal(s, es)
+
+
 def test_fullsize_mf_decode_and_fused_rectify(ctx, oracle, scene):
     st, maps, calib, _ = scene
     for cam in range(2):
@@ -220,3 +295,63 @@ def test_config5_size_mfn_decode_and_chunked_match(ctx, oracle, synth):
                                         row0=r0, image_h=H5)
         ctx.synchronize()
         assert torch.equal(bx, xyz[r0:r1]) and torch.equal(bh, has[r0:r1]) and torch.equal(bk, mk[r0:r1]), b
+
+
+def test_batch_entry_ge_two_frames_with_spare_planes(ctx, oracle, synth, scene, slr):
+    """slr_reconstruct_batch in SLR_MODE_GE (what `bench.py --mode ge` times; Reconstruct::runReconstruction_GE,
+    reconstruct.cpp:271-307): two different 4096x3000 frames in one stack whose planes_per_cam (28) exceeds what the mode needs
+    (26), rectification + colour, every frame against the oracle chain remap -> decode -> triangulation_ge"""
+    _, maps, calib, _ = scene
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+    dev = torch.device("cuda", 0)
+    ncol = synth.gray_num_bits(W)
+    ppc = 2 + 2 * ncol + 2
+    stack = torch.full((2, 2, ppc, H, W), 123, dtype=torch.uint8, device=dev)         # spare planes: junk that must not be read
+    for f in range(2):
+        stack[f, :, :2 + 2 * ncol] = synth.render_gray_stack(W, H, W, seed=300 + f, noise=2, device=dev)
+    torch.cuda.synchronize()
+    xyz, has, col = ctx.reconstruct_batch(slr.capi.MODE_GE, stack, BLACK, 3, n_col_bits=ncol, scan_w=W, rectify=True, have_color=True)
+    ctx.synchronize()
+    _, _, Q, T = calib_parts(oracle, calib)
+    for f in range(2):
+        edec, white = [], []
+        for cam in range(2):
+            raw = stack[f, cam, :2 + 2 * ncol].cpu().numpy()
+            mx, mf = maps[cam][0].cpu().numpy(), maps[cam][1].cpu().numpy()
+            rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(raw.shape[0])])
+            ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 3, W, 0)
+            edec.append((ex, ev))
+            white.append(rect[0])
+        exyz, ehas, ecol, _ = oracle.ge_triangulate(edec[0][0], edec[0][1], edec[1][0], edec[1][1], Q, T, white[0], white[1])
+        assert bits_equal(np_of(has[f]), ehas) and bits_equal(np_of(xyz[f]), exyz) and bits_equal(np_of(col[f]), ecol), f
+        assert ehas.mean() > 0.3
+    assert not torch.equal(has[0], has[1])
+
+
+def test_batch_entry_gray_only_two_frames_with_spare_planes(ctx, oracle, synth, slr):
+    """slr_reconstruct_batch in SLR_MODE_GRAY (what `bench.py --mode gray` times; Reconstruct::runReconstruction,
+    reconstruct.cpp:230-265): two different frames, 46 planes per camera in the stack for a mode that needs 44"""
+    scan_w, scan_h = 1280, 1024
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    dev = torch.device("cuda", 0)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    need = 2 + 2 * ncol + 2 * nrow
+    stack = torch.full((2, 2, need + 2, H, W), 77, dtype=torch.uint8, device=dev)
+    for f in range(2):
+        stack[f, :, :need] = synth.render_gray_stack(W, H, scan_w, scan_h, seed=60 + f, noise=2, device=dev, rows=True)
+    torch.cuda.synchronize()
+    xyz, cnt, _ = ctx.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=scan_w,
+                                        scan_h=scan_h, rectify=False)
+    ctx.synchronize()
+    for f in range(2):
+        dec = [oracle.gray_decode(stack[f, c, :need].cpu().numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h) for c in range(2)]
+        offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+        offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+        exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+        assert bits_equal(np_of(cnt[f]), ecnt) and bits_equal(np_of(xyz[f]), exyz), f
+        assert (ecnt > 0).mean() > 0.2
+    assert not torch.equal(cnt[0], cnt[1])

@@ -148,8 +148,9 @@ def test_dma_form_strict_when_asked_for_and_auto_falls_back(dma_ctx, slr, oracle
     assert bits_equal(np_of(v), ev) and bits_equal(np_of(ph), eph)
 
 
-def test_dma_form_fullsize_pair_launch(dma_ctx, slr, oracle, synth):
-    """4096x3000, both cameras: the bench configuration, every shape at depth 1 and three of them at depth 2"""
+def test_dma_form_fullsize_every_shape(dma_ctx, slr, oracle, synth):
+    """4096x3000, both cameras one launch each (the pair launch proper: test_gpu_fullsize.py): every shape at depth 1 and four of
+    them at depth 2, the shipped default (3, 2) among them"""
     ctx = dma_ctx
     W, H = 4096, 3000
     dev = torch.device("cuda", 0)
@@ -158,7 +159,7 @@ def test_dma_form_fullsize_pair_launch(dma_ctx, slr, oracle, synth):
     torch.cuda.synchronize()
     exp = [_expect(oracle, st[cam].cpu().numpy(), maps[cam][0].cpu().numpy(), maps[cam][1].cpu().numpy()) for cam in range(2)]
     ran = []
-    for shape, depth in [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (0, 2), (1, 2), (4, 2)]:
+    for shape, depth in [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (0, 2), (1, 2), (3, 2), (4, 2)]:
         _opts(ctx, slr, 7, shape, depth)
         for cam in range(2):
             ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
