@@ -139,10 +139,13 @@ def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
     camL, camR, Q, T = calib_parts(O, calib)
     t0 = time.perf_counter()
     dec = []
+    t_remap = 0.0
     for cam in range(2):
         planes = stack_cpu[cam]
         if maps_cpu is not None:
+            tr = time.perf_counter()
             planes = np.stack([O.remap_u8(planes[p], maps_cpu[cam][0], maps_cpu[cam][1]) for p in range(14)])
+            t_remap += time.perf_counter() - tr
         dec.append(O.mf_decode(planes, BLACK_THR))
     t_dec = time.perf_counter() - t0
     r0 = H // 2 - rows // 2
@@ -176,12 +179,53 @@ def cpu_baseline(synth, W, H, stack_cpu, maps_cpu, calib, rows):
                  "note": "NOT the reference (single-threaded): the same C port, row-parallel over all host cores; whole frame, %.2f s" % t_all}
     except Exception as e:                               # the baseline must never break the bench line
         extra = {"error": repr(e)}
+    try:
+        literal = literal_cost_baseline(synth, O, W, H, t_remap)
+    except Exception as e:                                   # the baseline must never break the bench line
+        literal = {"error": repr(e)}
     return {
+        "literal_cost": literal,
         "value": round(W * H / per_frame / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
         "sample": "1 stereo frame %dx%d: full-frame remap+decode of both cameras (%.1f s) + match/triangulate on %d of %d "
                   "rows (%.1f s), scaled to the frame; single thread, gcc -O2" % (W, H, t_dec, rows, H, t_tri),
         "host_cpus": os.cpu_count(), "all_cores_extra": extra,
     }
+
+
+def literal_cost_baseline(synth, O, W, H, t_remap_frame):
+    """the reference's REAL cost model (oracle/slr_literal.cpp: a heap vector per pixel, by-value matrix headers, a
+    vector copy per comparison -- mfreconstruct.cpp:165, :286-291, utilities.cpp:125) timed at 640x480 (whole frame) and
+    1280x1024 (whole-frame decode, match on every 16th row) and extrapolated to W x H: the decode linearly in pixels, the match
+    as rows x W^(1 + e) with the exponent e fitted between the two sizes (a left pixel's search walks ~half the right row, so
+    e ~ 1).  A reported baseline only, like the flat port beside it."""
+    import math
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import calib_parts
+    pts = []
+    for (w, h, step) in ((640, 480, 1), (1280, 1024, 16)):
+        calib, _ = synth.make_calibration(w, h)
+        camL, camR, Q, T = calib_parts(O, calib)
+        st = synth.render_mf_stack(w, h, seed=1234, noise=2).numpy()
+        rows = len(range(0, h, step))
+        _, has, t_dec, t_tri = O.literal_mf(st[0], st[1], BLACK_THR, camL, camR, Q, T, rows=(0, h), row_step=step)
+        pts.append({"size": "%dx%d" % (w, h), "decode_s": round(t_dec, 3), "match_rows": rows, "match_s": round(t_tri, 3),
+                    "decode_ns_per_cam_px": round(t_dec / (2.0 * w * h) * 1e9, 1),
+                    "match_ns_per_left_px": round(t_tri / (rows * float(w)) * 1e9, 1), "matched_frac": round(float(has[::step].mean()), 3),
+                    "_w": w})
+    a, b = pts
+    e = math.log(b["match_ns_per_left_px"] / a["match_ns_per_left_px"]) / math.log(b["_w"] / float(a["_w"]))
+    t_dec = b["decode_ns_per_cam_px"] * 1e-9 * 2.0 * W * H
+    t_match = b["match_ns_per_left_px"] * 1e-9 * (W / float(b["_w"])) ** e * float(W) * H
+    total = t_dec + t_match + t_remap_frame
+    for p_ in pts:
+        del p_["_w"]
+    return {"value": round(W * H / total / 1e6, 5), "unit": "Mpix/s", "cores": 1, "kind": "port (literal cost model)",
+            "extrapolated_s_per_frame": {"decode": round(t_dec, 1), "match_triangulate": round(t_match, 1),
+                                         "remap_flat_port": round(t_remap_frame, 2), "total": round(total, 1)},
+            "match_width_exponent": round(e, 3), "measured": pts,
+            "sample": "oracle/slr_literal.cpp at 640x480 (whole frame) and 1280x1024 (decode whole, match on every 16th row), extrapolated to "
+                      "%dx%d; single thread, g++ -O2" % (W, H)}
 
 
 def live_traffic(args, kernel_name):

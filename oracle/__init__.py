@@ -10,8 +10,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libslr_oracle.so")
+# SLR_ORACLE_SANITIZED=1 (set by tests/test_oracle_sanitized.py for its child process, which also preloads the sanitizer
+# runtimes): load the AddressSanitizer + UBSan builds of the two libraries (oracle/san/, `make -C oracle sanitized`)
+_SAN = os.environ.get("SLR_ORACLE_SANITIZED") == "1"
+_LIB_DIR = os.path.join(_HERE, "san") if _SAN else _HERE
+_LIB_PATH = os.path.join(_LIB_DIR, "libslr_oracle.so")
+_LIT_PATH = os.path.join(_LIB_DIR, "libslr_literal.so")
 _lib = None
+_lit = None
 
 MF_PLANES = 14
 PI_F = np.float32(3.1416)
@@ -38,11 +44,12 @@ class Camera(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "slr_oracle.c")
-    if (not force and os.path.exists(_LIB_PATH)
-            and (not os.path.exists(src) or os.path.getmtime(_LIB_PATH) >= os.path.getmtime(src))):
+    srcs = [os.path.join(_HERE, f) for f in ("slr_oracle.c", "slr_oracle.h", "slr_literal.cpp")]
+    newest = max(os.path.getmtime(f) for f in srcs if os.path.exists(f))
+    if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_LIT_PATH)
+            and min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_LIT_PATH)) >= newest):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _HERE, "-B"] + (["sanitized"] if _SAN else []), stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
 
@@ -202,6 +209,35 @@ def mf_triangulate(phaseL, validL, phaseR, validR, camL, camR, Q, T=None, rows=N
                                    C.c_int(W), C.c_int(H), C.c_int(r0), C.c_int(r1),
                                    C.byref(camL), C.byref(camR), _p(Qa), _p(Ta), _p(xyz), _p(has), _p(mk))
     return xyz, has, mk
+
+
+def literal_lib():
+    """the literal-cost model of the reference's MF path (slr_literal.cpp): the oracle's arithmetic on the reference's data
+    structures -- a baseline / test helper like everything else in this package"""
+    global _lit
+    if _lit is None:
+        if not os.path.exists(_LIT_PATH):
+            build()
+        _lit = C.CDLL(_LIT_PATH)
+    return _lit
+
+
+def literal_mf(planesL, planesR, black_thr, camL, camR, Q, T=None, rows=None, row_step=1):
+    """planes: [14][H][W] u8, already rectified.  Decodes both cameras with per-pixel heap vectors and by-value matrix headers,
+    matches + triangulates image rows rows[0], rows[0] + row_step, ... < rows[1] (default: all).  Returns (xyz, has, t_decode_s,
+    t_triangulate_s)."""
+    pl, pitch = _planes_ptrs(planesL)
+    pr, pitch2 = _planes_ptrs(planesR)
+    H, W = planesL.shape[1], planesL.shape[2]
+    assert pitch == pitch2 == W and planesL.shape[0] == MF_PLANES and planesR.shape == planesL.shape
+    xyz = np.zeros((H, W, 3), np.float32)
+    has = np.zeros((H, W), np.uint8)
+    t = np.zeros(2, np.float64)
+    r0, r1 = (0, H) if rows is None else rows
+    Qa, Ta = _q(Q), _t(T)
+    literal_lib().slro_literal_mf(pl, pr, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr), C.byref(camL), C.byref(camR),
+                                  _p(Qa), _p(Ta), C.c_int(r0), C.c_int(r1), C.c_int(row_step), _p(xyz), _p(has), _p(t))
+    return xyz, has, float(t[0]), float(t[1])
 
 
 def ge_triangulate(codeL, validL, codeR, validR, Q, T=None, whiteL=None, whiteR=None):

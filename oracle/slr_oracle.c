@@ -314,7 +314,7 @@ void slro_undistort_point(float px, float py, const slro_camera *cam, float *ox,
 }
 
 /* cv::Mat 3x4 f32 * 4x1 f32 : OpenCV f32 GEMM accumulates in f64 and narrows (SURVEY 8c-3 iii) */
-static void slro_apply_T(const float *T, const float in[3], float out[3])
+void slro_apply_T(const float *T, const float in[3], float out[3])
 {
     const float p[4] = {in[0], in[1], in[2], 1.0f};
     for (int r = 0; r < 3; r++) {
@@ -325,7 +325,7 @@ static void slro_apply_T(const float *T, const float in[3], float out[3])
 }
 
 /* Q (4x4 f64) * p (4x1 f64), then x/w..  mfreconstruct.cpp:299-311 / reconstruct.cpp:570-582 */
-static void slro_reproject(const double Q[16], const double p[4], float out[3])
+void slro_reproject(const double Q[16], const double p[4], float out[3])
 {
     double r[4];
     for (int i = 0; i < 4; i++) {

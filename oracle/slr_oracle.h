@@ -82,6 +82,12 @@ void slro_gray_decode(const uint8_t *const *planes, int n_col_bits, int n_row_bi
 /* ---- a11 : Utilities::undistortPoints utilities.cpp:58-94 ---------------------------------------- */
 void slro_undistort_point(float px, float py, const slro_camera *cam, float *ox, float *oy);
 
+/* the two matrix products of a matched pixel, exposed for the literal-cost model (slr_literal.cpp):
+ * Q (4x4 f64) * p (4x1 f64), then x/w, y/w, z/w narrowed  mfreconstruct.cpp:299-311 / reconstruct.cpp:570-582;
+ * matCoordTrans (3x4 f32) * [X;1]: f64 accumulate, narrowed once  mfreconstruct.cpp:316-322 */
+void slro_reproject(const double Q[16], const double p[4], float out[3]);
+void slro_apply_T(const float *T, const float in[3], float out[3]);
+
 /* ---- a4 : MFReconstruct::triangulation mfreconstruct.cpp:272-334 (natural [H][W] output, Q11 lives
  *      in slro_pointcloud_from_grid).  T: 3x4 row-major f32 or NULL (scanSN==0).
  *      xyz [H][W][3] (0 where no point), has [H][W], match_k [H][W] (-1 where none; may be NULL). */

@@ -466,7 +466,12 @@ struct DmaDecode {
     // waits concern its own DMAs only, the barrier behind them covers everybody else's -- so there is no scratch slot for dummy
     // transfers: with it the triple buffer of DMA depth 2 plus the 8 KB weight tables would miss three workgroups per CU by 1 KB.
     static constexpr int DIG_OFF = D * 2 * PS, DIG_BYTES = TW * TH * 4;
+#if defined(SLR_DMA_NOWT)            // experiment: blend weights computed per tile instead of tabulated (8 KB of LDS back)
+    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF, WT_BYTES = 0, TAP_WT = -1;
+#else
     static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4, WT_BYTES = 2 * 1026 * 4;   // two tables: w0[1025], w1[1025]
+    static constexpr int TAP_WT = WT_OFF;
+#endif
     static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
     static constexpr int LDS_BYTES = LUT_OFF + (kLutWords + 1) * 4;
     static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
@@ -577,7 +582,7 @@ struct DmaDecode {
             if (out_pending) flush();
             // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
             ok = 0;
         }
         constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
@@ -684,6 +689,7 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
     d.lut = lut;
     for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
+    if constexpr (Dec::WT_BYTES > 0)
     for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
         unsigned w0, w1;
         dma_weights(i, w0, w1);
@@ -733,6 +739,9 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     };
 
+#if defined(SLR_DMA_CLOCKPROBE)      // experiment: shader clocks vs the 100 MHz constant clock over workgroup 0's life -> phase[0..3]
+    const unsigned long long probe_c0 = clock64(), probe_w0 = wall_clock64();
+#endif
     int cur = xcd * per + lb;
     unsigned voff_cur = box_voff(boxes[cur]);
     // prologue = what the last phases of a previous tile would have issued: digest, plane DMAs of phases 0 .. A-1
@@ -763,6 +772,12 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     }
     d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
+#if defined(SLR_DMA_CLOCKPROBE)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(jobs.j[0].phase);
+        o[0] = clock64() - probe_c0; o[1] = wall_clock64() - probe_w0;
+    }
+#endif
 }
 
 // the stack layout this form needs: 14 planes equally spaced in one allocation (buffer addressing: plane = scalar offset),
@@ -814,6 +829,10 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
     return hipGetLastError();
 }
 
+#ifndef SLR_DMA_A2
+#define SLR_DMA_A2 2            // DMA issue distance of SLR_OPT_RECT_DMA_DEPTH = 2 (experiments: 3 with -DSLR_DMA_NOWT)
+#endif
+#define SLR_DMA_DEPTH2(TW, TH, NT) ((TW) == 128 && (TH) == 16 && (NT) == 512 ? SLR_DMA_A2 : 2)   // (only the default shape has the LDS for more)
 // one camera (n == 1) or both cameras of a stereo frame (n == 2) in one launch.  *done = false: this form does not apply
 // (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
@@ -831,8 +850,8 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
     *done = true;
     hipError_t e = hipSuccess;
 #define SLR_DMA_X(TW, TH, NT)                                                                                          \
-    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, 2, true>(j, n, pitch, W, H, black_thr, lut, s)              \
-                         : launch_dma_variant<TW, TH, NT, 2, false>(j, n, pitch, W, H, black_thr, lut, s))            \
+    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true>(j, n, pitch, W, H, black_thr, lut, s)     \
+                         : launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), false>(j, n, pitch, W, H, black_thr, lut, s))   \
                    : (hv ? launch_dma_variant<TW, TH, NT, 1, true>(j, n, pitch, W, H, black_thr, lut, s)              \
                          : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, s))
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
