@@ -149,6 +149,22 @@ int slr_set_rectify_maps(slr_ctx *ctx, int cam, const int16_t *map_xy, const uin
  * rectification maps (bit-identical to the host restatement, which the oracle checks). */
 int slr_init_rectify_maps(slr_ctx *ctx, int cam, const double M[9], const double D[5], const double R[9],
                           const double P[12], int W, int H);
+/* What the installed maps of `cam` mean for the fused rectify + decode kernels (they pick their form per call from this):
+ *   mf_form          the SLR_OPT_RECT_DECODE_ALGO value the multi-frequency decode resolves to for these maps under the current
+ *                    options (7 = LDS-DMA form; 5 / 6 = round-1 LDS tiles, which fall back per tile to a gather)
+ *   dma_tiles / dma_nofit_tiles   tiles of the LDS-DMA form's shape, and how many of them have a source box larger than the
+ *                    form holds (any -> auto does not use form 7 for these maps); 0xFFFFFFFF: no tables (W % 16 != 0)
+ *   quads_by_class   4-pixel quads whose taps fit one 8-byte window of 2 source rows / of 3 rows / neither (fitting tiles)
+ *   waves_by_mode    (tile, wave) pairs decoded in the two-row / three-row / per-pixel read mode (the three-row mode costs
+ *                    ~27 % more instructions, the per-pixel one ~4x the LDS reads)
+ *   lds_nofit_tiles  tiles that fit neither the 64x8 nor the 128x8 round-1 form (those pixels are gathered) */
+typedef struct slr_rectify_info {
+    int W, H, mf_form, dma_shape, dma_depth;
+    unsigned dma_tiles, dma_nofit_tiles;
+    unsigned quads_by_class[3], waves_by_mode[3];
+    unsigned lds_nofit_tiles[2];
+} slr_rectify_info;
+int slr_get_rectify_info(slr_ctx *ctx, int cam, slr_rectify_info *out);
 /* read back the maps currently installed for `cam` (host or device destination) */
 int slr_get_rectify_maps(slr_ctx *ctx, int cam, int16_t *map_xy, uint16_t *map_frac, int W, int H, slr_mem mem);
 

@@ -35,7 +35,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED
 SYMBOLS = [
     "slr_version", "slr_status_string", "slr_current_device", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
     "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_init_rectify_maps",
-    "slr_get_rectify_maps", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
+    "slr_get_rectify_maps", "slr_get_rectify_info", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
     "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
@@ -61,6 +61,12 @@ class Camera(C.Structure):
 class BatchDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("mode", "n_frames", "planes_per_cam", "pitch", "W", "H", "black_thr", "white_thr",
                                         "n_col_bits", "n_row_bits", "scan_w", "scan_h", "rectify", "have_color")]
+
+
+class RectifyInfo(C.Structure):
+    _fields_ = [("W", C.c_int), ("H", C.c_int), ("mf_form", C.c_int), ("dma_shape", C.c_int), ("dma_depth", C.c_int),
+                ("dma_tiles", C.c_uint), ("dma_nofit_tiles", C.c_uint), ("quads_by_class", C.c_uint * 3),
+                ("waves_by_mode", C.c_uint * 3), ("lds_nofit_tiles", C.c_uint * 2)]
 
 
 MODE_GRAY, MODE_GE, MODE_MF = 0, 1, 2
@@ -276,6 +282,15 @@ class Context:
         a = [np.ascontiguousarray(x, np.float64).reshape(n) for x, n in ((M, 9), (D, 5), (R, 9), (P, 12))]
         self._chk(self.lib.slr_init_rectify_maps(self.h, C.c_int(cam), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
                                                  C.c_int(W), C.c_int(H)))
+
+    def rectify_info(self, cam):
+        """slr_get_rectify_info as a dict: which fused-decode form the installed maps of `cam` select, tile / quad statistics."""
+        info = RectifyInfo()
+        self._chk(self.lib.slr_get_rectify_info(self.h, C.c_int(cam), C.byref(info)))
+        return {"mf_form": info.mf_form, "dma_shape": info.dma_shape, "dma_depth": info.dma_depth, "dma_tiles": info.dma_tiles,
+                "dma_nofit_tiles": None if info.dma_nofit_tiles == 0xFFFFFFFF else info.dma_nofit_tiles,
+                "quads_by_class": list(info.quads_by_class), "waves_by_mode": list(info.waves_by_mode),
+                "lds_nofit_tiles": list(info.lds_nofit_tiles)}
 
     def get_rectify_maps(self, cam, W, H):
         xy = np.empty((H, W, 2), np.int16)

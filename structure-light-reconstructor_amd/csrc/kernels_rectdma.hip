@@ -145,6 +145,7 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     }
     __syncthreads();
     const int x0 = sbox[0], y0 = sbox[1], fits = sbox[2];
+    unsigned tcls = 0;                                      // the thread's read class over its quads (what dma_tap_setup sees)
 #pragma unroll
     for (int p = 0; p < Gm::NQ; p++) {
         // the quad's class and base (r0, c0) over its pixels that sample anything
@@ -166,6 +167,16 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             if (fits && sxs[q] != 0x7FFFFFFF && (sxs[q] - x0) - 4 * c0 > 6) wide = true;
         }
         const unsigned cls = wide ? 2u : (r1 > r0 ? 1u : 0u);
+        tcls = cls > tcls ? cls : tcls;
+        if (fits) {                                         // statistics (slr_get_rectify_info): quads per class
+            const unsigned long long b1 = __ballot(cls == 1u), b2 = __ballot(cls == 2u);
+            if (lane == 0) {
+                const unsigned n1 = (unsigned)__popcll(b1), n2 = (unsigned)__popcll(b2);
+                atomicAdd(nofit + 1, 64u - n1 - n2);
+                if (n1) atomicAdd(nofit + 2, n1);
+                if (n2) atomicAdd(nofit + 3, n2);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int q = 4 * p + i;
@@ -182,6 +193,10 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             digest[(size_t)blockIdx.x * (TW * TH) + threadIdx.x * Gm::PX + q] = e;
         }
     }
+    if (fits) {                                             // ... and waves per read mode (the wave-uniform choice of the decode)
+        const int mode = __ballot(tcls == 2u) != 0ull ? 2 : (__ballot(tcls == 1u) != 0ull ? 1 : 0);
+        if (lane == 0) atomicAdd(nofit + 4 + mode, 1u);
+    }
 }
 
 static size_t dma_tile_count(int W, int H, int shape)
@@ -195,6 +210,7 @@ static size_t dma_nofit_offset(int W, int H, int shape)
     return dma_digest_offset(W, H, shape) + dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
 }
 size_t dma_tiles_bytes(int W, int H, int shape) { return dma_nofit_offset(W, H, shape) + 256; }
+size_t dma_tile_count_of(int W, int H, int shape) { return dma_tile_count(W, H, shape); }
 
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
                             unsigned *nofit_host, hipStream_t s)
@@ -203,7 +219,7 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
     int4 *boxes = reinterpret_cast<int4 *>(b);
     unsigned *digest = reinterpret_cast<unsigned *>(b + dma_digest_offset(W, H, shape));
     unsigned *nofit = reinterpret_cast<unsigned *>(b + dma_nofit_offset(W, H, shape));
-    hipError_t e = hipMemsetAsync(nofit, 0, 16, s);
+    hipError_t e = hipMemsetAsync(nofit, 0, kDmaTileStats * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
     const dim3 grid((unsigned)dma_tile_count(W, H, shape));
@@ -212,7 +228,7 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
 #undef SLR_DMA_X
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return hipMemcpyAsync(nofit_host, nofit, sizeof(unsigned), hipMemcpyDeviceToHost, s);   // the caller synchronises the stream
+    return hipMemcpyAsync(nofit_host, nofit, kDmaTileStats * sizeof(unsigned), hipMemcpyDeviceToHost, s);   // the caller synchronises the stream
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -686,6 +702,9 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     d.smem = smem;
     d.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     if (d.lds0 & 0x1FFFu) __builtin_trap();                 // the tap addresses OR the buffer base in (no static LDS here: 0)
+#if defined(SLR_DMA_CLOCKPROBE)
+    const unsigned long long probe_entry = wall_clock64();
+#endif
     float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
     d.lut = lut;
     for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
@@ -739,7 +758,7 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     };
 
-#if defined(SLR_DMA_CLOCKPROBE)      // experiment: shader clocks vs the 100 MHz constant clock over workgroup 0's life -> phase[0..3]
+#if defined(SLR_DMA_CLOCKPROBE)      // experiment: every workgroup's life on the 100 MHz constant clock (+ shader cycles) -> phase buffer of job 0
     const unsigned long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
     int cur = xcd * per + lb;
@@ -773,9 +792,11 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
 #if defined(SLR_DMA_CLOCKPROBE)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long *o = reinterpret_cast<unsigned long long *>(jobs.j[0].phase);
-        o[0] = clock64() - probe_c0; o[1] = wall_clock64() - probe_w0;
+    if (threadIdx.x == 0) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(jobs.j[0].phase) + 4 * blockIdx.x;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = probe_entry; o[1] = wall_clock64(); (void)probe_w0; o[2] = clock64() - probe_c0; o[3] = (unsigned long long)it << 32 | (xcc & 0xFu) << 8 | (unsigned)xcd;
     }
 #endif
 }

@@ -54,7 +54,7 @@ struct slr_ctx {
     void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
     unsigned tile_nofit[2][2] = {};             // per camera: tiles that do not fit the 64x8 / the 128x8 fused-decode form
     void *d_dma_tiles[2] = {nullptr, nullptr};  // boxes + map digest of the LDS-DMA fused decode (launch_dma_tiles), or null
-    unsigned dma_nofit[2] = {0, 0};             // tiles whose box does not fit that form
+    unsigned dma_stats[2][kDmaTileStats] = {};  // launch_dma_tiles' statistics; [0] = tiles whose box does not fit that form
     int dma_shape_built[2] = {-1, -1};          // SLR_OPT_RECT_DMA_SHAPE the tables were built for
     DebugKnobs debug;              // SLR_OPT_DEBUG_*
     int opt_dma_shape = 3, opt_dma_depth = 2;   // SLR_OPT_RECT_DMA_SHAPE / _DEPTH (128x16 tiles on 512 threads, two phases of DMA in flight: measured best)
@@ -118,7 +118,7 @@ bool dma_form_wanted(const slr_ctx *c, int a, int b)
 {
     if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return false;
     for (int cam = a; cam <= b; cam++)
-        if (!c->d_dma_tiles[cam] || c->dma_nofit[cam] != 0 || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
+        if (!c->d_dma_tiles[cam] || c->dma_stats[cam][0] != 0 || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
     return true;
 }
 
@@ -595,7 +595,7 @@ static int build_dma_tiles(slr_ctx *c, int cam)
     if (W % 16 != 0) return SLR_OK;                         // the form needs whole 16-byte chunks per row
     if (!c->d_dma_tiles[cam]) SLR_HIP(c, hipMalloc(&c->d_dma_tiles[cam], dma_tiles_bytes(W, H, c->opt_dma_shape)));
     SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape,
-                                &c->dma_nofit[cam], c->stream));
+                                c->dma_stats[cam], c->stream));
     c->dma_shape_built[cam] = c->opt_dma_shape;
     return SLR_OK;
 }
@@ -624,6 +624,28 @@ int slr_init_rectify_maps(slr_ctx *c, int cam, const double M[9], const double D
     SLR_HIP(c, launch_tile_boxes(c->d_map_xy[cam], c->d_map_frac[cam], W, H, (int4 *)c->d_tile_box[cam], c->tile_nofit[cam], c->stream));
     SLR_TRY(build_dma_tiles(c, cam));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+int slr_get_rectify_info(slr_ctx *c, int cam, slr_rectify_info *out)
+{
+    if (!c || !out) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 (left) or 1 (right)");
+    if (!c->d_map_xy[cam]) return fail(c, SLR_ERR_NOT_CONFIGURED, "rectify maps not set (slr_set_rectify_maps)");
+    memset(out, 0, sizeof *out);
+    out->W = c->map_w; out->H = c->map_h;
+    const bool dma = dma_form_wanted(c, cam, cam);
+    out->mf_form = dma ? 7 : (c->opt_rect_algo != 0 && c->opt_rect_algo != 7 ? c->opt_rect_algo : mf_rect_algo(c, cam, cam));
+    out->dma_shape = c->opt_dma_shape; out->dma_depth = c->opt_dma_depth;
+    if (c->d_dma_tiles[cam] && c->dma_shape_built[cam] == c->opt_dma_shape) {
+        const unsigned *st = c->dma_stats[cam];
+        out->dma_tiles = (unsigned)dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape);
+        out->dma_nofit_tiles = st[0];
+        for (int k = 0; k < 3; k++) { out->quads_by_class[k] = st[1 + k]; out->waves_by_mode[k] = st[4 + k]; }
+    } else {
+        out->dma_nofit_tiles = 0xFFFFFFFFu;                 // no LDS-DMA tables for these maps (W % 16 != 0)
+    }
+    out->lds_nofit_tiles[0] = c->tile_nofit[cam][0]; out->lds_nofit_tiles[1] = c->tile_nofit[cam][1];
     return SLR_OK;
 }
 

@@ -205,6 +205,16 @@ static void undistort_corner(double u, double v, const Matd &A, const Matd &D, f
 
 void stereoRect::calParameters()
 {
+    calRectification();
+    if (Q.empty()) return;
+    initUndistortRectifyMap(M1, D1, R1, P1, w, h, map11, map12);
+    initUndistortRectifyMap(M2, D2, R2, P2, w, h, map21, map22);
+}
+
+// cv::stereoRectify(flags 0, alpha -1) alone: R1, R2, P1, P2, Q from M1, D1, M2, D2, R, T (the maps can then be built on the
+// device: uploadFromCalibration)
+void stereoRect::calRectification()
+{
     if (M1.empty() || M2.empty() || D1.empty() || D2.empty() || R.empty() || T.empty()) return;
     const int nx = w, ny = h;
     double om[3], r_r[9], t[3], uu[3] = {0, 0, 0}, ww[3], wR[9], Ri[9];
@@ -257,8 +267,6 @@ void stereoRect::calParameters()
     Q.at(0, 0) = 1; Q.at(0, 3) = -ccx[0]; Q.at(1, 1) = 1; Q.at(1, 3) = -ccy[0]; Q.at(2, 3) = fc_new;
     Q.at(3, 2) = -1. / t[idx];
     Q.at(3, 3) = (idx == 0 ? ccx[0] - ccx[1] : ccy[0] - ccy[1]) / t[idx];
-    initUndistortRectifyMap(M1, D1, R1, P1, w, h, map11, map12);
-    initUndistortRectifyMap(M2, D2, R2, P2, w, h, map21, map22);
 }
 
 void initUndistortRectifyMap(const Matd &M, const Matd &D, const Matd &R, const Matd &P, int W, int H,

@@ -82,6 +82,7 @@ public:
     stereoRect(const std::string &projectPath, int width, int height);
     void getParameters();                                    // 6 text files, parsed via float into f64 (stereorect.cpp:46-62)
     void calParameters();                                    // cv::stereoRectify(flags 0, alpha -1) + 2x initUndistortRectifyMap, restated
+    void calRectification();                                 // the stereoRectify half alone (R1, R2, P1, P2, Q)
     bool doStereoRectify(slr_ctx *ctx, Image8 &img, bool isleft);   // cv::remap on the GPU (slr_remap_u8)
     bool upload(slr_ctx *ctx);                               // slr_set_rectify_maps for both cameras
     bool uploadFromCalibration(slr_ctx *ctx);                // slr_init_rectify_maps: the maps are built on the device

@@ -191,6 +191,26 @@ int duke_stereo_rect(const char *project, int W, int H, double *R1, double *R2, 
     DUKE_GUARD_END(0, nullptr, 0)
 }
 
+// cv::stereoRectify(M1, D1, M2, D2, size, R, T, flags 0, alpha -1) from arrays (row-major f64: M 3x3, D 5, R 3x3, T 3):
+// R1, R2 (9), P1, P2 (12), Q (16) -- what stereoRect::calParameters computes before it builds the maps (bench.py builds the maps
+// of verged rigs on the device with slr_init_rectify_maps from these)
+int duke_stereo_rectify(const double *M1, const double *D1, const double *M2, const double *D2, const double *R, const double *T,
+                        int W, int H, double *R1, double *R2, double *P1, double *P2, double *Q)
+{
+    DUKE_GUARD_BEGIN
+    if (!M1 || !D1 || !M2 || !D2 || !R || !T || !R1 || !R2 || !P1 || !P2 || !Q || W <= 0 || H <= 0) return 0;
+    stereoRect sr("", W, H);
+    auto set = [](Matd &m, int rows, int cols, const double *src) { m.rows = rows; m.cols = cols; m.v.assign(src, src + (size_t)rows * cols); };
+    set(sr.M1, 3, 3, M1); set(sr.D1, 5, 1, D1); set(sr.M2, 3, 3, M2); set(sr.D2, 5, 1, D2); set(sr.R, 3, 3, R); set(sr.T, 3, 1, T);
+    sr.calRectification();
+    if (sr.Q.empty()) return 0;
+    memcpy(R1, sr.R1.v.data(), 72); memcpy(R2, sr.R2.v.data(), 72);
+    memcpy(P1, sr.P1.v.data(), 96); memcpy(P2, sr.P2.v.data(), 96);
+    memcpy(Q, sr.Q.v.data(), 128);
+    return 1;
+    DUKE_GUARD_END(0, nullptr, 0)
+}
+
 // png: 0 = PGM, 1 = PNG, 2 = Adam7-interlaced PNG (test input)
 int duke_imwrite(const char *path, const uint8_t *data, int w, int h, int png)
 {

@@ -342,7 +342,9 @@ def test_batch_entry_gray_only_two_frames_with_spare_planes(ctx, oracle, synth, 
     need = 2 + 2 * ncol + 2 * nrow
     stack = torch.full((2, 2, need + 2, H, W), 77, dtype=torch.uint8, device=dev)
     for f in range(2):
-        stack[f, :, :need] = synth.render_gray_stack(W, H, scan_w, scan_h, seed=60 + f, noise=2, device=dev, rows=True)
+        g = synth.render_gray_stack(W, H, scan_w, scan_h, seed=60 + f, noise=2, device=dev, rows=True)
+        stack[f, :, :need] = g if f == 0 else torch.flip(g, dims=[0])          # frame 1: the cameras swapped
+        del g
     torch.cuda.synchronize()
     xyz, cnt, _ = ctx.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=scan_w,
                                         scan_h=scan_h, rectify=False)
@@ -354,4 +356,4 @@ def test_batch_entry_gray_only_two_frames_with_spare_planes(ctx, oracle, synth, 
         exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
         assert bits_equal(np_of(cnt[f]), ecnt) and bits_equal(np_of(xyz[f]), exyz), f
         assert (ecnt > 0).mean() > 0.2
-    assert not torch.equal(cnt[0], cnt[1])
+    assert not torch.equal(xyz[0], xyz[1])                    # (the pair COUNTS are symmetric in the cameras, the points are not)
