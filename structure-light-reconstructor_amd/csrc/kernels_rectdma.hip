@@ -460,12 +460,62 @@ __device__ __forceinline__ void dma_differences(int mode, const DmaTap tap[PX], 
 // included the output stores let the wait pass with the DMA still pending -- found the hard way), so the stores of a tile
 // are issued at the start of the NEXT tile's phase 0, a whole phase before the following wait, and a wave that still has
 // one of them outstanding there merely waits a little longer.
+constexpr int kDmaDigestPhase = 3;    // the phase of a tile in which the NEXT tile's digest is fetched (the next tile is known from phase 2 on)
 template <int PX, int A, int PLANE_DMAS = 2>
 __device__ __host__ constexpr int dma_wait_count(int p)
 {
     int n = 0;
-    for (int j = 1; j < A; j++) { const int ph = ((p - A + j) % 7 + 7) % 7; n += PLANE_DMAS + (ph == 1 ? PX / 4 : 0); }
+    for (int j = 1; j < A; j++) { const int ph = ((p - A + j) % 7 + 7) % 7; n += PLANE_DMAS + (ph == kDmaDigestPhase ? PX / 4 : 0); }
     return n;
+}
+
+// ---- dynamic tile schedule -----------------------------------------------------------------------------------------------
+// Round 2 gave every workgroup a fixed, strided share of its XCD band's tiles.  The per-workgroup timeline (profiles/r03:
+// all 768 workgroups start within 1 us, the first finishes after 92 us, the median after 114, the last after 138) showed that
+// the kernel's duration was its SLOWEST workgroup's, a fifth above the mean: tiles differ in cost (read modes, borders) and the
+// three workgroups of a CU share its SIMDs.  Now a workgroup takes its first tile by its index and every further one from a
+// per-(camera, XCD band) ticket counter in global memory.  The ticket is drawn with a SCALAR-memory atomic (s_atomic_add ... glc,
+// returned through lgkmcnt): the vector-memory queue, whose counted waits track the LDS-DMA operations, never sees it.  Wave 0
+// draws the ticket of the next tile during phase 1 and publishes it through LDS; every wave picks it up behind the barrier of
+// phase 2; the next tile's digest and boxes are fetched from phase 3 / 7 - A on.  The counters return to zero in the launch
+// that used them: the last workgroup to leave (a second counter) clears them.
+// An XCD's pool is not one band of the image but kSubBands of them, dealt round-robin (band g belongs to XCD g % 8) and walked
+// in order: the bands at the top and the bottom of the frame are dearer (taller boxes, more three-row waves) than the ones in
+// the middle -- with one band per XCD the XCDs finished 112 .. 120 us after the start.  A pool still moves down the image
+// through rows that are adjacent in memory (a band is 1 / 32 of the frame), so what its L2 holds of the rows above stays useful.
+constexpr int kSubBands = 4;
+struct DmaPool {
+    int pb;                              // tiles per band
+    int per;                             // pool-local indices: kSubBands * pb
+    __device__ __host__ static DmaPool of(int T) { DmaPool p; p.pb = (T + 8 * kSubBands - 1) / (8 * kSubBands); p.per = kSubBands * p.pb; return p; }
+    // pool-local index l of XCD x -> tile (>= T: beyond the image, and so is every larger l)
+    __device__ int tile(int x, int l) const { const int k = l / pb; return (k * 8 + x) * pb + (l - k * pb); }
+};
+constexpr int kSchedStride = 16;                             // one counter per 64-byte line
+constexpr int kSchedDone = 2 * 8 * kSchedStride;             // sched[kSchedDone]: workgroups that have left the kernel
+constexpr size_t kSchedBytes = (size_t)(kSchedDone + kSchedStride) * sizeof(unsigned);
+size_t dma_sched_bytes() { return kSchedBytes; }
+
+// old value of *p, which is incremented by 1: scalar atomic, issued here and NOT waited for (dma_ticket_wait)
+__device__ __forceinline__ unsigned dma_ticket_issue(unsigned *p)
+{
+    unsigned v = 1u;
+    asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(v) : "s"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void dma_ticket_wait(unsigned &v)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) :: "memory");
+}
+// a workgroup leaves the kernel (one thread calls this): the last one zeroes the counters for the next launch
+__device__ __forceinline__ void dma_sched_leave(unsigned *sched)
+{
+    unsigned v = dma_ticket_issue(sched + kSchedDone);
+    dma_ticket_wait(v);
+    if (v + 1u == gridDim.x) {
+        for (int i = 0; i < 16; i++) __hip_atomic_store(sched + i * kSchedStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sched + kSchedDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 template <int TW, int TH, int NT, int A, bool HASVALID>
@@ -489,7 +539,8 @@ struct DmaDecode {
     static constexpr int TAP_WT = WT_OFF;
 #endif
     static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
-    static constexpr int LDS_BYTES = LUT_OFF + (kLutWords + 1) * 4;
+    static constexpr int TKT_OFF = LUT_OFF + (kLutWords + 1) * 4;        // the next tile's ticket (wave 0 -> everybody)
+    static constexpr int LDS_BYTES = TKT_OFF + 12;
     static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
     static constexpr int kSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
 
@@ -502,6 +553,16 @@ struct DmaDecode {
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_phase, rs_valid;
     unsigned pstride;
     int W, H, black_thr;
+    // schedule (see "dynamic tile schedule"): this workgroup's band and its ticket counter
+    unsigned *ctr;
+    const int4 *boxes;
+    int pitch, crow, ccol, xcd, T, first_ticket;
+    DmaPool pool;
+    bool chunk_live;                     // this thread owns a chunk of the plane images
+    bool wave0;
+    int nxt;                             // the tile after the current one (valid from phase 2 on)
+    bool has_next;
+    unsigned voff_next;
     // per-tile state
     DmaTap tap[PX];
     unsigned qbase[PX / 4];              // LDS address of the 8-byte window of each quad (read modes 0 and 1)
@@ -582,17 +643,41 @@ struct DmaDecode {
         return __builtin_fmaf(r, rc, q) * (255.0f / 16777216.0f);
     }
 
-    // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur / voff_next: this thread's chunk of the current / next
-    // tile's box.
-    template <int K0, int P>
-    __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    // this thread's chunk of tile t's source box: the buffer offset its DMAs fetch from (or the out-of-range offset: zeros)
+    __device__ __forceinline__ unsigned box_voff(int t) const
     {
+        // t is wave-uniform: an explicit SCALAR load (hipcc emits a vector load for boxes[t], and waiting for that would drain the
+        // vector-memory queue, i.e. the DMAs in flight)
+        i32x4 b;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b) : "s"(boxes + __builtin_amdgcn_readfirstlane(t)) : "memory");
+        const int gx = b.x + 16 * ccol, gy = b.y + crow;
+        const bool in = chunk_live && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
+    }
+
+    // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur: this thread's chunk of the current tile's box.
+    template <int K0, int P>
+    __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur)
+    {
+        static_assert(7 - A > 2 && kDmaDigestPhase > 2 && kDmaDigestPhase < 7, "the next tile is known from phase 2 on");
         if (plane_wave) wait_vm<dma_wait_count<PX, A, PLANE_DMAS>(P)>();
-        else if (P == 0) wait_vm<0>();   // (its share of the tile's digest, issued six phases ago)
+        else if (P == 0) wait_vm<0>();   // (its share of the tile's digest, issued four phases ago)
 #if !defined(SLR_DMA_ABL) || SLR_DMA_ABL != 3
         asm volatile("s_barrier" ::: "memory");
 #endif
-        if (P == 1) issue_digest(next_tile, has_next);
+        unsigned ticket = 0;
+        if (P == 1 && wave0) ticket = dma_ticket_issue(ctr);          // (scalar memory: invisible to the counted vmcnt waits)
+        if constexpr (P == 2) {                                       // the ticket wave 0 drew in phase 1 -> the next tile
+            unsigned tk;                                              // (explicit DS operations: a generic-pointer access would be a
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"  //  FLAT instruction and drain the vector-memory queue)
+                         : "=v"(tk) : "v"(lds0 + (unsigned)TKT_OFF) : "memory");
+            const int nl = first_ticket + (int)__builtin_amdgcn_readfirstlane(tk);
+            const int nt = pool.tile(xcd, nl);
+            has_next = nl < pool.per && nt < T;
+            nxt = has_next ? nt : 0;
+            voff_next = has_next ? box_voff(nxt) : kDmaInvalid;
+        }
+        if (P == kDmaDigestPhase) issue_digest((unsigned)nxt, has_next);
         issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? voff_next : voff_cur);
         if constexpr (P == 0) {
             if (out_pending) flush();
@@ -632,6 +717,11 @@ struct DmaDecode {
         dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (P == 1 && wave0) {                                        // the ticket has had the tap loop to arrive
+            dma_ticket_wait(ticket);
+            // every lane writes the same word; the barriers here are bare s_barrier, so the write must have landed before the next
+            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(lds0 + (unsigned)TKT_OFF), "v"(ticket) : "memory");
+        }
         if constexpr (P == 0) {
 #pragma unroll
             for (int q = 0; q < PX; q++) {                         // computeShadows :198-204
@@ -665,16 +755,16 @@ struct DmaDecode {
     }
 
     template <int K0>
-    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur)
     {
         const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
-        phase<K0, 0>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 1>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 2>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 3>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 4>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 5>(ty, tx, voff_cur, voff_next, next_tile, has_next);
-        phase<K0, 6>(ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K0, 0>(ty, tx, voff_cur);
+        phase<K0, 1>(ty, tx, voff_cur);
+        phase<K0, 2>(ty, tx, voff_cur);
+        phase<K0, 3>(ty, tx, voff_cur);
+        phase<K0, 4>(ty, tx, voff_cur);
+        phase<K0, 5>(ty, tx, voff_cur);
+        phase<K0, 6>(ty, tx, voff_cur);
     }
 };
 
@@ -693,7 +783,7 @@ constexpr int mf_dma_waves() { return dma_waves_per_simd<LDS_BYTES, NT>() > 6 ? 
 template <int TW, int TH, int NT, int A, bool HASVALID>
 __global__ __launch_bounds__(NT, (mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
 void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
-                               int tiles_x, int tiles_y)
+                               int tiles_x, int tiles_y, unsigned *__restrict__ sched)
 {
     typedef DmaDecode<TW, TH, NT, A, HASVALID> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
@@ -719,13 +809,20 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     if (!HASVALID && threadIdx.x == 0)                      // the undefined wrapped phase (n == d == 0: lutR -> S = 9, s = 0, sgn 0)
         reinterpret_cast<int *>(lut)[kLutP + (9 << 8)] = Dec::kSentinel;
     __syncthreads();
-    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
-    const bool second = blockIdx.x >= nblk;
-    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
-    const int ji = second ? 1 : 0;
-    const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
-    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
-    if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
+    // workgroup -> (XCD band, camera, index in the pool): the hardware deals workgroups round-robin to the XCDs, so bits 0-2 are the
+    // band; the cameras ALTERNATE over the workgroups of a band.  (Round 2 gave the first half of the grid to camera 0.  The
+    // workgroups of a persistent kernel keep the age they were launched with and the SIMDs favour older waves: the first third
+    // of the grid runs its tiles in ~6 us, the last third in ~8 us -- so camera 0's tiles were gone after 100 us and camera 1's
+    // after 130.  With the cameras interleaved and the tiles drawn by ticket, both pools are served by the same mix.)
+    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per camera (a multiple of 8)
+    const int xcd = (int)(blockIdx.x & 7u), nbx = (int)(nblk >> 3);
+    const int ji = (int)((blockIdx.x >> 3) % (unsigned)njobs), lb = (int)((blockIdx.x >> 3) / (unsigned)njobs);
+    const int T = tiles_x * tiles_y;
+    d.pool = DmaPool::of(T);
+    if (lb >= d.pool.per || d.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
+        if (threadIdx.x == 0) dma_sched_leave(sched);
+        return;
+    }
 
     d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
 #if defined(SLR_DMA_STATIC_PRIO)
@@ -741,28 +838,35 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         d.pslot_off = (Dec::SPLIT ? wv % wpp : wv) * 1024u;
         d.plane_wave = Dec::SPLIT ? wv < 2u * wpp : wv < wpp;
     }
-    d.pstride = jobs.j[ji].pstride;
     d.W = W; d.H = H; d.black_thr = black_thr;
-    d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
-    d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
-    d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, (int)((unsigned)W * (unsigned)H * 4u), 0x00020000);
-    d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, HASVALID ? (int)((unsigned)W * (unsigned)H) : 0, 0x00020000);
-    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
-
+    d.pitch = pitch;
     // this thread's chunk of a box: row crow, 16-byte column ccol
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
-    const int crow = chunk / Gm::CMAX, ccol = chunk - crow * Gm::CMAX;
-    auto box_voff = [&](const int4 b) -> unsigned {
-        const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = (Dec::SPLIT || chunk < Gm::NCH) && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
-    };
+    d.crow = chunk / Gm::CMAX; d.ccol = chunk - d.crow * Gm::CMAX;
+    d.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
+    d.xcd = xcd; d.T = T; d.first_ticket = nbx;
+    d.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
 
 #if defined(SLR_DMA_CLOCKPROBE)      // experiment: every workgroup's life on the 100 MHz constant clock (+ shader cycles) -> phase buffer of job 0
     const unsigned long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
-    int cur = xcd * per + lb;
-    unsigned voff_cur = box_voff(boxes[cur]);
+    // the schedule: the first tile by index, the others by ticket (tickets count from the band's nbx-th tile)
+    d.pstride = jobs.j[ji].pstride;
+    d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
+    d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
+    d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, (int)((unsigned)W * (unsigned)H * 4u), 0x00020000);
+    d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, HASVALID ? (int)((unsigned)W * (unsigned)H) : 0, 0x00020000);
+    d.boxes = jobs.j[ji].boxes;
+    d.ctr = sched + (ji * 8 + xcd) * kSchedStride;
+    d.nxt = 0; d.has_next = false; d.voff_next = kDmaInvalid;
+    int cur = d.pool.tile(xcd, lb);
+#if defined(SLR_DMA_CLOCKPROBE)
+    int it = 0;
+#define SLR_DMA_COUNT(x) ((x)++)
+#else
+#define SLR_DMA_COUNT(x) ((void)0)
+#endif
+    unsigned voff_cur = d.box_voff(cur);
     // prologue = what the last phases of a previous tile would have issued: digest, plane DMAs of phases 0 .. A-1
     d.out_pending = false;
     d.ok = 0;
@@ -770,18 +874,14 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
 #pragma unroll
     for (int a = 0; a < A; a++) d.issue_planes(a, a % Dec::D, voff_cur);
 
-    int it = 1;
     for (;;) {
         // the phase-0 buffer index advances by 7 mod D from tile to tile: D tiles per round of this loop
 #define SLR_DMA_TILE(K0)                                                                                       \
         {                                                                                                      \
-            const int nl = lb + it * nbx;                                                                      \
-            const bool has_next = nl < per && xcd * per + nl < T;                                              \
-            const int nxt = has_next ? xcd * per + nl : cur;                                                   \
-            const unsigned voff_next = has_next ? box_voff(boxes[nxt]) : kDmaInvalid;                          \
-            d.template tile<K0>(cur, tiles_x, voff_cur, voff_next, (unsigned)nxt, has_next);                   \
-            if (!has_next) break;                                                                              \
-            cur = nxt; voff_cur = voff_next; it++;                                                             \
+            d.template tile<K0>(cur, tiles_x, voff_cur);                                                       \
+            SLR_DMA_COUNT(it);                                                                                 \
+            if (!d.has_next) break;                                                                            \
+            cur = d.nxt; voff_cur = d.voff_next;                                                               \
         }
         SLR_DMA_TILE(0)
         SLR_DMA_TILE(7 % Dec::D)
@@ -789,14 +889,16 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         if constexpr (Dec::D >= 4) SLR_DMA_TILE(21 % Dec::D)
 #undef SLR_DMA_TILE
     }
+#undef SLR_DMA_COUNT
     d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
+    if (threadIdx.x == 0) dma_sched_leave(sched);
 #if defined(SLR_DMA_CLOCKPROBE)
     if (threadIdx.x == 0) {
         unsigned long long *o = reinterpret_cast<unsigned long long *>(jobs.j[0].phase) + 4 * blockIdx.x;
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        o[0] = probe_entry; o[1] = wall_clock64(); (void)probe_w0; o[2] = clock64() - probe_c0; o[3] = (unsigned long long)it << 32 | (xcc & 0xFu) << 8 | (unsigned)xcd;
+        o[0] = probe_entry; o[1] = wall_clock64(); (void)probe_w0; o[2] = clock64() - probe_c0; o[3] = (unsigned long long)it << 32 | (unsigned)ji << 16 | (xcc & 0xFu) << 8 | (unsigned)xcd;
     }
 #endif
 }
@@ -823,7 +925,8 @@ static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, u
 }
 
 template <int TW, int TH, int NT, int A, bool HV>
-static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, const float *lut, hipStream_t s)
+static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, const float *lut, unsigned *sched,
+                                     hipStream_t s)
 {
     typedef DmaDecode<TW, TH, NT, A, HV> Dec;
     auto kern = mf_rect_decode_dma_kernel<TW, TH, NT, A, HV>;
@@ -841,12 +944,12 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
         resident.put(dev, res);
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int T = tiles_x * tiles_y, per = (T + 7) / 8;
+    const int T = tiles_x * tiles_y, per = DmaPool::of(T).per;
     const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, lut,
-               tiles_x, tiles_y);
+               tiles_x, tiles_y, sched);
     return hipGetLastError();
 }
 
@@ -858,10 +961,10 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
 // (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
-                                     bool *done, hipStream_t s)
+                                     unsigned *sched, bool *done, hipStream_t s)
 {
     *done = false;
-    if (shape < 0 || shape >= kDmaShapes) return hipSuccess;
+    if (shape < 0 || shape >= kDmaShapes || !sched) return hipSuccess;
     DmaJobs j;
     for (int c = 0; c < n; c++)
         if (!dma_job(pl[c], pitch, W, H, phase[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
@@ -871,10 +974,10 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
     *done = true;
     hipError_t e = hipSuccess;
 #define SLR_DMA_X(TW, TH, NT)                                                                                          \
-    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true>(j, n, pitch, W, H, black_thr, lut, s)     \
-                         : launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), false>(j, n, pitch, W, H, black_thr, lut, s))   \
-                   : (hv ? launch_dma_variant<TW, TH, NT, 1, true>(j, n, pitch, W, H, black_thr, lut, s)              \
-                         : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, s))
+    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true>(j, n, pitch, W, H, black_thr, lut, sched, s)     \
+                         : launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), false>(j, n, pitch, W, H, black_thr, lut, sched, s))   \
+                   : (hv ? launch_dma_variant<TW, TH, NT, 1, true>(j, n, pitch, W, H, black_thr, lut, sched, s)              \
+                         : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, sched, s))
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
     return e;

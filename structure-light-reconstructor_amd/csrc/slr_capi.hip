@@ -49,6 +49,7 @@ struct slr_ctx {
     bool has_calib = false;
     DevCalib cal;
     float *d_lut = nullptr;
+    unsigned *d_sched = nullptr;                // tile tickets of the LDS-DMA fused decodes (zero between launches)
     int16_t *d_map_xy[2] = {nullptr, nullptr};
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
@@ -291,7 +292,7 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
         uint8_t *const vd[1] = {valid};
         const void *const tl[1] = {c->d_dma_tiles[cam]};
         SLR_HIP(c, launch_mf_rect_decode_dma(&mp, 1, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
-                                             &done, c->stream));
+                                             c->d_sched, &done, c->stream));
         if (done) return SLR_OK;
     }
     if (rectify && c->opt_rect_algo == 7)
@@ -478,6 +479,8 @@ int slr_create(int device_id, slr_ctx **out)
         }
         if (hipMalloc((void **)&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
         if (hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) { st = SLR_ERR_HIP; break; }
+        if (hipMalloc((void **)&c->d_sched, dma_sched_bytes()) != hipSuccess) { st = SLR_ERR_OOM; break; }
+        if (hipMemset(c->d_sched, 0, dma_sched_bytes()) != hipSuccess) { st = SLR_ERR_HIP; break; }
         if (hipEventCreate(&c->t0) != hipSuccess || hipEventCreate(&c->t1) != hipSuccess) { st = SLR_ERR_HIP; break; }
     } while (0);
     if (st != SLR_OK) { slr_destroy(c); return st; }
@@ -497,6 +500,7 @@ int slr_destroy(slr_ctx *c)
     for (int i = 0; i < S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); if (c->d_dma_tiles[k]) (void)hipFree(c->d_dma_tiles[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_sched) (void)hipFree(c->d_sched);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SLR_OK;
@@ -924,7 +928,7 @@ static int decode_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
         if (dma_form_wanted(c, 0, 1)) {
             const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
             SLR_HIP(c, launch_mf_rect_decode_dma(mp, 2, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
-                                                 &paired, c->stream));
+                                                 c->d_sched, &paired, c->stream));
         }
         if (!paired && c->opt_rect_algo != 7)
         SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, mf_rect_algo(c, 0, 1),

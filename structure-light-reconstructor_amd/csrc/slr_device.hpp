@@ -123,7 +123,9 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
                             unsigned *nofit_host, hipStream_t s);
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
+                                     unsigned *sched /* dma_sched_bytes() of zeros, owned by the context: the tile tickets */,
                                      bool *done, hipStream_t s);
+size_t     dma_sched_bytes();
 
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
