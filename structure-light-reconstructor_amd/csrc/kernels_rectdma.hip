@@ -518,6 +518,53 @@ __device__ __forceinline__ void dma_sched_leave(unsigned *sched)
     }
 }
 
+// the schedule state of a workgroup (both fused decodes): its pool, the tile after the current one, this thread's box chunk
+struct DmaSched {
+    unsigned *ctr;                       // the pool's ticket counter
+    const int4 *boxes;                   // the camera's box table
+    int pitch, W, H, crow, ccol, xcd, T, first_ticket;
+    unsigned tkt_lds;                    // LDS address of the ticket slot
+    DmaPool pool;
+    bool chunk_live;                     // this thread owns a chunk of the plane images
+    bool wave0;
+    int nxt;                             // the tile after the current one (valid once pick_up() ran in the current tile)
+    bool has_next;
+    unsigned voff_next;                  // this thread's chunk of that tile's box
+
+    // this thread's chunk of tile t's source box: the buffer offset its DMAs fetch from (or the out-of-range offset: zeros)
+    __device__ __forceinline__ unsigned box_voff(int t) const
+    {
+        // t is wave-uniform: an explicit SCALAR load (hipcc emits a vector load for boxes[t], and waiting for that would drain the
+        // vector-memory queue, i.e. the DMAs in flight)
+        i32x4 b;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b) : "s"(boxes + __builtin_amdgcn_readfirstlane(t)) : "memory");
+        const int gx = b.x + 16 * ccol, gy = b.y + crow;
+        const bool in = chunk_live && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
+    }
+    // wave 0, one phase before pick_up(): draw (before the phase's tap loop) and publish (behind it) the next tile's ticket
+    __device__ __forceinline__ unsigned draw() const { return wave0 ? dma_ticket_issue(ctr) : 0u; }
+    __device__ __forceinline__ void publish(unsigned ticket) const
+    {
+        if (!wave0) return;
+        dma_ticket_wait(ticket);
+        // every lane writes the same word; the barriers of these kernels are bare s_barrier, so the write must have landed before
+        // the next one (explicit DS operations: a generic-pointer access would be a FLAT instruction and drain the vector-memory queue)
+        asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(tkt_lds), "v"(ticket) : "memory");
+    }
+    // every wave, behind the barrier that follows publish(): the ticket -> the next tile
+    __device__ __forceinline__ void pick_up()
+    {
+        unsigned tk;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(tkt_lds) : "memory");
+        const int nl = first_ticket + (int)__builtin_amdgcn_readfirstlane(tk);
+        const int nt = pool.tile(xcd, nl);
+        has_next = nl < pool.per && nt < T;
+        nxt = has_next ? nt : 0;
+        voff_next = has_next ? box_voff(nxt) : kDmaInvalid;
+    }
+};
+
 template <int TW, int TH, int NT, int A, bool HASVALID>
 struct DmaDecode {
     typedef DmaGeom<TW, TH, NT> Gm;
@@ -553,16 +600,7 @@ struct DmaDecode {
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_phase, rs_valid;
     unsigned pstride;
     int W, H, black_thr;
-    // schedule (see "dynamic tile schedule"): this workgroup's band and its ticket counter
-    unsigned *ctr;
-    const int4 *boxes;
-    int pitch, crow, ccol, xcd, T, first_ticket;
-    DmaPool pool;
-    bool chunk_live;                     // this thread owns a chunk of the plane images
-    bool wave0;
-    int nxt;                             // the tile after the current one (valid from phase 2 on)
-    bool has_next;
-    unsigned voff_next;
+    DmaSched sc;                         // schedule (see "dynamic tile schedule")
     // per-tile state
     DmaTap tap[PX];
     unsigned qbase[PX / 4];              // LDS address of the 8-byte window of each quad (read modes 0 and 1)
@@ -643,18 +681,6 @@ struct DmaDecode {
         return __builtin_fmaf(r, rc, q) * (255.0f / 16777216.0f);
     }
 
-    // this thread's chunk of tile t's source box: the buffer offset its DMAs fetch from (or the out-of-range offset: zeros)
-    __device__ __forceinline__ unsigned box_voff(int t) const
-    {
-        // t is wave-uniform: an explicit SCALAR load (hipcc emits a vector load for boxes[t], and waiting for that would drain the
-        // vector-memory queue, i.e. the DMAs in flight)
-        i32x4 b;
-        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b) : "s"(boxes + __builtin_amdgcn_readfirstlane(t)) : "memory");
-        const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = chunk_live && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
-    }
-
     // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur: this thread's chunk of the current tile's box.
     template <int K0, int P>
     __device__ __forceinline__ void phase(int ty, int tx, unsigned voff_cur)
@@ -666,19 +692,10 @@ struct DmaDecode {
         asm volatile("s_barrier" ::: "memory");
 #endif
         unsigned ticket = 0;
-        if (P == 1 && wave0) ticket = dma_ticket_issue(ctr);          // (scalar memory: invisible to the counted vmcnt waits)
-        if constexpr (P == 2) {                                       // the ticket wave 0 drew in phase 1 -> the next tile
-            unsigned tk;                                              // (explicit DS operations: a generic-pointer access would be a
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"  //  FLAT instruction and drain the vector-memory queue)
-                         : "=v"(tk) : "v"(lds0 + (unsigned)TKT_OFF) : "memory");
-            const int nl = first_ticket + (int)__builtin_amdgcn_readfirstlane(tk);
-            const int nt = pool.tile(xcd, nl);
-            has_next = nl < pool.per && nt < T;
-            nxt = has_next ? nt : 0;
-            voff_next = has_next ? box_voff(nxt) : kDmaInvalid;
-        }
-        if (P == kDmaDigestPhase) issue_digest((unsigned)nxt, has_next);
-        issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? voff_next : voff_cur);
+        if (P == 1) ticket = sc.draw();                               // (scalar memory: invisible to the counted vmcnt waits)
+        if constexpr (P == 2) sc.pick_up();                           // the ticket wave 0 drew in phase 1 -> the next tile
+        if (P == kDmaDigestPhase) issue_digest((unsigned)sc.nxt, sc.has_next);
+        issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? sc.voff_next : voff_cur);
         if constexpr (P == 0) {
             if (out_pending) flush();
             // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
@@ -717,11 +734,7 @@ struct DmaDecode {
         dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if (P == 1 && wave0) {                                        // the ticket has had the tap loop to arrive
-            dma_ticket_wait(ticket);
-            // every lane writes the same word; the barriers here are bare s_barrier, so the write must have landed before the next
-            asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(lds0 + (unsigned)TKT_OFF), "v"(ticket) : "memory");
-        }
+        if (P == 1) sc.publish(ticket);                               // (the ticket has had the tap loop to arrive)
         if constexpr (P == 0) {
 #pragma unroll
             for (int q = 0; q < PX; q++) {                         // computeShadows :198-204
@@ -818,8 +831,8 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     const int xcd = (int)(blockIdx.x & 7u), nbx = (int)(nblk >> 3);
     const int ji = (int)((blockIdx.x >> 3) % (unsigned)njobs), lb = (int)((blockIdx.x >> 3) / (unsigned)njobs);
     const int T = tiles_x * tiles_y;
-    d.pool = DmaPool::of(T);
-    if (lb >= d.pool.per || d.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
+    d.sc.pool = DmaPool::of(T);
+    if (lb >= d.sc.pool.per || d.sc.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
         if (threadIdx.x == 0) dma_sched_leave(sched);
         return;
     }
@@ -839,13 +852,14 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         d.plane_wave = Dec::SPLIT ? wv < 2u * wpp : wv < wpp;
     }
     d.W = W; d.H = H; d.black_thr = black_thr;
-    d.pitch = pitch;
+    d.sc.pitch = pitch; d.sc.W = W; d.sc.H = H;
     // this thread's chunk of a box: row crow, 16-byte column ccol
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
-    d.crow = chunk / Gm::CMAX; d.ccol = chunk - d.crow * Gm::CMAX;
-    d.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
-    d.xcd = xcd; d.T = T; d.first_ticket = nbx;
-    d.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    d.sc.crow = chunk / Gm::CMAX; d.sc.ccol = chunk - d.sc.crow * Gm::CMAX;
+    d.sc.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
+    d.sc.xcd = xcd; d.sc.T = T; d.sc.first_ticket = nbx;
+    d.sc.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    d.sc.tkt_lds = d.lds0 + (unsigned)Dec::TKT_OFF;
 
 #if defined(SLR_DMA_CLOCKPROBE)      // experiment: every workgroup's life on the 100 MHz constant clock (+ shader cycles) -> phase buffer of job 0
     const unsigned long long probe_c0 = clock64(), probe_w0 = wall_clock64();
@@ -856,17 +870,17 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
     d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, (int)((unsigned)W * (unsigned)H * 4u), 0x00020000);
     d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, HASVALID ? (int)((unsigned)W * (unsigned)H) : 0, 0x00020000);
-    d.boxes = jobs.j[ji].boxes;
-    d.ctr = sched + (ji * 8 + xcd) * kSchedStride;
-    d.nxt = 0; d.has_next = false; d.voff_next = kDmaInvalid;
-    int cur = d.pool.tile(xcd, lb);
+    d.sc.boxes = jobs.j[ji].boxes;
+    d.sc.ctr = sched + (ji * 8 + xcd) * kSchedStride;
+    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid;
+    int cur = d.sc.pool.tile(xcd, lb);
 #if defined(SLR_DMA_CLOCKPROBE)
     int it = 0;
 #define SLR_DMA_COUNT(x) ((x)++)
 #else
 #define SLR_DMA_COUNT(x) ((void)0)
 #endif
-    unsigned voff_cur = d.box_voff(cur);
+    unsigned voff_cur = d.sc.box_voff(cur);
     // prologue = what the last phases of a previous tile would have issued: digest, plane DMAs of phases 0 .. A-1
     d.out_pending = false;
     d.ok = 0;
@@ -880,8 +894,8 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         {                                                                                                      \
             d.template tile<K0>(cur, tiles_x, voff_cur);                                                       \
             SLR_DMA_COUNT(it);                                                                                 \
-            if (!d.has_next) break;                                                                            \
-            cur = d.nxt; voff_cur = d.voff_next;                                                               \
+            if (!d.sc.has_next) break;                                                                         \
+            cur = d.sc.nxt; voff_cur = d.sc.voff_next;                                                         \
         }
         SLR_DMA_TILE(0)
         SLR_DMA_TILE(7 % Dec::D)
@@ -1025,10 +1039,12 @@ struct GrayDma {
     // dynamic LDS from address 0: 2 buffers of 2 * NPP plane images | digest of the tile | weight tables
     static constexpr int DIG_OFF = 4 * NPP * PS, DIG_BYTES = TW * TH * 4;     // (no scratch slot: waves without chunks issue no DMAs)
     static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4;
-    static constexpr int LDS_BYTES = WT_OFF + 2 * 1026 * 4;
+    static constexpr int TKT_OFF = WT_OFF + 2 * 1026 * 4;                   // the next tile's ticket (wave 0 -> everybody)
+    static constexpr int LDS_BYTES = TKT_OFF + 8;
     static_assert(WT_OFF <= 65536, "DMA destinations are 16-bit LDS addresses (M0)");
 
     const uint8_t *smem;
+    DmaSched sc;                                             // schedule (see "dynamic tile schedule")
     unsigned lds0, wave_off, pslot_off, plane_g;             // (pslot_off, plane_g: see DmaDecode)
     bool plane_wave, has_cy, has_valid;
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_cx, rs_cy, rs_valid;
@@ -1115,13 +1131,18 @@ struct GrayDma {
     // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
     // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
     template <int B, bool FIRST>
-    __device__ __forceinline__ void phase(int k, int ty, int tx, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    __device__ __forceinline__ void phase(int k, int ty, int tx, unsigned voff_cur)
     {
         if (plane_wave || FIRST) wait_vm<0>();              // (a wave without chunks only waits for its share of the digest)
         asm volatile("s_barrier" ::: "memory");
-        if (k == 1) issue_digest(next_tile, has_next);      // (every wave is past its digest reads of phase 0; nq >= 2)
+        // the schedule: wave 0 draws the next tile's ticket around the tap loop of phase 0, every wave picks it up here in phase 1
+        // (nq >= 2); the next tile's digest and its first planes are fetched in the tile's last phase
+        unsigned ticket = 0;
+        if constexpr (FIRST) ticket = sc.draw();
+        else if (k == 1) sc.pick_up();
         const bool last = k + 1 == nq;
-        issue_planes(last ? 0 : k + 1, B ^ 1, last ? voff_next : voff_cur);
+        if (last) issue_digest((unsigned)sc.nxt, sc.has_next);   // (every wave is past its digest reads of phase 0)
+        issue_planes(last ? 0 : k + 1, B ^ 1, last ? sc.voff_next : voff_cur);
         if constexpr (FIRST) {
             if (out_pending) flush();
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
@@ -1152,19 +1173,20 @@ struct GrayDma {
             }
         }
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (FIRST) sc.publish(ticket);             // (the ticket has had the tap loop to arrive)
         if (last) finish(ty, tx);
     }
     template <int K>
-    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur, unsigned voff_next, unsigned next_tile, bool has_next)
+    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur)
     {
         const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
-        phase<K, true>(0, ty, tx, voff_cur, voff_next, next_tile, has_next);
+        phase<K, true>(0, ty, tx, voff_cur);
         int k = 1;
         for (; k + 1 < nq; k += 2) {
-            phase<K ^ 1, false>(k, ty, tx, voff_cur, voff_next, next_tile, has_next);
-            phase<K, false>(k + 1, ty, tx, voff_cur, voff_next, next_tile, has_next);
+            phase<K ^ 1, false>(k, ty, tx, voff_cur);
+            phase<K, false>(k + 1, ty, tx, voff_cur);
         }
-        if (k < nq) phase<K ^ 1, false>(k, ty, tx, voff_cur, voff_next, next_tile, has_next);
+        if (k < nq) phase<K ^ 1, false>(k, ty, tx, voff_cur);
     }
 };
 
@@ -1178,7 +1200,7 @@ constexpr int gray_dma_waves()
 template <int TW, int TH, int NT, int NPP, bool ODD>
 __global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP>::LDS_BYTES, NT, NPP>()))
 void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
-                                 int scan_w, int scan_h, int tiles_x, int tiles_y)
+                                 int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched)
 {
     typedef GrayDma<TW, TH, NT, NPP> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
@@ -1194,13 +1216,16 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
         *reinterpret_cast<unsigned *>(smem + Dec::WT1_OFF + 4u * i) = w1;
     }
     __syncthreads();
-    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per job (a multiple of 8)
-    const bool second = blockIdx.x >= nblk;
-    const unsigned bid = second ? blockIdx.x - nblk : blockIdx.x;
-    const int ji = second ? 1 : 0;
-    const int T = tiles_x * tiles_y, per = (T + 7) >> 3;
-    const int xcd = (int)(bid & 7u), lb = (int)(bid >> 3), nbx = (int)(nblk >> 3);
-    if (lb >= per || xcd * per + lb >= T) return;           // (whole workgroup) nothing to do
+    // workgroup -> (XCD band set, camera, index in the pool): see mf_rect_decode_dma_kernel
+    const unsigned nblk = gridDim.x / (unsigned)njobs;      // workgroups per camera (a multiple of 8)
+    const int xcd = (int)(blockIdx.x & 7u), nbx = (int)(nblk >> 3);
+    const int ji = (int)((blockIdx.x >> 3) % (unsigned)njobs), lb = (int)((blockIdx.x >> 3) / (unsigned)njobs);
+    const int T = tiles_x * tiles_y;
+    d.sc.pool = DmaPool::of(T);
+    if (lb >= d.sc.pool.per || d.sc.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
+        if (threadIdx.x == 0) dma_sched_leave(sched);
+        return;
+    }
 
     d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
     {
@@ -1220,33 +1245,29 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     d.rs_cx = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_x, 0, n4, 0x00020000);
     d.rs_cy = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_y, 0, d.has_cy ? n4 : 0, 0x00020000);
     d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, d.has_valid ? n4 / 4 : 0, 0x00020000);
-    const int4 *__restrict__ boxes = jobs.j[ji].boxes;
-
+    d.sc.boxes = jobs.j[ji].boxes;
+    d.sc.pitch = pitch; d.sc.W = W; d.sc.H = H;
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
-    const int crow = chunk / Gm::CMAX, ccol = chunk - crow * Gm::CMAX;
-    auto box_voff = [&](const int4 b) -> unsigned {
-        const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = (Dec::SPLIT || chunk < Gm::NCH) && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-        return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
-    };
+    d.sc.crow = chunk / Gm::CMAX; d.sc.ccol = chunk - d.sc.crow * Gm::CMAX;
+    d.sc.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
+    d.sc.xcd = xcd; d.sc.T = T; d.sc.first_ticket = nbx;
+    d.sc.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    d.sc.tkt_lds = d.lds0 + (unsigned)Dec::TKT_OFF;
+    d.sc.ctr = sched + (ji * 8 + xcd) * kSchedStride;
+    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid;
 
-    int cur = xcd * per + lb;
-    unsigned voff_cur = box_voff(boxes[cur]);
+    int cur = d.sc.pool.tile(xcd, lb);
+    unsigned voff_cur = d.sc.box_voff(cur);
     d.out_pending = false;
     d.issue_digest((unsigned)cur, true);                    // prologue = what the last phase of a previous tile would have issued
     d.issue_planes(0, 0, voff_cur);
 
-    int it = 1;
     for (;;) {
 #define SLR_GDMA_TILE(K0)                                                                                      \
         {                                                                                                      \
-            const int nl = lb + it * nbx;                                                                      \
-            const bool has_next = nl < per && xcd * per + nl < T;                                              \
-            const int nxt = has_next ? xcd * per + nl : cur;                                                   \
-            const unsigned voff_next = has_next ? box_voff(boxes[nxt]) : kDmaInvalid;                          \
-            d.template tile<K0>(cur, tiles_x, voff_cur, voff_next, (unsigned)nxt, has_next);                   \
-            if (!has_next) break;                                                                              \
-            cur = nxt; voff_cur = voff_next; it++;                                                             \
+            d.template tile<K0>(cur, tiles_x, voff_cur);                                                       \
+            if (!d.sc.has_next) break;                                                                         \
+            cur = d.sc.nxt; voff_cur = d.sc.voff_next;                                                         \
         }
         SLR_GDMA_TILE(0)
         if constexpr (ODD) SLR_GDMA_TILE(1)
@@ -1254,6 +1275,7 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     }
     d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
+    if (threadIdx.x == 0) dma_sched_leave(sched);
 }
 
 static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, int32_t *cx, int32_t *cy, uint8_t *valid, const void *tiles,
@@ -1279,7 +1301,7 @@ static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, 
 
 template <int TW, int TH, int NT, int NPP, bool ODD>
 static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol,
-                                          int nrow, int scan_w, int scan_h, hipStream_t s)
+                                          int nrow, int scan_w, int scan_h, unsigned *sched, hipStream_t s)
 {
     typedef GrayDma<TW, TH, NT, NPP> Dec;
     auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD>;
@@ -1297,12 +1319,12 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
         resident.put(dev, res);
     }
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    const int T = tiles_x * tiles_y, per = (T + 7) / 8;
+    const int T = tiles_x * tiles_y, per = DmaPool::of(T).per;
     const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, white_thr,
-               ncol, nrow, scan_w, scan_h, tiles_x, tiles_y);
+               ncol, nrow, scan_w, scan_h, tiles_x, tiles_y, sched);
     return hipGetLastError();
 }
 
@@ -1310,9 +1332,11 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
 // layout, image width, a tile shape without a Gray instantiation), nothing was launched
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, bool *done, hipStream_t s)
+                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, bool *done,
+                                       hipStream_t s)
 {
     *done = false;
+    if (!sched) return hipSuccess;
     if (shape != 1 && shape != 3 && shape != 4 && shape != 5) return hipSuccess;      // the 4-pixels-per-thread shapes
     if (ncol + nrow < 2) return hipSuccess;                 // (a tile needs two phases: the next digest arrives during the second)
     const int np = 2 + 2 * ncol + 2 * nrow;
@@ -1325,8 +1349,8 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     const bool odd = ((((1 + ncol + nrow) + NPP - 1) / NPP) & 1) != 0;   // phases (of NPP plane pairs) per tile
     hipError_t e = hipSuccess;
 #define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
-    e = odd ? launch_gray_dma_variant<TW, TH, NT, NPP, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, s)    \
-            : launch_gray_dma_variant<TW, TH, NT, NPP, false>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, s)
+    e = odd ? launch_gray_dma_variant<TW, TH, NT, NPP, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)    \
+            : launch_gray_dma_variant<TW, TH, NT, NPP, false>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)
     switch (shape) {
     case 1:  SLR_GDMA_X(256, 8, 512); break;
     case 4:  SLR_GDMA_X(128, 8, 256); break;

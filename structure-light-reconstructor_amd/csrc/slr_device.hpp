@@ -129,7 +129,8 @@ size_t     dma_sched_bytes();
 
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, bool *done, hipStream_t s);
+                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, bool *done,
+                                       hipStream_t s);
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,
