@@ -112,6 +112,9 @@ def parse_args():
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
+    ap.add_argument("--map-sweep", type=int, default=1,
+                    help="also time the fused decode on the maps of three verged rigs (stereoRectify + initUndistortRectifyMap), outside "
+                         "the timed region: form selected, tiles that do not fit, read-mode histogram (realistic_maps)")
     ap.add_argument("--host-io", type=int, default=1,
                     help="also time the SLR_MEM_HOST entry point (PCIe-inclusive, reported beside the result, never `value`)")
     return ap.parse_args()
@@ -590,6 +593,50 @@ def main():
                            "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         ctx.profile_enable(False)
 
+    # the timed region runs on friendly maps (near-identity: ~0.2 deg of roll, k1 = -0.08); what the fused decode does on the maps
+    # of VERGED rigs -- built by the repo's own stereoRectify + slr_init_rectify_maps -- is measured here, outside the timed region:
+    # which form `auto` picks for them, how many tiles do not fit it, the quad / wave read-mode histogram, and the kernel's time
+    maps_info, realistic = None, []
+    if rank == 0 and rectify and mode == "mf":
+        try:
+            maps_info = [ctx.rectify_info(cam) for cam in range(2)]
+        except Exception as e:
+            maps_info = {"error": repr(e)}
+    if rank == 0 and args.profile and rectify and mode == "mf" and args.map_sweep and not args.pmc_child:
+        for theta, k1 in ((0.1, -0.10), (0.2, -0.15), (0.3, -0.20)):
+            ent = {"rig": "verged, theta %.1f rad, k1 %.2f" % (theta, k1)}
+            try:
+                rig = synth.make_verged_rig(W, H, theta, k1)
+                synth.install_verged_maps(ctx, rig, W, H)
+                info = [ctx.rectify_info(cam) for cam in range(2)]
+                # stream-event time of F back-to-back calls (the LDS-DMA form's fix-up launches for tiles that do not fit it are
+                # part of a call; the per-kernel profiler would only see the main kernel)
+                ph_sw = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+                for f in range(2):
+                    ctx.mf_rectify_decode_pair(stack[f % F, 0], stack[f % F, 1], BLACK_THR, W=W, want_valid=False, phase=ph_sw)
+                ctx.synchronize()
+                ctx.timer_begin()
+                for f in range(F):
+                    ctx.mf_rectify_decode_pair(stack[f, 0], stack[f, 1], BLACK_THR, W=W, want_valid=False, phase=ph_sw)
+                per_frame_us = ctx.timer_end() / F * 1e3
+                name = "_pair"
+                gbs = ALG_BYTES["slr_mf_rectify_decode_pair"] * npix / (per_frame_us * 1e-6) / 1e9
+                ent.update({"form_selected": [i["mf_form"] for i in info], "nofit_tiles": [i["dma_nofit_tiles"] for i in info],
+                            "dma_tiles": info[0]["dma_tiles"], "quads_by_class": [i["quads_by_class"] for i in info],
+                            "waves_by_mode": [i["waves_by_mode"] for i in info], "lds_nofit_tiles": [i["lds_nofit_tiles"] for i in info],
+                            "decode_us_per_frame": round(per_frame_us, 1),
+                            "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+            except Exception as e:                          # never break the bench line
+                ent["error"] = repr(e)
+            realistic.append(ent)
+        for cam in range(2):                                 # back to the maps of the timed region
+            ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+
+    if roofline and isinstance(maps_info, list):
+        roofline["form_selected"] = [i["mf_form"] for i in maps_info]
+        roofline["nofit_tiles"] = [i["dma_nofit_tiles"] for i in maps_info]
+        roofline["quads_by_class"] = [i["quads_by_class"] for i in maps_info]
+        roofline["waves_by_mode"] = [i["waves_by_mode"] for i in maps_info]
     ceiling = hostio = None
     if rank == 0:
         ceiling = copy_ceiling(torch, dev, compute)
@@ -617,6 +664,8 @@ def main():
                                     "gray": "%dx%d stereo, GRAY_ONLY (Gray-code columns+rows, 44 planes/camera, 1280x1024 projector): "
                                             "decode+bucket scatter+ray-ray triangulation"}[mode] % (W, H)
                                    + "; a step = %d distinct HBM-resident frames per GPU" % F,
+                       "maps": ("synthetic near-identity rectification maps (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / -0.06); "
+                                "verged rigs: see realistic_maps") if rectify else None,
                        "mode": mode, "frames_per_gpu_per_step": F, "rectify": rectify, "streams_per_gpu": S,
                        "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
@@ -638,6 +687,7 @@ def main():
                                        "unit": "GB/s", "frac": e["frac_hbm_peak"], "avg_launch_us": e["avg_us"],
                                        "alg_bytes_per_launch": e["alg_bytes_per_px"] * npix, "target_frac": 0.60}
                                       for e in extras if e["name"] == "slr_mf_decode"), None),
+            "maps_of_the_timed_region": maps_info, "realistic_maps": realistic,
             "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
             "host_buffers_pcie_inclusive": hostio,
         }

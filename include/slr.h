@@ -106,7 +106,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
  *   6 = 64x8 tiles, 256 threads, one round, pre-digested 4-byte map entries
  *   7 = LDS-DMA form (round 2): 256- or 128-pixel-wide tiles (SLR_OPT_RECT_DMA_SHAPE) decoded in 7 phases of two
  *       planes whose source boxes go HBM -> LDS by buffer_load ... lds into a double / triple buffer.  Needs the 14 planes
- *       of a camera equally spaced in one allocation, 16-byte aligned rows, W % 16 == 0 and maps whose tile boxes fit;
+ *       of a camera equally spaced in one allocation, 16-byte aligned rows, W % 16 == 0 and maps at least three quarters
+ *       of whose tile boxes fit (the other tiles are rewritten by a gather pass behind the main kernel);
  *       auto falls back to 5 / 6 otherwise (also per call); an explicit 7 makes such calls fail with SLR_ERR_UNSUPPORTED.
  * The Gray fused decode only distinguishes 1 (gather), 2 (64x4 tiles) and everything else (64x8 tiles when they fit). */
 #define SLR_OPT_RECT_DECODE_ALGO 3
@@ -153,7 +154,8 @@ int slr_init_rectify_maps(slr_ctx *ctx, int cam, const double M[9], const double
  *   mf_form          the SLR_OPT_RECT_DECODE_ALGO value the multi-frequency decode resolves to for these maps under the current
  *                    options (7 = LDS-DMA form; 5 / 6 = round-1 LDS tiles, which fall back per tile to a gather)
  *   dma_tiles / dma_nofit_tiles   tiles of the LDS-DMA form's shape, and how many of them have a source box larger than the
- *                    form holds (any -> auto does not use form 7 for these maps); 0xFFFFFFFF: no tables (W % 16 != 0)
+ *                    form holds: those are rewritten by a gather pass behind the main kernel; beyond a quarter of the tiles auto
+ *                    does not use form 7 for these maps; 0xFFFFFFFF: no tables (W % 16 != 0)
  *   quads_by_class   4-pixel quads whose taps fit one 8-byte window of 2 source rows / of 3 rows / neither (fitting tiles)
  *   waves_by_mode    (tile, wave) pairs decoded in the two-row / three-row / per-pixel read mode (the three-row mode costs
  *                    ~27 % more instructions, the per-pixel one ~4x the LDS reads)

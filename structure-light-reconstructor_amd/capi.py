@@ -326,7 +326,7 @@ class Context:
         self._chk(st)
         return phase, valid
 
-    def mf_rectify_decode_pair(self, planesL, planesR, black_thr, W=None, want_valid=True):
+    def mf_rectify_decode_pair(self, planesL, planesR, black_thr, W=None, want_valid=True, phase=None):
         """slr_mf_rectify_decode_pair: both cameras of a frame (ONE launch when the LDS-tiled fused forms apply).
         want_valid=False: no valid arrays, invalid pixels carry a NaN phase (what the whole-path entries run)."""
         pl, n, H, pitch = _plane_ptrs(planesL)
@@ -335,7 +335,7 @@ class Context:
         W = pitch if W is None else W
         mem = self._mem(_flat(planesL) + _flat(planesR))
         like = _flat(planesL)[0]
-        ph = [self._new(mem, (H, W), np.float32, like) for _ in range(2)]
+        ph = [self._new(mem, (H, W), np.float32, like) for _ in range(2)] if phase is None else phase
         vd = [self._new(mem, (H, W), np.uint8, like) if want_valid else None for _ in range(2)]
         self._chk(self.lib.slr_mf_rectify_decode_pair(self.h, pl, pr, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr),
                                                       _ptr(ph[0]), _ptr(vd[0]), _ptr(ph[1]), _ptr(vd[1]), C.c_int(mem)))

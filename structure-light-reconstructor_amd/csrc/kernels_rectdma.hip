@@ -90,7 +90,8 @@ constexpr unsigned kDmaZeroEntry = 1024u << 18;
 template <int TW, int TH, int NT>
 __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
                                                        int W, int H, int tiles_x, int4 *__restrict__ boxes,
-                                                       unsigned *__restrict__ digest, unsigned *__restrict__ nofit)
+                                                       unsigned *__restrict__ digest, unsigned *__restrict__ nofit,
+                                                       unsigned *__restrict__ nofit_list)
 {
     typedef DmaGeom<TW, TH, NT> Gm;
     __shared__ int red[Gm::NWAVES][4];
@@ -138,7 +139,10 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             b.z = (((mxx + 1) - b.x) >> 4) + 1;              // chunks covering x0 .. mxx+1
             b.w = (mxy + 1) - mny + 1;                       // rows y0 .. mxy+1
             fits = b.z <= Gm::CMAX && b.w <= Gm::BHMAX;
-            if (!fits) atomicAdd(nofit, 1u);
+            if (!fits) {                                     // decoded by the fix-up pass (mf_rect_fixup_kernel): nothing to fetch here
+                nofit_list[atomicAdd(nofit, 1u)] = blockIdx.x;
+                b.z = 0; b.w = 0;
+            }
         }
         boxes[blockIdx.x] = b;
         sbox[0] = b.x; sbox[1] = b.y; sbox[2] = fits;
@@ -209,7 +213,8 @@ static size_t dma_nofit_offset(int W, int H, int shape)
 {
     return dma_digest_offset(W, H, shape) + dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
 }
-size_t dma_tiles_bytes(int W, int H, int shape) { return dma_nofit_offset(W, H, shape) + 256; }
+static size_t dma_list_offset(int W, int H, int shape) { return dma_nofit_offset(W, H, shape) + 256; }     // tiles that do not fit
+size_t dma_tiles_bytes(int W, int H, int shape) { return dma_list_offset(W, H, shape) + dma_tile_count(W, H, shape) * sizeof(unsigned); }
 size_t dma_tile_count_of(int W, int H, int shape) { return dma_tile_count(W, H, shape); }
 
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
@@ -219,11 +224,12 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
     int4 *boxes = reinterpret_cast<int4 *>(b);
     unsigned *digest = reinterpret_cast<unsigned *>(b + dma_digest_offset(W, H, shape));
     unsigned *nofit = reinterpret_cast<unsigned *>(b + dma_nofit_offset(W, H, shape));
+    unsigned *nofit_list = reinterpret_cast<unsigned *>(b + dma_list_offset(W, H, shape));
     hipError_t e = hipMemsetAsync(nofit, 0, kDmaTileStats * sizeof(unsigned), s);
     if (e != hipSuccess) return e;
     const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
     const dim3 grid((unsigned)dma_tile_count(W, H, shape));
-#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit)
+#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit, nofit_list)
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
     e = hipGetLastError();
@@ -917,6 +923,84 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fix-up pass.  A tile whose source box is larger than the form's LDS image (strong keystone in the image corners: the
+// maps of a verged rig tilt the rows there) used to send the WHOLE frame back to round 1's forms -- 1.6 % of the tiles of a
+// rig verged by 0.2 rad cost 215 instead of ~140 us.  Now the tile tables list those tiles, the LDS-DMA kernel fetches nothing
+// for them (and writes junk), and these kernels rewrite them behind it on the same stream: one workgroup per listed tile,
+// every pixel gathered straight from global memory (same make_tap / sample / decode as the direct-gather form).
+// ------------------------------------------------------------------------------------------------------
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void mf_rect_fixup_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
+                                                            const float *__restrict__ lut_g, const int16_t *__restrict__ map_xy,
+                                                            const uint16_t *__restrict__ map_frac, const unsigned *__restrict__ list,
+                                                            unsigned n, int tiles_x, float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    __shared__ float lut[kLutWords + 1];
+    load_lut(lut, lut_g);
+    // one pixel per thread, TW * TH / 256 workgroups per listed tile: a tile's pixels are gathered side by side, not one after the
+    // other (one workgroup per tile took longer than the whole main kernel: every pixel is 56 dependent-latency byte loads)
+    constexpr unsigned kParts = TW * TH / 256;
+    for (unsigned i = blockIdx.x; i < n * kParts; i += gridDim.x) {
+        const int t = (int)list[i / kParts], ty = t / tiles_x, tx = t - ty * tiles_x;
+        {
+            const int p = (int)((i % kParts) * 256u + threadIdx.x);
+            const int row = ty * TH + p / TW, col = tx * TW + p % TW;
+            if (row >= H || col >= W) continue;
+            const size_t m = (size_t)row * W + col;
+            const Tap tap = make_tap(map_xy[2 * m], map_xy[2 * m + 1], map_frac[m], pitch, W, H);
+            int g[SLR_MF_PLANES];
+#pragma unroll
+            for (int k = 0; k < SLR_MF_PLANES; k++) g[k] = sample(pl.p[k], pitch, W, H, tap);
+            int v;
+            const float ph = mf_pixel(g, black_thr, lut, v);
+            phase[m] = valid || v ? ph : kInvalidPhase;
+            if (valid) valid[m] = (uint8_t)v;
+        }
+    }
+}
+
+template <int TW, int TH>
+__global__ __launch_bounds__(256) void gray_rect_fixup_kernel(GrayPlanes pl, int ncol, int nrow, int pitch, int W, int H, int black_thr,
+                                                              int white_thr, int scan_w, int scan_h, const int16_t *__restrict__ map_xy,
+                                                              const uint16_t *__restrict__ map_frac, const unsigned *__restrict__ list,
+                                                              unsigned n, int tiles_x, int32_t *__restrict__ code_x,
+                                                              int32_t *__restrict__ code_y, uint8_t *__restrict__ valid)
+{
+    constexpr unsigned kParts = TW * TH / 256;              // (see mf_rect_fixup_kernel)
+    for (unsigned i = blockIdx.x; i < n * kParts; i += gridDim.x) {
+        const int t = (int)list[i / kParts], ty = t / tiles_x, tx = t - ty * tiles_x;
+        {
+            const int p = (int)((i % kParts) * 256u + threadIdx.x);
+            const int row = ty * TH + p / TW, col = tx * TW + p % TW;
+            if (row >= H || col >= W) continue;
+            const size_t m = (size_t)row * W + col;
+            const Tap tap = make_tap(map_xy[2 * m], map_xy[2 * m + 1], map_frac[m], pitch, W, H);
+            const int mask = sample(pl.p[0], pitch, W, H, tap) - sample(pl.p[1], pitch, W, H, tap) > black_thr ? 1 : 0;   // reconstruct.cpp:218-224
+            int gx = 0, gy = 0, err = 0;
+            for (int c = 0; c < ncol + nrow; c++) {                          // reconstruct.cpp:387-400 / 349-360
+                const int df = sample(pl.p[2 * c + 2], pitch, W, H, tap) - sample(pl.p[2 * c + 3], pitch, W, H, tap);
+                err |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                if (c < ncol) gx = (gx << 1) | (df > 0 ? 1 : 0);
+                else gy = (gy << 1) | (df > 0 ? 1 : 0);
+            }
+            gx ^= gx >> 1; gx ^= gx >> 2; gx ^= gx >> 4; gx ^= gx >> 8;     // grayToDec (graycodes.cpp:116-128)
+            gy ^= gy >> 1; gy ^= gy >> 2; gy ^= gy >> 4; gy ^= gy >> 8;
+            if (nrow > 0) err |= (gy > scan_h || gx > scan_w) ? 1 : 0;       // reconstruct.cpp:364 (Q9 '>')
+            else err |= (gx > scan_w) ? 1 : 0;                               // reconstruct.cpp:403
+            const int ok = mask & (err ^ 1);
+            code_x[m] = ok ? gx : -1;
+            if (code_y) code_y[m] = (ok && nrow > 0) ? gy : -1;
+            if (valid) valid[m] = (uint8_t)ok;
+        }
+    }
+}
+
+static const unsigned *dma_nofit_list(const void *tiles, int W, int H, int shape)
+{
+    return reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(tiles) + dma_list_offset(W, H, shape));
+}
+
 // the stack layout this form needs: 14 planes equally spaced in one allocation (buffer addressing: plane = scalar offset),
 // 16-byte aligned rows, W a multiple of 16 (a chunk is completely inside or completely outside the image)
 static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, uint8_t *valid, const void *tiles, int shape, DmaJob &j)
@@ -975,10 +1059,12 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
 // (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
-                                     unsigned *sched, bool *done, hipStream_t s)
+                                     unsigned *sched, const DmaFixup *fix, bool *done, hipStream_t s)
 {
     *done = false;
     if (shape < 0 || shape >= kDmaShapes || !sched) return hipSuccess;
+    for (int c = 0; c < n; c++)
+        if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
     DmaJobs j;
     for (int c = 0; c < n; c++)
         if (!dma_job(pl[c], pitch, W, H, phase[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
@@ -994,6 +1080,18 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
                          : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, sched, s))
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
+    // the tiles this form does not hold (none for mild maps): rewritten behind the main kernel
+    for (int c = 0; c < n && e == hipSuccess; c++) {
+        if (!fix || fix->nofit[c] == 0) continue;
+        const unsigned cnt = fix->nofit[c];
+        const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
+#define SLR_DMA_X(TW, TH, NT)                                                                                          \
+        hipLaunchKernelGGL((mf_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], pitch, W, H, black_thr, \
+                           lut, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], valid[c])
+        SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
+#undef SLR_DMA_X
+        e = hipGetLastError();
+    }
     return e;
 }
 
@@ -1332,11 +1430,13 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
 // layout, image width, a tile shape without a Gray instantiation), nothing was launched
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, bool *done,
-                                       hipStream_t s)
+                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
+                                       bool *done, hipStream_t s)
 {
     *done = false;
     if (!sched) return hipSuccess;
+    for (int c = 0; c < n; c++)
+        if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
     if (shape != 1 && shape != 3 && shape != 4 && shape != 5) return hipSuccess;      // the 4-pixels-per-thread shapes
     if (ncol + nrow < 2) return hipSuccess;                 // (a tile needs two phases: the next digest arrives during the second)
     const int np = 2 + 2 * ncol + 2 * nrow;
@@ -1358,6 +1458,23 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     default: SLR_GDMA_X(128, 16, 512); break;
     }
 #undef SLR_GDMA_X
+    for (int c = 0; c < n && e == hipSuccess; c++) {        // the tiles this form does not hold: rewritten behind the main kernel
+        if (!fix || fix->nofit[c] == 0) continue;
+        const unsigned cnt = fix->nofit[c];
+        const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
+#define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
+        hipLaunchKernelGGL((gray_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], ncol, nrow, pitch, W, H, \
+                           black_thr, white_thr, scan_w, scan_h, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), \
+                           cnt, tiles_x, code_x[c], code_y[c], valid[c])
+        switch (shape) {
+        case 1:  SLR_GDMA_X(256, 8, 512); break;
+        case 4:  SLR_GDMA_X(128, 8, 256); break;
+        case 5:  SLR_GDMA_X(256, 4, 256); break;
+        default: SLR_GDMA_X(128, 16, 512); break;
+        }
+#undef SLR_GDMA_X
+        e = hipGetLastError();
+    }
     return e;
 }
 

@@ -114,13 +114,28 @@ int mf_rect_algo(const slr_ctx *c, int a, int b)
         if (s__ != SLR_OK) return s__; \
     } while (0)
 
-// the LDS-DMA form (7) is used when it is asked for or auto is on, and the installed maps fit it
+// the LDS-DMA form (7) is used when it is asked for or auto is on, and the installed maps suit it: tables built for the
+// current tile shape, and at most a quarter of the tiles with a source box the form does not hold (those are rewritten by its
+// gather fix-up pass; beyond that round 1's forms, which gather per tile inside the kernel, are the better choice)
 bool dma_form_wanted(const slr_ctx *c, int a, int b)
 {
     if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return false;
-    for (int cam = a; cam <= b; cam++)
-        if (!c->d_dma_tiles[cam] || c->dma_stats[cam][0] != 0 || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
+    for (int cam = a; cam <= b; cam++) {
+        if (!c->d_dma_tiles[cam] || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
+        if (4ull * c->dma_stats[cam][0] > dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape)) return false;
+    }
     return true;
+}
+
+// what the fix-up pass of the LDS-DMA form needs for cameras a (and b): the original maps and the number of listed tiles
+DmaFixup dma_fixup_of(const slr_ctx *c, int a, int b)
+{
+    DmaFixup f;
+    const int cams[2] = {a, b};
+    for (int k = 0; k < 2; k++) {
+        f.map_xy[k] = c->d_map_xy[cams[k]]; f.map_frac[k] = c->d_map_frac[cams[k]]; f.nofit[k] = c->dma_stats[cams[k]][0];
+    }
+    return f;
 }
 
 int use_device(slr_ctx *c)
@@ -291,8 +306,9 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
         float *const ph[1] = {phase};
         uint8_t *const vd[1] = {valid};
         const void *const tl[1] = {c->d_dma_tiles[cam]};
+        const DmaFixup fix = dma_fixup_of(c, cam, cam);
         SLR_HIP(c, launch_mf_rect_decode_dma(&mp, 1, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
-                                             c->d_sched, &done, c->stream));
+                                             c->d_sched, &fix, &done, c->stream));
         if (done) return SLR_OK;
     }
     if (rectify && c->opt_rect_algo == 7)
@@ -343,8 +359,9 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
         int32_t *const xs[1] = {cx}, *const ys[1] = {cy};
         uint8_t *const vd[1] = {valid};
         const void *const tl[1] = {c->d_dma_tiles[cam]};
+        const DmaFixup fix = dma_fixup_of(c, cam, cam);
         SLR_HIP(c, launch_gray_rect_decode_dma(&gp, 1, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, xs, ys, vd, tl,
-                                               c->opt_dma_shape, c->d_sched, &done, c->stream));
+                                               c->opt_dma_shape, c->d_sched, &fix, &done, c->stream));
         if (done) return SLR_OK;
     }
     if (rectify && c->opt_rect_algo == 7)
@@ -927,8 +944,9 @@ static int decode_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
         ProfScope ps(c, K_MF_RECT_DECODE_PAIR, true);
         if (dma_form_wanted(c, 0, 1)) {
             const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
+            const DmaFixup fix = dma_fixup_of(c, 0, 1);
             SLR_HIP(c, launch_mf_rect_decode_dma(mp, 2, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
-                                                 c->d_sched, &paired, c->stream));
+                                                 c->d_sched, &fix, &paired, c->stream));
         }
         if (!paired && c->opt_rect_algo != 7)
         SLR_HIP(c, launch_mf_rect_decode_pair(mp, pitch, W, H, black_thr, c->d_lut, ph, vd, mxy, mfr, box, mf_rect_algo(c, 0, 1),
@@ -1091,8 +1109,9 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
         uint8_t *const vd[2] = {(uint8_t *)vl, (uint8_t *)vr};
         const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
         ProfScope ps(c, K_GRAY_RECT_DECODE_PAIR, true);
+        const DmaFixup fix = dma_fixup_of(c, 0, 1);
         SLR_HIP(c, launch_gray_rect_decode_dma(gp, 2, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, xs, ys, vd, tl,
-                                               c->opt_dma_shape, c->d_sched, &paired, c->stream));
+                                               c->opt_dma_shape, c->d_sched, &fix, &paired, c->stream));
     }
     if (!paired) {
         SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,

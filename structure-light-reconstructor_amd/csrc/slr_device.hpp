@@ -121,16 +121,23 @@ size_t     dma_tiles_bytes(int W, int H, int shape);
 size_t     dma_tile_count_of(int W, int H, int shape);
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
                             unsigned *nofit_host, hipStream_t s);
+// the tiles whose source box does not fit the form (launch_dma_tiles counted and listed them) are rewritten by a gather pass
+// behind the main kernel: it needs the camera's original maps and the count
+struct DmaFixup {
+    const int16_t *map_xy[2];
+    const uint16_t *map_frac[2];
+    unsigned nofit[2];
+};
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
                                      unsigned *sched /* dma_sched_bytes() of zeros, owned by the context: the tile tickets */,
-                                     bool *done, hipStream_t s);
+                                     const DmaFixup *fix, bool *done, hipStream_t s);
 size_t     dma_sched_bytes();
 
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, bool *done,
-                                       hipStream_t s);
+                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
+                                       bool *done, hipStream_t s);
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,

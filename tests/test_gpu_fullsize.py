@@ -357,3 +357,45 @@ def test_batch_entry_gray_only_two_frames_with_spare_planes(ctx, oracle, synth, 
         assert bits_equal(np_of(cnt[f]), ecnt) and bits_equal(np_of(xyz[f]), exyz), f
         assert (ecnt > 0).mean() > 0.2
     assert not torch.equal(xyz[0], xyz[1])                    # (the pair COUNTS are symmetric in the cameras, the points are not)
+
+
+@pytest.mark.parametrize("theta,k1", [(0.2, -0.15), (0.3, -0.2)])
+def test_fullsize_verged_rig_maps_from_stereo_rectify(ctx, oracle, synth, scene, theta, k1):
+    """Maps of a VERGED rig (keystone: rows tilt towards the image sides) built the way the reference builds them -- the host
+    mirror's stereoRectify, then initUndistortRectifyMap on the device (stereorect.cpp:36-44) -- instead of the near-identity maps
+    of the other tests: the device maps equal the oracle's map builder, and the fused pair decode (whatever form auto selects
+    for these maps: the LDS-DMA form when every tile box fits, else round 1's forms with their per-tile gather) equals
+    remap -> decode of the oracle for both cameras."""
+    st, _, _, _ = scene
+    rig = synth.make_verged_rig(W, H, theta, k1)
+    synth.install_verged_maps(ctx, rig, W, H)
+    info = [ctx.rectify_info(cam) for cam in range(2)]
+    print("verged rig theta %.1f k1 %.2f:" % (theta, k1), info)
+    ph, vd = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=True)
+    ctx.synchronize()
+    for cam in range(2):
+        mx, mf = ctx.get_rectify_maps(cam, W, H)
+        R, P = (rig["R1"], rig["P1"]) if cam == 0 else (rig["R2"], rig["P2"])
+        ex, ef = oracle.init_undistort_rectify_map(rig["M"][cam], rig["D"][cam], R, P, W, H)
+        assert np.array_equal(mx, ex) and np.array_equal(mf, ef), cam
+        raw = st[cam].cpu().numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
+        eph, ev = oracle.mf_decode(rect, BLACK)
+        assert bits_equal(np_of(vd[cam]), ev) and bits_equal(np_of(ph[cam]), eph), cam
+        assert 0.3 < ev.mean() < 1.0
+    # no silent drop to round 1's forms: the LDS-DMA form keeps these maps, the few corner tiles whose boxes it does not hold
+    # (keystone) go through its gather fix-up pass
+    assert all(i["mf_form"] == 7 and 4 * i["dma_nofit_tiles"] <= i["dma_tiles"] for i in info), info
+    assert theta < 0.25 or sum(i["dma_nofit_tiles"] for i in info) > 0                       # (the fix-up pass did run)
+    # the Gray fused decode on the same maps (its own fix-up kernel)
+    g = synth.render_gray_stack(W, H, 1024, seed=9, noise=2, device=st.device)
+    ncol = synth.gray_num_bits(1024)
+    torch.cuda.synchronize()
+    for cam in range(2):
+        mx, mf = ctx.get_rectify_maps(cam, W, H)
+        raw = g[cam].cpu().numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(raw.shape[0])])
+        ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 3, 1024, 0)
+        cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
+        ctx.synchronize()
+        assert bits_equal(np_of(cx), ex) and bits_equal(np_of(v), ev), cam
