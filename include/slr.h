@@ -133,6 +133,11 @@ const char  *slr_last_error(const slr_ctx *ctx);
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9
 #define SLR_OPT_DEBUG_K4_STOP 10
+/* SLR_OPT_HYBRID_ONE_PASS: how slr_hybrid_rectify_decode_pair / slr_reconstruct_hybrid_batch decode a hybrid stack (identical
+ * results): 0 (default) = two launches over the one stack -- the fused Gray decode of both cameras on planes 0 .. 2 n + 1, then the
+ * fused multi-frequency decode of both cameras on white, black and the fringes behind the Gray planes (measured faster: 349 vs
+ * 385 us at 4096x3000); 1 = ONE kernel that walks all 2 n + 14 planes of a tile (one digest, one shadow mask). */
+#define SLR_OPT_HYBRID_ONE_PASS 11
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */
@@ -271,6 +276,25 @@ int slr_reconstruct_gray(slr_ctx *ctx, const uint8_t *const *planesL, const uint
                          int n_col_bits, int n_row_bits, int pitch, int W, int H,
                          int black_thr, int white_thr, int scan_w, int scan_h,
                          float *xyz_sum, uint8_t *count, slr_mem mem);          /* runReconstruction */
+
+/* ---- BASELINE config 3: Gray code + multi-frequency phase from ONE hybrid stack -----------------------------------------------
+ * The reference's modes are exclusive (MainWindow::startreconstruct switches on codePatternUsed, mainwindow.h:94-95); a hybrid
+ * scan projects both pattern sets and shares the white / black pair.  planes of a camera: 0 white, 1 black, 2 + 2c / 3 + 2c the
+ * (pattern, inverse) pair of column bit c (MSB first, graycodes.cpp:55-114), then the 12 fringe planes 4f + s (3 frequencies x 4
+ * steps, multifrequency.cpp:14-33): 2 + 2 n_col_bits + 12 planes.  Raw camera images; the ctx maps are applied (fused).
+ * Each output is exactly what its own mode computes: code_x = Reconstruct::decodePatterns_GE / getProjPixel_GE
+ * (reconstruct.cpp:79-97, 381-407; -1 where masked or erroneous), phase = MFReconstruct::decodePatterns / getPhase
+ * (mfreconstruct.cpp:210-269; a quiet NaN where the pixel is invalid, see slr_mf_rectify_decode_pair).  One pass over the stack
+ * -- both cameras in one launch, the shadow mask, the map digest and the source-box geometry shared by the two decodes -- when
+ * the LDS-DMA form applies (equally spaced planes, W % 16 == 0, the default tile shape); otherwise two fused decodes per camera. */
+int slr_hybrid_rectify_decode_pair(slr_ctx *ctx, const uint8_t *const *planesL, const uint8_t *const *planesR, int n_col_bits,
+                                   int pitch, int W, int H, int black_thr, int white_thr, int scan_w,
+                                   int32_t *code_xL, float *phaseL, int32_t *code_xR, float *phaseR, slr_mem mem);
+/* device-resident batch: stack [n_frames][2 cams][planes_per_cam >= 2 + 2 n_col_bits + 12][H][pitch]; per frame the hybrid decode
+ * above, then MFReconstruct::triangulation on the two phase images (slr_mf_triangulate) -> xyz [n][H][W][3], has [n][H][W];
+ * code_x: [n][2 cams][H][W] i32 or NULL (the codes are not needed by the caller). */
+int slr_reconstruct_hybrid_batch(slr_ctx *ctx, int n_frames, const uint8_t *stack, int planes_per_cam, int n_col_bits, int pitch,
+                                 int W, int H, int black_thr, int white_thr, int scan_w, float *xyz, uint8_t *has, int32_t *code_x);
 
 /* slr_reconstruct_mf followed by slr_pointcloud_from_grid without the W x H XYZ grid ever leaving the device: what
  * MFReconstruct::runReconstruction hands to the application (mfreconstruct.cpp:160-187 -> points3DProjView). */

@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03
+( timeout 1500 python -m pytest tests/test_gpu_hybrid.py tests/test_gpu_rectdma.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -15 ) > gpurun_out/r03/b15_pytest.txt
+rm -f gpurun_out/var_ab.txt
+bash profiles/exp/ab/var_run.sh 2 "--mode hybrid" base
+bash profiles/exp/ab/var_run.sh 1 "--mode hybrid --hybrid-one-pass 1" base
+bash profiles/exp/ab/var_run.sh 1 "" base
+mv gpurun_out/var_ab.txt gpurun_out/r03/b15_bench.txt
+echo done

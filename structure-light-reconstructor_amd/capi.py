@@ -25,6 +25,7 @@ OPT_RECT_DMA_DEPTH = 7         # phases of LDS-DMA in flight ahead of the decode
 OPT_DEBUG_RECT_RESIDENT = 8    # tests: workgroups of the persistent fused decodes (0 = resident set)
 OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form
 OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
+OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()
 OPT_MF_DECODE_VEC = 2          # 0 auto, 4 / 8 / 16 pixels per thread in the unfused K2 kernel
@@ -39,7 +40,7 @@ SYMBOLS = [
     "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
     "slr_prefix_index", "slr_compact_points",
     "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
@@ -452,6 +453,38 @@ class Context:
                                               C.c_int(black_thr), C.c_int(1 if rectify else 0), _ptr(xyz), _ptr(has),
                                               C.c_int(mem)))
         return xyz, has
+
+    # -- BASELINE config 3: Gray code + phase from one hybrid stack
+    def hybrid_rectify_decode_pair(self, planesL, planesR, n_col_bits, black_thr, white_thr, scan_w, W=None):
+        """slr_hybrid_rectify_decode_pair: planes [2 + 2 n_col_bits + 12][H][pitch] per camera -> ([code_xL, code_xR], [phaseL, phaseR]);
+        code -1 / phase NaN where invalid."""
+        pl, n, H, pitch = _plane_ptrs(planesL)
+        pr, n2, H2, pitch2 = _plane_ptrs(planesR)
+        assert n >= 2 + 2 * n_col_bits + 12 and n2 == n and (H, pitch) == (H2, pitch2)
+        W = pitch if W is None else W
+        mem = self._mem(_flat(planesL) + _flat(planesR))
+        like = _flat(planesL)[0]
+        cx = [self._new(mem, (H, W), np.int32, like) for _ in range(2)]
+        ph = [self._new(mem, (H, W), np.float32, like) for _ in range(2)]
+        self._chk(self.lib.slr_hybrid_rectify_decode_pair(self.h, pl, pr, C.c_int(n_col_bits), C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                                          C.c_int(black_thr), C.c_int(white_thr), C.c_int(scan_w), _ptr(cx[0]), _ptr(ph[0]),
+                                                          _ptr(cx[1]), _ptr(ph[1]), C.c_int(mem)))
+        return cx, ph
+
+    def reconstruct_hybrid_batch(self, stack, n_col_bits, black_thr, white_thr, scan_w, W=None, xyz=None, has=None, want_codes=False):
+        """slr_reconstruct_hybrid_batch: stack = torch.cuda u8 [n_frames][2][planes_per_cam][H][pitch] -> (xyz, has, code_x or None)."""
+        import torch
+        nf, two, ppc, H, pitch = stack.shape
+        assert two == 2 and stack.is_cuda and stack.is_contiguous()
+        W = pitch if W is None else W
+        xyz = torch.empty((nf, H, W, 3), dtype=torch.float32, device=stack.device) if xyz is None else xyz
+        has = torch.empty((nf, H, W), dtype=torch.uint8, device=stack.device) if has is None else has
+        codes = torch.empty((nf, 2, H, W), dtype=torch.int32, device=stack.device) if want_codes else None
+        self._mem([stack, xyz, has, codes])
+        self._chk(self.lib.slr_reconstruct_hybrid_batch(self.h, C.c_int(nf), _ptr(stack), C.c_int(ppc), C.c_int(n_col_bits), C.c_int(pitch),
+                                                        C.c_int(W), C.c_int(H), C.c_int(black_thr), C.c_int(white_thr), C.c_int(scan_w),
+                                                        _ptr(xyz), _ptr(has), _ptr(codes)))
+        return xyz, has, codes
 
     def reconstruct_mf_cloud(self, planesL, planesR, black_thr, rectify, scan_w, scan_h, W=None):
         """slr_reconstruct_mf_cloud: the whole MF path + the PointCloudImage adaptor -> (pc_sum [scan_h][scan_w][3], pc_count)."""

@@ -241,9 +241,11 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
 // the decode kernel
 // ------------------------------------------------------------------------------------------------------
 struct DmaJob {
-    const uint8_t *base;         // plane 0; plane p is base + p * pstride
+    const uint8_t *base;         // plane 0; plane p is base + p * pstride (+ fringe_skip for the fringe planes p >= 2)
     unsigned pstride;
-    unsigned stack_bytes;        // 13 * pstride + H * pitch
+    unsigned fringe_skip;        // bytes between black and the first fringe plane beyond one plane stride (a hybrid stack keeps its
+                                 // Gray planes there, BASELINE config 3); 0 for a plain 14-plane stack
+    unsigned stack_bytes;        // 13 * pstride + fringe_skip + H * pitch
     const int4 *boxes;
     const unsigned *digest;
     unsigned digest_bytes;
@@ -257,8 +259,10 @@ struct DmaJobs { DmaJob j[2]; };
 __device__ __forceinline__ void dma16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned soff)
 {
     unsigned keep;
+    // (lds_dst and soff are wave-uniform; under register pressure hipcc may keep such a value in a VGPR and would then hand the
+    //  VGPR to the "s" operand: readfirstlane pins it to the scalar file)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 
 template <int N>
@@ -524,6 +528,25 @@ __device__ __forceinline__ void dma_sched_leave(unsigned *sched)
     }
 }
 
+// the wrapped phases' difference as the f32 image of the 2^24-scaled integers (het_pair_q24 with wrapping arithmetic: a
+// sentinel operand must not be undefined behaviour, its result is discarded)
+__device__ __forceinline__ float dma_pair_q24(int Pa, int Pb)
+{
+    return (float)(int)(((unsigned)Pa - (unsigned)Pb) + ((Pa > Pb) ? 0u : (unsigned)kQ24TwoPI));
+}
+// het_finish_q24 with the 2^-24 scaling moved behind the division: every step is the same rounding of the same real
+// number (power-of-two scalings are exact, 255 * 2^-24 is a float)
+__device__ __forceinline__ float dma_finish_q24(float Fa, float Fb)
+{
+    constexpr float two_pi_q24 = kTwoPI * 16777216.0f;
+    const float F123 = (Fa > Fb) ? (Fa - Fb) : (Fa - Fb + two_pi_q24);
+    constexpr float rc = 1.0f / kTwoPI;
+    const float q = F123 * rc;
+    const float r = __builtin_fmaf(-q, kTwoPI, F123);
+    return __builtin_fmaf(r, rc, q) * (255.0f / 16777216.0f);
+}
+constexpr int kDmaSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
+
 // the schedule state of a workgroup (both fused decodes): its pool, the tile after the current one, this thread's box chunk
 struct DmaSched {
     unsigned *ctr;                       // the pool's ticket counter
@@ -595,7 +618,7 @@ struct DmaDecode {
     static constexpr int TKT_OFF = LUT_OFF + (kLutWords + 1) * 4;        // the next tile's ticket (wave 0 -> everybody)
     static constexpr int LDS_BYTES = TKT_OFF + 12;
     static_assert(WT_OFF <= 65536 && LDS_BYTES <= 160 * 1024, "DMA destinations are 16-bit LDS addresses (M0)");
-    static constexpr int kSentinel = 0x7FFFFFFF;        // wrapped phase of the reference's undefined case (n == d == 0), folded mode
+    static constexpr int kSentinel = kDmaSentinel;
 
     const uint8_t *smem;
     const float *lut;
@@ -604,7 +627,7 @@ struct DmaDecode {
     unsigned plane_g;                    // SPLIT: which plane of a phase's pair this wave fetches (wave-uniform)
     bool plane_wave;                     // this wave owns chunks of the plane images (wave-uniform)
     __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_phase, rs_valid;
-    unsigned pstride;
+    unsigned pstride, fringe_skip;
     int W, H, black_thr;
     DmaSched sc;                         // schedule (see "dynamic tile schedule")
     // per-tile state
@@ -653,11 +676,12 @@ struct DmaDecode {
         if (!plane_wave) return;         // (wave-uniform)
         if constexpr (SPLIT) {
             const unsigned plane = (unsigned)dma_phase_plane(p, 0) + (p == 0 ? plane_g : 2u * plane_g);
-            dma16(voff, rs_stack, lds0 + (unsigned)(buf * 2 * PS) + plane_g * (unsigned)PS + pslot_off, plane * pstride);
+            dma16(voff, rs_stack, lds0 + (unsigned)(buf * 2 * PS) + plane_g * (unsigned)PS + pslot_off, plane * pstride + (p == 0 ? 0u : fringe_skip));
         } else {
 #pragma unroll
             for (int g = 0; g < 2; g++)
-                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 + g) * PS) + pslot_off, (unsigned)dma_phase_plane(p, g) * pstride);
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 + g) * PS) + pslot_off,
+                      (unsigned)dma_phase_plane(p, g) * pstride + (p == 0 ? 0u : fringe_skip));
         }
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
@@ -669,23 +693,8 @@ struct DmaDecode {
         }
     }
 
-    // the wrapped phases' difference as the f32 image of the 2^24-scaled integers (het_pair_q24 with wrapping arithmetic: a
-    // sentinel operand must not be undefined behaviour, its result is discarded)
-    static __device__ __forceinline__ float pair_q24(int Pa, int Pb)
-    {
-        return (float)(int)(((unsigned)Pa - (unsigned)Pb) + ((Pa > Pb) ? 0u : (unsigned)kQ24TwoPI));
-    }
-    // het_finish_q24 with the 2^-24 scaling moved behind the division: every step is the same rounding of the same real
-    // number (power-of-two scalings are exact, 255 * 2^-24 is a float)
-    static __device__ __forceinline__ float finish_q24(float Fa, float Fb)
-    {
-        constexpr float two_pi_q24 = kTwoPI * 16777216.0f;
-        const float F123 = (Fa > Fb) ? (Fa - Fb) : (Fa - Fb + two_pi_q24);
-        constexpr float rc = 1.0f / kTwoPI;
-        const float q = F123 * rc;
-        const float r = __builtin_fmaf(-q, kTwoPI, F123);
-        return __builtin_fmaf(r, rc, q) * (255.0f / 16777216.0f);
-    }
+    static __device__ __forceinline__ float pair_q24(int Pa, int Pb) { return dma_pair_q24(Pa, Pb); }
+    static __device__ __forceinline__ float finish_q24(float Fa, float Fb) { return dma_finish_q24(Fa, Fb); }
 
     // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur: this thread's chunk of the current tile's box.
     template <int K0, int P>
@@ -871,7 +880,7 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     const unsigned long long probe_c0 = clock64(), probe_w0 = wall_clock64();
 #endif
     // the schedule: the first tile by index, the others by ticket (tickets count from the band's nbx-th tile)
-    d.pstride = jobs.j[ji].pstride;
+    d.pstride = jobs.j[ji].pstride; d.fringe_skip = jobs.j[ji].fringe_skip;
     d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
     d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
     d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, (int)((unsigned)W * (unsigned)H * 4u), 0x00020000);
@@ -1001,18 +1010,21 @@ static const unsigned *dma_nofit_list(const void *tiles, int W, int H, int shape
     return reinterpret_cast<const unsigned *>(reinterpret_cast<const char *>(tiles) + dma_list_offset(W, H, shape));
 }
 
-// the stack layout this form needs: 14 planes equally spaced in one allocation (buffer addressing: plane = scalar offset),
+// the stack layout this form needs: 14 planes equally spaced in one allocation (buffer addressing: plane = scalar offset) -- or
+// white, black and, a whole number of plane strides further on, the 12 fringes (a hybrid stack with its Gray planes in between) --
 // 16-byte aligned rows, W a multiple of 16 (a chunk is completely inside or completely outside the image)
 static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, uint8_t *valid, const void *tiles, int shape, DmaJob &j)
 {
     if (!tiles || W % 16 != 0 || pitch % 16 != 0 || ((uintptr_t)pl.p[0] % 16) != 0 || ((uintptr_t)phase % 4) != 0) return false;
     const long long st = (long long)(pl.p[1] - pl.p[0]);
     if (st < (long long)H * pitch || st % 16 != 0) return false;
-    for (int i = 2; i < SLR_MF_PLANES; i++) if ((long long)(pl.p[i] - pl.p[0]) != st * i) return false;
-    const long long bytes = st * (SLR_MF_PLANES - 1) + (long long)H * pitch;
+    const long long skip = (long long)(pl.p[2] - pl.p[0]) - 2 * st;
+    if (skip < 0 || skip % st != 0) return false;
+    for (int i = 2; i < SLR_MF_PLANES; i++) if ((long long)(pl.p[i] - pl.p[0]) != st * i + skip) return false;
+    const long long bytes = st * (SLR_MF_PLANES - 1) + skip + (long long)H * pitch;
     if (bytes >= (1ll << 31) || (long long)W * H * 4 >= (1ll << 31)) return false;
     const char *b = reinterpret_cast<const char *>(tiles);
-    j.base = pl.p[0]; j.pstride = (unsigned)st; j.stack_bytes = (unsigned)bytes;
+    j.base = pl.p[0]; j.pstride = (unsigned)st; j.fringe_skip = (unsigned)skip; j.stack_bytes = (unsigned)bytes;
     j.boxes = reinterpret_cast<const int4 *>(b);
     j.digest = reinterpret_cast<const unsigned *>(b + dma_digest_offset(W, H, shape));
     const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
@@ -1117,6 +1129,7 @@ struct GrayDmaJob {
     unsigned digest_bytes;
     int32_t *code_x, *code_y;    // code_y may be null
     uint8_t *valid;              // may be null (the consumer reads validity off code_x == -1)
+    float *phase;                // hybrid stacks only (invalid pixels: NaN)
 };
 struct GrayDmaJobs { GrayDmaJob j[2]; };
 
@@ -1126,7 +1139,13 @@ struct GrayDmaJobs { GrayDmaJob j[2]; };
 #ifndef SLR_GRAY_DMA_NPP
 #define SLR_GRAY_DMA_NPP 2
 #endif
-template <int TW, int TH, int NT, int NPP>
+// HYB (BASELINE config 3, "Gray-code + phase hybrid decode"): the stack carries the 12 fringe planes of the multi-frequency
+// method behind the Gray pairs -- white, black, 2 * bits Gray planes, 3 x 4 fringes -- and the tile goes through six more plane
+// pairs, (G1, G3) and (G2, G4) of each frequency, decoded exactly as the multi-frequency kernel above decodes them (same tables,
+// same integer heterodyne): ONE pass over one box geometry and one digest gives the code image AND the phase image, the shadow
+// mask computed once.  The reference's modes are exclusive (mainwindow.h:94); each output equals its own mode's decode
+// (reconstruct.cpp:79-97,381-407 and mfreconstruct.cpp:210-269).  Validity travels in-band: code -1 / phase NaN.
+template <int TW, int TH, int NT, int NPP, bool HYB = false>
 struct GrayDma {
     static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
     typedef DmaGeom<TW, TH, NT> Gm;
@@ -1136,8 +1155,12 @@ struct GrayDma {
     static constexpr bool SPLIT = 2 * Gm::NCH <= NT;
     // dynamic LDS from address 0: 2 buffers of 2 * NPP plane images | digest of the tile | weight tables
     static constexpr int DIG_OFF = 4 * NPP * PS, DIG_BYTES = TW * TH * 4;     // (no scratch slot: waves without chunks issue no DMAs)
-    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4;
-    static constexpr int TKT_OFF = WT_OFF + 2 * 1026 * 4;                   // the next tile's ticket (wave 0 -> everybody)
+    // (HYB with two plane pairs per phase: the blend weights are computed per tile instead of tabulated -- the 8 KB the tables
+    //  take would push the workgroup over a third of the CU's LDS)
+    static constexpr bool NOWT = HYB && NPP == 2;
+    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + (NOWT ? 0 : 1026 * 4), TAP_WT = NOWT ? -1 : WT_OFF;
+    static constexpr int LUT_OFF = WT_OFF + (NOWT ? 0 : 2 * 1026 * 4);      // HYB: the decode tables (slr_create's, kLutWords)
+    static constexpr int TKT_OFF = LUT_OFF + (HYB ? (kLutWords + 1) * 4 : 0);   // the next tile's ticket (wave 0 -> everybody)
     static constexpr int LDS_BYTES = TKT_OFF + 8;
     static_assert(WT_OFF <= 65536, "DMA destinations are 16-bit LDS addresses (M0)");
 
@@ -1145,9 +1168,16 @@ struct GrayDma {
     DmaSched sc;                                             // schedule (see "dynamic tile schedule")
     unsigned lds0, wave_off, pslot_off, plane_g;             // (pslot_off, plane_g: see DmaDecode)
     bool plane_wave, has_cy, has_valid;
-    __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_cx, rs_cy, rs_valid;
+    __amdgpu_buffer_rsrc_t rs_stack, rs_dig, rs_cx, rs_cy, rs_valid, rs_phase;
     unsigned pstride;
     int W, H, black_thr, white_thr, ncol, nrow, npairs, nq, scan_w, scan_h;
+    // HYB: multi-frequency state (see DmaDecode: folded validity through a running max with the table's sentinel).  The kernel
+    // sits at its register budget and its pair loop is a run-time loop, so the state that is never live together shares
+    // registers by hand: d of the frequency in flight lives in acc[] and the previous wrapped phase in gxs[] (the code words
+    // are finished before the first fringe pair), and the phase to store replaces F12 in fo[].
+    const float *lut;
+    int pm[PX];
+    float fo[PX];
     DmaTap tap[PX];
     unsigned qbase[PX / 4], second;      // (the quad read modes of the MF kernel: dma_tap_setup)
     int mode;
@@ -1169,14 +1199,28 @@ struct GrayDma {
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             const u32x4_t vx = {(unsigned)out_x[4 * p], (unsigned)out_x[4 * p + 1], (unsigned)out_x[4 * p + 2], (unsigned)out_x[4 * p + 3]};
             __builtin_amdgcn_raw_buffer_store_b128(vx, rs_cx, inb ? m * 4u : kDmaInvalid, 0, 2);
-            if (has_cy) {
+            if (!HYB && has_cy) {
                 const u32x4_t vy = {(unsigned)out_y[4 * p], (unsigned)out_y[4 * p + 1], (unsigned)out_y[4 * p + 2], (unsigned)out_y[4 * p + 3]};
                 __builtin_amdgcn_raw_buffer_store_b128(vy, rs_cy, inb ? m * 4u : kDmaInvalid, 0, 2);
             }
-            if (has_valid)
+            if (!HYB && has_valid)
                 __builtin_amdgcn_raw_buffer_store_b32(__umul24((out_ok >> (4 * p)) & 0xFu, 0x204081u) & 0x01010101u, rs_valid,
                                                       inb ? m : kDmaInvalid, 0, 0);
+            if constexpr (HYB) {
+                const u32x4_t vp = {__builtin_bit_cast(unsigned, fo[4 * p]), __builtin_bit_cast(unsigned, fo[4 * p + 1]),
+                                    __builtin_bit_cast(unsigned, fo[4 * p + 2]), __builtin_bit_cast(unsigned, fo[4 * p + 3])};
+                __builtin_amdgcn_raw_buffer_store_b128(vp, rs_phase, inb ? m * 4u : kDmaInvalid, 0, 2);
+            }
         }
+    }
+    // plane g (0 / 1) of pair j: pair 0 = (white, black), pair c = code bit c - 1 (pattern, inverse); HYB, behind the code bits:
+    // pair 2f = (G1, G3) and pair 2f + 1 = (G2, G4) of frequency f (fringe plane 4f + s holds G(s+1), mfreconstruct.cpp:239-242)
+    __device__ __forceinline__ int pair_plane(int j, int g) const
+    {
+        const int nb = HYB ? ncol : ncol + nrow;                      // (a hybrid stack carries column bits only)
+        if (!HYB || j <= nb) return 2 * j + g;
+        const int m = j - 1 - nb;
+        return 2 + 2 * nb + 4 * (m >> 1) + (m & 1) + 2 * g;
     }
     // the planes of phase k -- plane pairs NPP * k .. -- into buffer buf
     __device__ __forceinline__ void issue_planes(int k, int buf, unsigned voff) const
@@ -1185,11 +1229,31 @@ struct GrayDma {
         const int n = NPP == 1 || 2 * k + 1 < npairs ? 2 * NPP : 2;
         if constexpr (SPLIT) {
             for (int g = (int)plane_g * NPP; g < (int)(plane_g + 1) * NPP && g < n; g++)
-                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)(2 * NPP * k + g) * pstride);
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)pair_plane(NPP * k + (g >> 1), g & 1) * pstride);
         } else {
             for (int g = 0; g < n; g++)
-                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)(2 * NPP * k + g) * pstride);
+                dma16(voff, rs_stack, lds0 + (unsigned)((buf * 2 * NPP + g) * PS) + pslot_off, (unsigned)pair_plane(NPP * k + (g >> 1), g & 1) * pstride);
         }
+    }
+    // HYB: the difference of fringe pair m (0 .. 5) of a pixel: d = G1 - G3 kept, n = G4 - G2 -> the frequency's wrapped phase,
+    // the heterodyne folded in as the frequencies arrive (DmaDecode::phase)
+    __device__ __forceinline__ void fringe_step(int q, int m, int sd)
+    {
+        if (m == 0) pm[q] = ((flags >> q) & 1u) != 0 ? (int)0x80000000 : kDmaSentinel;      // the shadow mask enters the running max
+        if ((m & 1) == 0) { acc[q] = (unsigned)sd; return; }                                 // d = G1 - G3
+        int nz;
+        const int Pw = wrapped_nd_q24(-sd, (int)acc[q], lut, nz);                            // n = G4 - G2
+        const int mx = pm[q] > Pw ? pm[q] : Pw;
+        pm[q] = mx;
+        if (m == 1) gxs[q] = (unsigned)Pw;
+        else if (m == 3) { fo[q] = dma_pair_q24((int)gxs[q], Pw); gxs[q] = (unsigned)Pw; }
+        else fo[q] = mx != kDmaSentinel ? dma_finish_q24(fo[q], dma_pair_q24((int)gxs[q], Pw)) : kInvalidPhase;
+    }
+    // the difference of pair j (>= 1) of a pixel goes where it belongs
+    __device__ __forceinline__ void pair_step(int q, int j, int sd)
+    {
+        if (!HYB || j <= ncol) bit_step(q, sd, j == ncol);
+        else fringe_step(q, j - 1 - ncol, sd);
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -1217,14 +1281,14 @@ struct GrayDma {
             gy ^= gy >> 1; gy ^= gy >> 2; gy ^= gy >> 4; gy ^= gy >> 8;
             const int x = (int)gx, y = (int)gy;
             bool err = ((flags >> (8 + q)) & 1u) != 0;
-            if (nrow > 0) err = err || y > scan_h || x > scan_w;   // reconstruct.cpp:364 (Q9 '>')
+            if (!HYB && nrow > 0) err = err || y > scan_h || x > scan_w;   // reconstruct.cpp:364 (Q9 '>')
             else err = err || x > scan_w;                          // reconstruct.cpp:403
             const bool ok = ((flags >> q) & 1u) != 0 && !err;
             out_x[q] = ok ? x : -1;
-            out_y[q] = (ok && nrow > 0) ? y : -1;
+            if constexpr (!HYB) out_y[q] = (ok && nrow > 0) ? y : -1;
             out_ok |= (ok ? 1u : 0u) << q;
         }
-        out_ty = ty; out_tx = tx; out_pending = true;
+        if constexpr (!HYB) { out_ty = ty; out_tx = tx; out_pending = true; }
     }
     // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
     // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
@@ -1244,7 +1308,7 @@ struct GrayDma {
         if constexpr (FIRST) {
             if (out_pending) flush();
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, WT_OFF, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
 #pragma unroll
             for (int q = 0; q < PX; q++) { acc[q] = 0; gxs[q] = 0; }
             flags = 0;
@@ -1254,25 +1318,27 @@ struct GrayDma {
         {
             int sd[PX];
             dma_differences<PX, i00, i01, (unsigned)RS>(mode, tap, qbase, second, sd);
-            const bool mv0 = NPP * k == ncol;
 #pragma unroll
             for (int q = 0; q < PX; q++) {
-                if constexpr (FIRST) flags |= (sd[q] > black_thr ? 1u : 0u) << q;     // computeShadows, reconstruct.cpp:218-224
-                else bit_step(q, sd[q], mv0);
+                if constexpr (FIRST) {
+                    flags |= (sd[q] > black_thr ? 1u : 0u) << q;                       // computeShadows, reconstruct.cpp:218-224
+                } else pair_step(q, NPP * k, sd[q]);
             }
         }
         if constexpr (NPP == 2) {
             if (2 * k + 1 < npairs) {                        // (a stack's last phase may hold one pair only)
                 int sd[PX];
                 dma_differences<PX, i10, i11, (unsigned)RS>(mode, tap, qbase, second, sd);
-                const bool mv1 = 2 * k + 1 == ncol;
 #pragma unroll
-                for (int q = 0; q < PX; q++) bit_step(q, sd[q], mv1);
+                for (int q = 0; q < PX; q++) pair_step(q, 2 * k + 1, sd[q]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
         if constexpr (FIRST) sc.publish(ticket);             // (the ticket has had the tap loop to arrive)
-        if (last) finish(ty, tx);
+        // the code words are complete behind the last code-bit pair (HYB: the fringe pairs follow; acc / gxs are free from here)
+        const int jlast = NPP * k + (NPP == 2 && 2 * k + 1 < npairs ? 1 : 0);
+        if (HYB ? (NPP * k <= ncol && jlast >= ncol && !FIRST) : last) finish(ty, tx);
+        if (HYB && last) { out_ty = ty; out_tx = tx; out_pending = true; }
     }
     template <int K>
     __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur)
@@ -1295,18 +1361,27 @@ constexpr int gray_dma_waves()
     return dma_waves_per_simd<LDS_BYTES, NT>() > cap ? cap : dma_waves_per_simd<LDS_BYTES, NT>();
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD>
-__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP>::LDS_BYTES, NT, NPP>()))
+template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false>
+__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB>::LDS_BYTES, NT, NPP>()))
 void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
-                                 int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched)
+                                 int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched,
+                                 const float *__restrict__ lut_g)
 {
-    typedef GrayDma<TW, TH, NT, NPP> Dec;
+    typedef GrayDma<TW, TH, NT, NPP, HYB> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Dec d;
     d.smem = smem;
     d.lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     if (d.lds0 & 0x1FFFu) __builtin_trap();                 // the tap addresses OR the buffer base in (no static LDS here: 0)
+    if constexpr (HYB) {                                    // the decode tables, the undefined wrapped phase patched to the sentinel
+        float *lut = reinterpret_cast<float *>(smem + Dec::LUT_OFF);
+        d.lut = lut;
+        for (int i = threadIdx.x; i < kLutWords; i += NT) lut[i] = lut_g[i];
+        __syncthreads();
+        if (threadIdx.x == 0) reinterpret_cast<int *>(lut)[kLutP + (9 << 8)] = kDmaSentinel;
+    }
+    if constexpr (!Dec::NOWT)
     for (unsigned i = threadIdx.x; i < 1025u; i += NT) {
         unsigned w0, w1;
         dma_weights(i, w0, w1);
@@ -1334,15 +1409,19 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
         d.plane_wave = Dec::SPLIT ? wv < 2u * wpp : wv < wpp;
     }
     d.pstride = jobs.j[ji].pstride;
-    d.W = W; d.H = H; d.black_thr = black_thr; d.white_thr = white_thr; d.ncol = ncol; d.nrow = nrow; d.npairs = 1 + ncol + nrow; d.nq = (d.npairs + NPP - 1) / NPP;
+    d.W = W; d.H = H; d.black_thr = black_thr; d.white_thr = white_thr; d.ncol = ncol; d.nrow = nrow;
+    d.npairs = 1 + ncol + nrow + (HYB ? 6 : 0); d.nq = (d.npairs + NPP - 1) / NPP;
     d.scan_w = scan_w; d.scan_h = scan_h;
     d.has_cy = jobs.j[ji].code_y != nullptr; d.has_valid = jobs.j[ji].valid != nullptr;
     const int n4 = (int)((unsigned)W * (unsigned)H * 4u);
     d.rs_stack = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].base, 0, (int)jobs.j[ji].stack_bytes, 0x00020000);
     d.rs_dig = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].digest, 0, (int)jobs.j[ji].digest_bytes, 0x00020000);
     d.rs_cx = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_x, 0, n4, 0x00020000);
-    d.rs_cy = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_y, 0, d.has_cy ? n4 : 0, 0x00020000);
-    d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, d.has_valid ? n4 / 4 : 0, 0x00020000);
+    if constexpr (!HYB) {
+        d.rs_cy = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].code_y, 0, d.has_cy ? n4 : 0, 0x00020000);
+        d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, d.has_valid ? n4 / 4 : 0, 0x00020000);
+    }
+    d.rs_phase = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].phase, 0, HYB ? n4 : 0, 0x00020000);
     d.sc.boxes = jobs.j[ji].boxes;
     d.sc.pitch = pitch; d.sc.W = W; d.sc.H = H;
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
@@ -1393,16 +1472,16 @@ static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, 
     const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
     if (dg >= (1ull << 31)) return false;
     j.digest_bytes = (unsigned)dg;
-    j.code_x = cx; j.code_y = cy; j.valid = valid;
+    j.code_x = cx; j.code_y = cy; j.valid = valid; j.phase = nullptr;
     return true;
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD>
+template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false>
 static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol,
-                                          int nrow, int scan_w, int scan_h, unsigned *sched, hipStream_t s)
+                                          int nrow, int scan_w, int scan_h, unsigned *sched, hipStream_t s, const float *lut = nullptr)
 {
-    typedef GrayDma<TW, TH, NT, NPP> Dec;
-    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD>;
+    typedef GrayDma<TW, TH, NT, NPP, HYB> Dec;
+    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD, HYB>;
     static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1422,7 +1501,7 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, white_thr,
-               ncol, nrow, scan_w, scan_h, tiles_x, tiles_y, sched);
+               ncol, nrow, scan_w, scan_h, tiles_x, tiles_y, sched, lut);
     return hipGetLastError();
 }
 
@@ -1478,5 +1557,51 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     return e;
 }
 
+#ifndef SLR_HYB_NPP
+#define SLR_HYB_NPP 1           // plane pairs per phase of the hybrid kernel
+#endif
+// BASELINE config 3: one pass over a hybrid stack (white, black, 2 * ncol Gray planes, 12 fringe planes; equally spaced) of one
+// camera (n == 1) or both (n == 2): code_x (-1 where invalid) and phase (NaN where invalid).  *done = false: the form does not
+// apply (stack layout, image width, maps), nothing was launched -- the caller runs the two separate fused decodes instead.
+hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int pitch, int W, int H, int black_thr, int white_thr,
+                                         int scan_w, const float *lut, int32_t *const *code_x, float *const *phase,
+                                         const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix, bool *done,
+                                         hipStream_t s)
+{
+    *done = false;
+    if (!sched || !lut || shape != 3 || ncol < 1) return hipSuccess;     // (the default tile shape only)
+    const int np = 2 + 2 * ncol + 12;
+    if (np > SLR_MAX_GRAY_PLANES) return hipSuccess;
+    for (int c = 0; c < n; c++)
+        if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
+    GrayDmaJobs j;
+    for (int c = 0; c < n; c++) {
+        if (!gray_dma_job(pl[c], np, pitch, W, H, code_x[c], nullptr, nullptr, tiles[c], shape, j.j[c])) return hipSuccess;
+        if (((uintptr_t)phase[c] % 16) != 0) return hipSuccess;
+        j.j[c].phase = phase[c];
+    }
+    if (n == 1) j.j[1] = j.j[0];
+    *done = true;
+    constexpr int NPP = SLR_HYB_NPP;
+    const bool odd = ((((1 + ncol + 6) + NPP - 1) / NPP) & 1) != 0;     // phases (of NPP plane pairs) per tile
+    hipError_t e = odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
+                       : launch_gray_dma_variant<128, 16, 512, NPP, false, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut);
+    // tiles the form does not hold: the two gather fix-ups, one per output
+    for (int c = 0; c < n && e == hipSuccess; c++) {
+        if (!fix || fix->nofit[c] == 0) continue;
+        const unsigned cnt = fix->nofit[c], grid = cnt * 8u < 16384u ? cnt * 8u : 16384u;
+        const int tiles_x = (W + 127) / 128;
+        MfPlanes mp;
+        mp.p[0] = pl[c].p[0]; mp.p[1] = pl[c].p[1];
+        for (int k = 0; k < 12; k++) mp.p[2 + k] = pl[c].p[2 + 2 * ncol + k];
+        hipLaunchKernelGGL((gray_rect_fixup_kernel<128, 16>), dim3(grid), dim3(256), 0, s, pl[c], ncol, 0, pitch, W, H, black_thr, white_thr,
+                           scan_w, 0, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, code_x[c],
+                           (int32_t *)nullptr, (uint8_t *)nullptr);
+        hipLaunchKernelGGL((mf_rect_fixup_kernel<128, 16>), dim3(grid), dim3(256), 0, s, mp, pitch, W, H, black_thr, lut, fix->map_xy[c],
+                           fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], (uint8_t *)nullptr);
+        e = hipGetLastError();
+    }
+    return e;
+}
 
 }  // namespace slr

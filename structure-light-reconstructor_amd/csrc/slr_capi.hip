@@ -23,7 +23,7 @@ const char *kKernelNames[K_COUNT] = {
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
     "slr_ray_triangulate",
     "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair", "slr_mfn_decode",
-    "slr_gray_rectify_decode_pair"};
+    "slr_gray_rectify_decode_pair", "slr_hybrid_rectify_decode_pair"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -64,6 +64,7 @@ struct slr_ctx {
     int opt_mf_decode_vec = 0;     // SLR_OPT_MF_DECODE_VEC
     int opt_rect_algo = 0;         // SLR_OPT_RECT_DECODE_ALGO
     int opt_async_host = 0;        // SLR_OPT_ASYNC_HOST
+    int opt_hybrid_one_pass = 0;   // SLR_OPT_HYBRID_ONE_PASS
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
@@ -1076,6 +1077,119 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
     return SLR_OK;
 }
 
+// ---- BASELINE config 3: Gray code + multi-frequency phase from one hybrid stack ----------------------------------------------------
+// planes of a camera: white, black, 2 * ncol Gray planes (pattern, inverse per column bit, MSB first), 12 fringe planes (3 x 4).
+// One pass (one launch for both cameras) when the LDS-DMA form applies; else the two fused decodes of each camera.
+static int hybrid_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int ncol, int pitch, int W, int H,
+                           int black_thr, int white_thr, int scan_w, int32_t *cxL, float *phL, int32_t *cxR, float *phR)
+{
+    const int np = 2 + 2 * ncol + 12;
+    bool done = false;
+    if (!c->opt_hybrid_one_pass) {
+        // two launches over the one stack (the default, measured faster than the one-pass kernel): the Gray planes of both
+        // cameras, then white + black + the fringes behind the Gray planes of both cameras (the LDS-DMA forms when they apply --
+        // the multi-frequency one takes the gap between black and the first fringe as a constant plane skip)
+        bool paired = false;
+        if (dma_form_wanted(c, 0, 1)) {
+            GrayPlanes gp[2];
+            for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) { gp[0].p[i] = i < 2 + 2 * ncol ? pL[i] : nullptr; gp[1].p[i] = i < 2 + 2 * ncol ? pR[i] : nullptr; }
+            int32_t *const xs[2] = {cxL, cxR}, *const ys[2] = {nullptr, nullptr};
+            uint8_t *const vd[2] = {nullptr, nullptr};
+            const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
+            const DmaFixup fix = dma_fixup_of(c, 0, 1);
+            ProfScope ps(c, K_GRAY_RECT_DECODE_PAIR, true);
+            SLR_HIP(c, launch_gray_rect_decode_dma(gp, 2, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, xs, ys, vd, tl,
+                                                   c->opt_dma_shape, c->d_sched, &fix, &paired, c->stream));
+        }
+        if (!paired) {
+            SLR_TRY(core_gray_decode(c, 0, true, pL, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cxL, nullptr, nullptr));
+            SLR_TRY(core_gray_decode(c, 1, true, pR, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cxR, nullptr, nullptr));
+        }
+        const uint8_t *ml[SLR_MF_PLANES], *mr[SLR_MF_PLANES];
+        ml[0] = pL[0]; ml[1] = pL[1]; mr[0] = pR[0]; mr[1] = pR[1];
+        for (int k = 0; k < 12; k++) { ml[2 + k] = pL[2 + 2 * ncol + k]; mr[2 + k] = pR[2 + 2 * ncol + k]; }
+        return decode_pair_dev(c, ml, mr, pitch, W, H, black_thr, 1, phL, nullptr, phR, nullptr);
+    }
+    if (dma_form_wanted(c, 0, 1)) {
+        GrayPlanes gp[2];
+        for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) { gp[0].p[i] = i < np ? pL[i] : nullptr; gp[1].p[i] = i < np ? pR[i] : nullptr; }
+        int32_t *const xs[2] = {cxL, cxR};
+        float *const ps[2] = {phL, phR};
+        const void *const tl[2] = {c->d_dma_tiles[0], c->d_dma_tiles[1]};
+        const DmaFixup fix = dma_fixup_of(c, 0, 1);
+        ProfScope ps_(c, K_HYBRID_RECT_DECODE_PAIR, true);
+        SLR_HIP(c, launch_hybrid_rect_decode_dma(gp, 2, ncol, pitch, W, H, black_thr, white_thr, scan_w, c->d_lut, xs, ps, tl,
+                                                 c->opt_dma_shape, c->d_sched, &fix, &done, c->stream));
+    }
+    if (done) return SLR_OK;
+    if (c->opt_rect_algo == 7)
+        return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_RECT_DECODE_ALGO = 7 (LDS-DMA form) does not apply to this hybrid stack / these maps");
+    for (int cam = 0; cam < 2; cam++) {                      // two passes per camera: the Gray planes, then white + black + fringes
+        const uint8_t *const *p = cam == 0 ? pL : pR;
+        const uint8_t *mf[SLR_MF_PLANES];
+        mf[0] = p[0]; mf[1] = p[1];
+        for (int k = 0; k < 12; k++) mf[2 + k] = p[2 + 2 * ncol + k];
+        SLR_TRY(core_gray_decode(c, cam, true, p, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cam == 0 ? cxL : cxR, nullptr, nullptr));
+        SLR_TRY(core_mf_decode(c, cam, true, mf, pitch, W, H, black_thr, cam == 0 ? phL : phR, nullptr));
+    }
+    return SLR_OK;
+}
+
+static int hybrid_check(slr_ctx *c, int ncol, int pitch, int W, int H, int scan_w)
+{
+    if (ncol < 1 || ncol > SLR_MAX_GRAY_BITS || scan_w <= 0) return fail(c, SLR_ERR_INVALID_ARG, "bit count / scan size out of range");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_maps(c, 0, W, H)); SLR_TRY(need_maps(c, 1, W, H));
+    return SLR_OK;
+}
+
+int slr_hybrid_rectify_decode_pair(slr_ctx *c, const uint8_t *const *planesL, const uint8_t *const *planesR, int ncol, int pitch, int W,
+                                   int H, int black_thr, int white_thr, int scan_w, int32_t *code_xL, float *phaseL, int32_t *code_xR,
+                                   float *phaseR, slr_mem mem)
+{
+    if (!c || !planesL || !planesR || !code_xL || !phaseL || !code_xR || !phaseR) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    SLR_TRY(hybrid_check(c, ncol, pitch, W, H, scan_w));
+    const int np = 2 + 2 * ncol + 12;
+    for (int i = 0; i < np; i++) if (!planesL[i] || !planesR[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    Stage st(c, mem);
+    const uint8_t *dl[SLR_MAX_GRAY_PLANES], *dr[SLR_MAX_GRAY_PLANES];
+    void *xl, *pl, *xr, *pr;
+    const size_t n = (size_t)W * H;
+    SLR_TRY(st.planes(planesL, np, pitch, H, dl));
+    SLR_TRY(st.planes(planesR, np, pitch, H, dr));
+    SLR_TRY(st.out(code_xL, n * 4, &xl)); SLR_TRY(st.out(phaseL, n * 4, &pl));
+    SLR_TRY(st.out(code_xR, n * 4, &xr)); SLR_TRY(st.out(phaseR, n * 4, &pr));
+    SLR_TRY(hybrid_pair_dev(c, dl, dr, ncol, pitch, W, H, black_thr, white_thr, scan_w, (int32_t *)xl, (float *)pl, (int32_t *)xr, (float *)pr));
+    return st.finish();
+}
+
+int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int planes_per_cam, int ncol, int pitch, int W, int H,
+                                 int black_thr, int white_thr, int scan_w, float *xyz, uint8_t *has, int32_t *code_x)
+{
+    if (!c || !stack || !xyz || !has || n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    SLR_TRY(hybrid_check(c, ncol, pitch, W, H, scan_w));
+    const int np = 2 + 2 * ncol + 12;
+    if (planes_per_cam < np || planes_per_cam > SLR_MAX_GRAY_PLANES) return fail(c, SLR_ERR_INVALID_ARG, "planes_per_cam does not hold the hybrid stack");
+    if (W > 32768) return fail(c, SLR_ERR_UNSUPPORTED, "W > 32768 does not fit the LDS row");
+    SLR_TRY(need_calib(c));
+    const size_t plane = (size_t)pitch * H, n = (size_t)W * H;
+    void *phL, *phR, *cxs = nullptr;
+    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL));
+    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR));
+    if (!code_x) SLR_TRY(get_scratch(c, S_CODEX_L, n * 8, &cxs));      // nobody wants the codes: one scratch pair for every frame
+    for (int f = 0; f < n_frames; f++) {
+        const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];
+        const uint8_t *base = stack + (size_t)f * 2 * planes_per_cam * plane;
+        for (int i = 0; i < np; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (planes_per_cam + i); }
+        int32_t *cx = code_x ? code_x + (size_t)f * 2 * n : (int32_t *)cxs;
+        SLR_TRY(hybrid_pair_dev(c, pl, pr, ncol, pitch, W, H, black_thr, white_thr, scan_w, cx, (float *)phL, cx + n, (float *)phR));
+        SLR_TRY(core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz + (size_t)f * n * 3, has + (size_t)f * n,
+                              nullptr));
+    }
+    return SLR_OK;
+}
+
 int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t *const *planesR, int ncol, int pitch,
                        int W, int H, int black_thr, int white_thr, int scan_w, int rectify, int have_color, float *xyz,
                        uint8_t *has, uint8_t *color, slr_mem mem)
@@ -1472,6 +1586,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_RECT_DMA_DEPTH:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_DEPTH must be 1 or 2");
             c->opt_dma_depth = value;
+            return SLR_OK;
+        case SLR_OPT_HYBRID_ONE_PASS:
+            if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_HYBRID_ONE_PASS must be 0 or 1");
+            c->opt_hybrid_one_pass = value;
             return SLR_OK;
         case SLR_OPT_PROFILE_STRIDE:
             if (value < 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_PROFILE_STRIDE must be >= 1");

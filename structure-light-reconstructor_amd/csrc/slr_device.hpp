@@ -47,7 +47,7 @@ struct DevCalib {
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_GRAY_RECT_DECODE_PAIR, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_GRAY_RECT_DECODE_PAIR, K_HYBRID_RECT_DECODE_PAIR, K_COUNT
 };
 
 // Every kernel launch goes through SLR_LAUNCH.  When the C-ABI layer's profiler has armed a pair of events for the
@@ -138,6 +138,11 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
                                        uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
                                        bool *done, hipStream_t s);
+// BASELINE config 3: Gray code + multi-frequency phase in ONE pass over a hybrid stack (kernels_rectdma.hip)
+hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int pitch, int W, int H, int black_thr, int white_thr,
+                                         int scan_w, const float *lut, int32_t *const *code_x, float *const *phase,
+                                         const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix, bool *done,
+                                         hipStream_t s);
 hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
                               int black_thr, int white_thr, int scan_w, int scan_h,
                               int32_t *code_x, int32_t *code_y, uint8_t *valid,

@@ -238,6 +238,14 @@ def render_mfn_stack(W, H, n_freq=4, n_step=8, proj_w=None, seed=1234, noise=0.5
     return out
 
 
+def render_hybrid_stack(W, H, scan_w, seed=1234, noise=2, device="cpu"):
+    """BASELINE config 3 input: [2 cams][2 + 2 n + 12][H][W] u8 -- white, black, the column Gray pairs of a scan_w-wide projector,
+    then the 12 multi-frequency fringes, all of ONE scene (the same projector column per pixel; white / black shared)."""
+    g = render_gray_stack(W, H, scan_w, seed=seed, noise=noise, device=device)
+    mf = render_mf_stack(W, H, seed=seed + 7919, noise=noise, device=device)
+    return torch.cat([g, mf[:, 2:]], dim=1).contiguous()
+
+
 def render_gray_stack(W, H, scan_w, scan_h=None, seed=1234, noise=2, device="cpu", rows=False):
     """[2 cams][2+2n(+2m)][H][W] u8 Gray-code stack.  rows=True adds the row-bit planes (GRAY_ONLY mode); the
     projector row seen by a pixel is a smooth function of the image row."""
