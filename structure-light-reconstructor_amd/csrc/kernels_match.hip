@@ -461,6 +461,44 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
 //   * the table gathers, the f64 arithmetic and the stores of a thread's 4 pixels are branch-free (unmatched pixels compute on
 //     column 0's table entry and are replaced by zeros at the end).
 // ------------------------------------------------------------------------------------------------------
+// Exclusive scan over a workgroup of BLOCK threads (the lean match kernels' index build): every wave scans itself with DPP lane
+// shifts (row_shr 1 / 2 / 4 / 8, then row_bcast 15 and 31: six VALU steps, no LDS crossbar), the (at most 16) wave totals cross in
+// LDS behind ONE barrier and every wave scans them for itself -- in place of hipcub::BlockScan, whose warp-scans form spends two
+// barriers.  result = op(init, v[0], ..., v[tid - 1]) (init must be op's identity); *total = the reduction over the workgroup.
+// wave_tot: LDS, BLOCK / 64 words, free for reuse after the caller's next barrier.
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T dpp_or(T identity, T v)       // the DPP source lane's v, or `identity` where there is none / the row is masked
+{
+    return (T)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int BLOCK, typename T, typename Op>
+__device__ __forceinline__ T wg_exclusive_scan(T v, T init, Op op, T *wave_tot, T *total)
+{
+    static_assert(sizeof(T) == 4, "32-bit DPP");
+    constexpr int NW = BLOCK / 64;
+    static_assert(NW >= 1 && NW <= 16, "the wave totals are scanned inside one DPP row");
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    T inc = v;
+    inc = op(dpp_or<0x111, 0xF>(init, inc), inc);           // row_shr:1
+    inc = op(dpp_or<0x112, 0xF>(init, inc), inc);           // row_shr:2
+    inc = op(dpp_or<0x114, 0xF>(init, inc), inc);           // row_shr:4
+    inc = op(dpp_or<0x118, 0xF>(init, inc), inc);           // row_shr:8   -> inclusive inside each row of 16
+    inc = op(dpp_or<0x142, 0xA>(init, inc), inc);           // row_bcast:15 into rows 1 and 3
+    inc = op(dpp_or<0x143, 0xC>(init, inc), inc);           // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    T t = wave_tot[lane < NW ? lane : NW - 1];
+    t = op(dpp_or<0x111, 0xF>(init, t), t);
+    if (NW > 2) t = op(dpp_or<0x112, 0xF>(init, t), t);
+    if (NW > 4) t = op(dpp_or<0x114, 0xF>(init, t), t);
+    if (NW > 8) t = op(dpp_or<0x118, 0xF>(init, t), t);
+    if (total) *total = (T)__builtin_amdgcn_readlane((int)t, NW - 1);
+    const T base = wv > 0 ? (T)__builtin_amdgcn_readlane((int)t, wv > 0 ? wv - 1 : 0) : init;
+    const T excl = dpp_or<0x138, 0xF>(init, inc);           // wave_shr:1: the wave's own exclusive prefix (lane 0: init)
+    return op(base, excl);
+}
+
 struct K4Lean {
     double q3, q7, q11, q14, q15;      // Q's five entries that are not structural zeros / ones
     double T[12];                      // matCoordTrans widened to f64 (exact)
@@ -479,11 +517,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     constexpr int TS = 2 * N;                            // hash slots (power of two, load factor <= 0.5)
     constexpr int kPer = kBins / BLOCK;                  // bins per thread (kBins is a multiple of BLOCK)
     constexpr unsigned kEmpty = 0xFFFFFFFFu;             // a NaN pattern: never a candidate's phase bits
-#if defined(SLR_K4_SCAN_RAKING)
-    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
-#else
-    typedef hipcub::BlockScan<unsigned, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanU;
-#endif
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     constexpr bool kCntInKey = TS >= kBins + BLOCK;        // the bin counters reuse the key half of the table when they fit it
     __shared__ union {
@@ -491,7 +524,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         struct { f32x4 pk2[N / 2 + 3]; unsigned bs[kBins + 3]; } b;      // pairs of (phi, column as bits) grouped by bin (+ sentinels, + a sink); bin index
         struct { unsigned pad[kCntInKey ? 1 : 2 * TS]; unsigned cnt[kCntInKey ? 1 : kBins + BLOCK]; } c;   // (small rows: behind the table)
     } sh;
-    __shared__ typename ScanU::TempStorage scan_tmp;
+    __shared__ unsigned scan_tmp[BLOCK / 64];
     static_assert(BLOCK != 1024 || sizeof(sh.b) <= sizeof(sh.t), "the index must fit the dead hash table (two workgroups per CU)");
 
     const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
@@ -570,8 +603,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         unsigned c[kPer], sum = 0;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { c[q] = cnt[tid * kPer + q]; sum += c[q]; }
-        unsigned excl, total;
-        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);  // (its barriers: every thread has read its counters)
+        unsigned total;
+        unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);   // (its barrier: every thread has read its counters)
 #pragma unroll
         for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }   // bs lies in the mink half
         if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
@@ -1265,13 +1298,11 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
                                                                 uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
 {
     constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, TC = 8192, kPer = TC / BLOCK, kMaxList = 32;
-    typedef hipcub::BlockScan<unsigned, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanU;
-    typedef hipcub::BlockScan<int, BLOCK, hipcub::BLOCK_SCAN_WARP_SCANS> ScanI;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned start[TC + BLOCK + 1];             // counters, then list starts (start[TC] = total); [TC + 1 + tid]: atomics' sinks
     __shared__ unsigned short S[N];                        // the lists: columns grouped by code, ascending inside a code
-    __shared__ union { typename ScanU::TempStorage u; typename ScanI::TempStorage i; } scan_tmp;
+    __shared__ union { unsigned u[BLOCK / 64]; int i[BLOCK / 64]; } scan_tmp;
 
     const int row = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)row * W;
@@ -1311,7 +1342,7 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
         unsigned sum = 0, longest = 0;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { c[q] = start[tid * kPer + q]; sum += c[q]; longest = c[q] > longest ? c[q] : longest; }
-        ScanU(scan_tmp.u).ExclusiveSum(sum, excl, total);  // (its barriers: every thread has read its counters)
+        excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp.u, &total);
         unsigned e = excl;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { start[tid * kPer + q] = e; e += c[q]; }
@@ -1365,8 +1396,7 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
                 }
             }
         }
-        int exc;
-        ScanI(scan_tmp.i).ExclusiveScan(lm, exc, -1, hipcub::Max());
+        const int exc = wg_exclusive_scan<BLOCK>(lm, -1, [](int a, int b) { return a > b ? a : b; }, scan_tmp.i, (int *)nullptr);
         const int new_in = exc > 0 ? exc : 0;
         dirty = new_in > fm;                               // kstart passed this thread's first match: its walk must be redone
         ks_in = new_in > ks_in ? new_in : ks_in;
