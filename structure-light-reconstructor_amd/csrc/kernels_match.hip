@@ -15,6 +15,17 @@
 #include "slr_device.hpp"
 
 #include <hipcub/hipcub.hpp>
+
+// stage ablation of the match kernels (profiles/k4_stages.sh): "leave after stage N, outputs are not written".  Only builds with
+// -DSLR_DEBUG_HOOKS contain the exits; the production kernels carry none of them.
+#if defined(SLR_DEBUG_HOOKS)
+#define SLR_K4_STOP_AT(n) do { if (stop == (n)) return; } while (0)
+#define SLR_K4_STOP_AT5(best0) do { if (stop == 5) { if ((best0) == 12345678) has[0] = 1; return; } } while (0)
+#else
+#define SLR_K4_STOP_AT(n) do { (void)stop; } while (0)
+#define SLR_K4_STOP_AT5(best0) do { (void)stop; } while (0)
+#endif
+
 #include <math.h>
 #include <stdlib.h>
 
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
 #pragma unroll
     for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
     __syncthreads();
-    if (stop == 1) return;
+    SLR_K4_STOP_AT(1);
 
     // A. distinct values and their smallest column
     unsigned slot[IPT];                                  // hash slot of this pixel's value; kEmpty = not a candidate
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     for (int i = 0; i < IPT; i++)
         if (slot[i] != kEmpty && sh.t.mink[slot[i]] == (unsigned)(k0 + i)) repmask |= 1u << i;
     __syncthreads();                                     // the table is dead from here on
-    if (stop == 2) return;
+    SLR_K4_STOP_AT(2);
 
     // B. counting sort of the representatives by phase bin
 #pragma unroll
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
         if (repmask & (1u << i))
             sh.b.pk[sh.b.binstart[slot[i] >> 16] + (slot[i] & 0xFFFFu)] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
     __syncthreads();
-    if (stop == 4) return;
+    SLR_K4_STOP_AT(4);
 
     // queries: exact reference predicate over the <= 3-bin candidate window, smallest column wins
     int best[IPT];
@@ -440,7 +451,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
         }
         best[i] = bk == 0xFFFFFFFFu ? -1 : (int)bk;
     }
-    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
+    SLR_K4_STOP_AT5(best[0]);
     k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
 }
 
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
 #pragma unroll
     for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
     __syncthreads();
-    if (stop == 1) return;
+    SLR_K4_STOP_AT(1);
 
     // A. distinct values and their smallest column (as mf_match_binned_kernel; the four first probes are independent LDS
     //    atomics in flight together, a collision continues in the loop)
@@ -589,7 +600,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     for (int i = 0; i < IPT; i++)
         if (cand[i] && mk4[i] == (unsigned)(k0 + i)) repmask |= 1u << i;
     __syncthreads();                                     // the whole table is dead from here on
-    if (stop == 2) return;
+    SLR_K4_STOP_AT(2);
 
     // B. counting sort of the representatives by phase bin
     unsigned bin[IPT], rank[IPT];
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         }
     }
     __syncthreads();
-    if (stop == 4) return;
+    SLR_K4_STOP_AT(4);
 
     // queries: the reference's predicate on the pairs of bins [b-1, b+1] (and a few neighbours), smallest column wins
     int best[IPT];
@@ -652,7 +663,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         }
         best[i] = (int)bk;                               // 0xFFFFFFFF == -1: no match
     }
-    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
+    SLR_K4_STOP_AT5(best[0]);
     if (!inrow) return;
 
     // triangulation (mfreconstruct.cpp:297-326), branch-free for the 4 pixels
@@ -953,10 +964,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         keys[i] = ok ? ((((unsigned)phase_bin(pr[i]) << 4) | h4) << 16) | (unsigned)(k0 + i) : 0xFFFFFFFFu;
         phR[k0 + i] = pr[i];
     }
-    if (stop == 1) return;
+    SLR_K4_STOP_AT(1);
     Sort(sh.sort).Sort(keys, 16, 32);
     __syncthreads();                                     // phR visible; everybody is done with sh.sort
-    if (stop == 2) return;
+    SLR_K4_STOP_AT(2);
     unsigned phb[IPT];                                   // phase bits of the sorted items (0xFFFFFFFF = none)
 #pragma unroll
     for (int i = 0; i < IPT; i++) phb[i] = keys[i] != 0xFFFFFFFFu ? __float_as_uint(phR[keys[i] & 0xFFFFu]) : 0xFFFFFFFFu;
@@ -981,7 +992,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     for (int b = tid; b <= kBins; b += BLOCK) binfirst[b] = 0xFFFFu;
     __syncthreads();
     const int nd = n_distinct;
-    if (stop == 3) return;
+    SLR_K4_STOP_AT(3);
 
     // Bin index over the distinct values: bin(phi) = clamp(floor((phi + 512) * 4)) is monotone and two values
     // closer than 0.1001 land at most one bin apart, so bins [b-1, b+1] of phiL hold a superset of its
@@ -1016,7 +1027,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
     }
     __syncthreads();
 
-    if (stop == 4) return;
+    SLR_K4_STOP_AT(4);
     // queries: exact reference predicate over the <= 3-bin candidate window, smallest column wins
     int best[IPT];
     int qi0[IPT], qi1[IPT];
@@ -1044,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         best[i] = bk == 0xFFFFFFFFu ? -1 : (int)bk;
     }
 
-    if (stop == 5) { if (best[0] == 12345678) has[0] = 1; return; }
+    SLR_K4_STOP_AT5(best[0]);
     k4_emit<IPT>(best, base, k0, row, W, vec, cal, undL, undRx, xyz, has, match_k);
 }
 

@@ -746,7 +746,9 @@ struct DmaDecode {
         // lockstep (all reading, then all blending); with it one runs ahead and the LDS and VALU work of different waves
         // overlap (157 -> 150 us per pair launch; priority by wave or by workgroup, or only around the read issue: 154-156)
         __builtin_amdgcn_s_setprio(1);
-        dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
+        // (the (G2, G4) phases take the planes in the other order: n = G4 - G2 comes out of the subtraction itself)
+        if constexpr (P >= 2 && (P & 1) == 0) dma_differences<PX, img1, img0, (unsigned)RS>(mode, tap, qbase, second, sd);
+        else dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
         __builtin_amdgcn_s_setprio(0);
 #endif
         if (P == 1) sc.publish(ticket);                               // (the ticket has had the tap loop to arrive)
@@ -763,7 +765,7 @@ struct DmaDecode {
 #pragma unroll
             for (int q = 0; q < PX; q++) {
                 int nz;
-                const int Pw = wrapped_nd_q24(-sd[q], dd[q], lut, nz);   // n = G4 - G2
+                const int Pw = wrapped_nd_q24(sd[q], dd[q], lut, nz);    // sd = n = G4 - G2 (see above), dd = d = G1 - G3
                 if constexpr (HASVALID) { if (nz == 0) ok &= ~(1u << q); }  // Q5 rule: an undefined P makes the pixel invalid
                 if constexpr (P == 2) { Pk[q] = Pw; if constexpr (!HASVALID) pm[q] = pm[q] > Pw ? pm[q] : Pw; }
                 else if constexpr (P == 4) { F12[q] = pair_q24(Pk[q], Pw); Pk[q] = Pw; if constexpr (!HASVALID) pm[q] = pm[q] > Pw ? pm[q] : Pw; }
