@@ -638,6 +638,7 @@ def main():
                 ent.update({"form_selected": [i["mf_form"] for i in info], "nofit_tiles": [i["dma_nofit_tiles"] for i in info],
                             "dma_tiles": info[0]["dma_tiles"], "quads_by_class": [i["quads_by_class"] for i in info],
                             "waves_by_mode": [i["waves_by_mode"] for i in info], "lds_nofit_tiles": [i["lds_nofit_tiles"] for i in info],
+                            "split_tile_extra_entries": [i["dma_extra_entries"] for i in info],
                             "decode_us_per_frame": round(per_frame_us, 1),
                             "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
             except Exception as e:                          # never break the bench line

@@ -158,9 +158,11 @@ int slr_init_rectify_maps(slr_ctx *ctx, int cam, const double M[9], const double
 /* What the installed maps of `cam` mean for the fused rectify + decode kernels (they pick their form per call from this):
  *   mf_form          the SLR_OPT_RECT_DECODE_ALGO value the multi-frequency decode resolves to for these maps under the current
  *                    options (7 = LDS-DMA form; 5 / 6 = round-1 LDS tiles, which fall back per tile to a gather)
- *   dma_tiles / dma_nofit_tiles   tiles of the LDS-DMA form's shape, and how many of them have a source box larger than the
- *                    form holds: those are rewritten by a gather pass behind the main kernel; beyond a quarter of the tiles auto
- *                    does not use form 7 for these maps; 0xFFFFFFFF: no tables (W % 16 != 0)
+ *   dma_tiles / dma_nofit_tiles   tiles of the LDS-DMA form's shape, and how many of them the form cannot hold even in parts:
+ *                    a tile whose source box is larger than the LDS image (keystone corners) is decoded in wave-aligned halves,
+ *                    quarters, ... (dma_extra_entries counts the extra parts); what no split makes fit is rewritten by a gather
+ *                    pass behind the main kernel; beyond a quarter of the tiles auto does not use form 7 for these maps;
+ *                    0xFFFFFFFF: no tables (W % 16 != 0)
  *   quads_by_class   4-pixel quads whose taps fit one 8-byte window of 2 source rows / of 3 rows / neither (fitting tiles)
  *   waves_by_mode    (tile, wave) pairs decoded in the two-row / three-row / per-pixel read mode (the three-row mode costs
  *                    ~27 % more instructions, the per-pixel one ~4x the LDS reads)
@@ -170,6 +172,7 @@ typedef struct slr_rectify_info {
     unsigned dma_tiles, dma_nofit_tiles;
     unsigned quads_by_class[3], waves_by_mode[3];
     unsigned lds_nofit_tiles[2];
+    unsigned dma_extra_entries;    /* extra parts of tiles that the LDS-DMA form decodes in wave-aligned halves / quarters / ... */
 } slr_rectify_info;
 int slr_get_rectify_info(slr_ctx *ctx, int cam, slr_rectify_info *out);
 /* read back the maps currently installed for `cam` (host or device destination) */

@@ -67,7 +67,7 @@ class BatchDesc(C.Structure):
 class RectifyInfo(C.Structure):
     _fields_ = [("W", C.c_int), ("H", C.c_int), ("mf_form", C.c_int), ("dma_shape", C.c_int), ("dma_depth", C.c_int),
                 ("dma_tiles", C.c_uint), ("dma_nofit_tiles", C.c_uint), ("quads_by_class", C.c_uint * 3),
-                ("waves_by_mode", C.c_uint * 3), ("lds_nofit_tiles", C.c_uint * 2)]
+                ("waves_by_mode", C.c_uint * 3), ("lds_nofit_tiles", C.c_uint * 2), ("dma_extra_entries", C.c_uint)]
 
 
 MODE_GRAY, MODE_GE, MODE_MF = 0, 1, 2
@@ -291,7 +291,7 @@ class Context:
         return {"mf_form": info.mf_form, "dma_shape": info.dma_shape, "dma_depth": info.dma_depth, "dma_tiles": info.dma_tiles,
                 "dma_nofit_tiles": None if info.dma_nofit_tiles == 0xFFFFFFFF else info.dma_nofit_tiles,
                 "quads_by_class": list(info.quads_by_class), "waves_by_mode": list(info.waves_by_mode),
-                "lds_nofit_tiles": list(info.lds_nofit_tiles)}
+                "lds_nofit_tiles": list(info.lds_nofit_tiles), "dma_extra_entries": info.dma_extra_entries}
 
     def get_rectify_maps(self, cam, W, H):
         xy = np.empty((H, W, 2), np.int16)

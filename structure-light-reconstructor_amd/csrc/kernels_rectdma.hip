@@ -87,6 +87,17 @@ static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape ==
 //   A zero-sample pixel inside a class 0 / 1 quad carries the quad's base address (r0, c0) in [12:2]: entry 0 always yields it.
 // box table: int4 per tile = x0 (multiple of 16, may be negative), y0, chunks per row, rows; z == 0: nothing to fetch
 constexpr unsigned kDmaZeroEntry = 1024u << 18;
+// An ENTRY of the tile tables is what a workgroup decodes in one go: a whole tile -- or, where the tile's source box is larger than
+// the LDS image (the corner tiles of a keystone map), a PART of it: the waves of a workgroup own fixed blocks of the tile
+// (DmaGeom::quad_row / quad_col), so a part is a contiguous group of waves (halves, quarters, ... single waves), has its own,
+// smaller box, and is decoded by its waves alone while the others only keep the barriers and fetch their chunks.  Entry t < T is
+// tile t (or its first part); the other parts take entries T, T + 1, ... in allocation order (an atomic counter, at most T / 2
+// of them).  A tile that no split makes fit goes to the gather fix-up list.
+// box int4 of an entry: x0 (multiple of 16, may be negative), y0, z = chunks per row | tx << 8, w = rows | ty << 8 | wave mask << 24;
+// chunks == 0: nothing to fetch; mask == 0: an unused extra entry (the table is zeroed first).
+constexpr int kDmaStatExtras = 7;                            // statistics word: extra entries allocated (may overshoot the capacity)
+__device__ __host__ constexpr unsigned dma_extra_capacity(unsigned T) { return T / 2; }
+
 template <int TW, int TH, int NT>
 __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
                                                        int W, int H, int tiles_x, int4 *__restrict__ boxes,
@@ -94,8 +105,11 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
                                                        unsigned *__restrict__ nofit_list)
 {
     typedef DmaGeom<TW, TH, NT> Gm;
-    __shared__ int red[Gm::NWAVES][4];
-    __shared__ int sbox[3];
+    constexpr int NW = Gm::NWAVES;
+    __shared__ int red[NW][4];
+    __shared__ int spart[NW][4];                             // per part: x0, y0, fits, entry
+    __shared__ int slevel;
+    const unsigned T = gridDim.x;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int sxs[Gm::PX], sys[Gm::PX];
@@ -127,28 +141,57 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < Gm::NWAVES; w++) {
-            mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
-            mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
-        }
-        int4 b = make_int4(0, 0, 0, 0);
-        int fits = 1;
-        if (mnx <= mxx) {
-            b.x = mnx & ~15;                                 // 16-byte aligned origin (also for negative x)
-            b.y = mny;
-            b.z = (((mxx + 1) - b.x) >> 4) + 1;              // chunks covering x0 .. mxx+1
-            b.w = (mxy + 1) - mny + 1;                       // rows y0 .. mxy+1
-            fits = b.z <= Gm::CMAX && b.w <= Gm::BHMAX;
-            if (!fits) {                                     // decoded by the fix-up pass (mf_rect_fixup_kernel): nothing to fetch here
-                nofit_list[atomicAdd(nofit, 1u)] = blockIdx.x;
-                b.z = 0; b.w = 0;
+        // the box of waves [w0, w1): z = 0 when they sample nothing; returns whether it fits the LDS image
+        auto part_box = [&](int w0, int w1, int4 &b) -> bool {
+            int ax = 0x7FFFFFFF, bx = -0x7FFFFFFF, ay = 0x7FFFFFFF, by = -0x7FFFFFFF;
+            for (int w = w0; w < w1; w++) {
+                ax = red[w][0] < ax ? red[w][0] : ax; bx = red[w][1] > bx ? red[w][1] : bx;
+                ay = red[w][2] < ay ? red[w][2] : ay; by = red[w][3] > by ? red[w][3] : by;
+            }
+            b = make_int4(0, 0, 0, 0);
+            if (ax > bx) return true;
+            b.x = ax & ~15;                                  // 16-byte aligned origin (also for negative x)
+            b.y = ay;
+            b.z = (((bx + 1) - b.x) >> 4) + 1;               // chunks covering x0 .. max sx + 1
+            b.w = (by + 1) - ay + 1;                         // rows y0 .. max sy + 1
+            return b.z <= Gm::CMAX && b.w <= Gm::BHMAX;
+        };
+        int4 b;
+        int level = 1;                                       // parts the tile is decoded in; 0: the gather fix-up
+        if (!part_box(0, NW, b)) {
+            level = 0;
+            for (int L = 2; L <= NW && level == 0; L *= 2) {
+                bool all = true;
+                for (int p = 0; p < L && all; p++) all = part_box(p * (NW / L), (p + 1) * (NW / L), b);
+                if (all) level = L;
             }
         }
-        boxes[blockIdx.x] = b;
-        sbox[0] = b.x; sbox[1] = b.y; sbox[2] = fits;
+        unsigned base = 0;
+        if (level > 1) {
+            base = atomicAdd(nofit + kDmaStatExtras, (unsigned)(level - 1));
+            if (base + (unsigned)(level - 1) > dma_extra_capacity(T)) level = 0;     // (the table is full: its slots stay unused entries)
+        }
+        if (level == 0) {                                    // rewritten by the fix-up pass (mf_rect_fixup_kernel): nothing to fetch here
+            nofit_list[atomicAdd(nofit, 1u)] = blockIdx.x;
+            boxes[blockIdx.x] = make_int4(0, 0, tx << 8, ty << 8 | (int)(((1u << NW) - 1u) << 24));
+            spart[0][0] = 0; spart[0][1] = 0; spart[0][2] = 0; spart[0][3] = (int)blockIdx.x;
+        } else {
+            for (int p = 0; p < level; p++) {
+                const int w0 = p * (NW / level), w1 = (p + 1) * (NW / level);
+                (void)part_box(w0, w1, b);
+                const unsigned ent = p == 0 ? blockIdx.x : T + base + (unsigned)(p - 1);
+                const unsigned mask = ((1u << (w1 - w0)) - 1u) << w0;
+                spart[p][0] = b.x; spart[p][1] = b.y; spart[p][2] = 1; spart[p][3] = (int)ent;
+                b.z |= tx << 8; b.w |= ty << 8 | (int)(mask << 24);
+                boxes[ent] = b;
+            }
+        }
+        slevel = level;
     }
     __syncthreads();
-    const int x0 = sbox[0], y0 = sbox[1], fits = sbox[2];
+    const int level = slevel, part = level > 1 ? wv / (NW / level) : 0;
+    const int x0 = spart[part][0], y0 = spart[part][1], fits = spart[part][2];
+    const size_t ent = (size_t)(unsigned)spart[part][3];
     unsigned tcls = 0;                                      // the thread's read class over its quads (what dma_tap_setup sees)
 #pragma unroll
     for (int p = 0; p < Gm::NQ; p++) {
@@ -194,7 +237,7 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             }
             if (i == 0) e |= (cls & 1u) << 15;
             if (i == 1) e |= (cls >> 1) << 15;
-            digest[(size_t)blockIdx.x * (TW * TH) + threadIdx.x * Gm::PX + q] = e;
+            digest[ent * (TW * TH) + threadIdx.x * Gm::PX + q] = e;      // (a part's digest holds its own waves' slots only)
         }
     }
     if (fits) {                                             // ... and waves per read mode (the wave-uniform choice of the decode)
@@ -208,14 +251,17 @@ static size_t dma_tile_count(int W, int H, int shape)
     const int tw = dma_shape_tw(shape), th = dma_shape_th(shape);
     return (size_t)((W + tw - 1) / tw) * ((H + th - 1) / th);
 }
-static size_t dma_digest_offset(int W, int H, int shape) { return (dma_tile_count(W, H, shape) * sizeof(int4) + 255) & ~(size_t)255; }
+// entries the tables have room for: the tiles + the extra parts of split tiles
+static size_t dma_entry_capacity(int W, int H, int shape) { const size_t T = dma_tile_count(W, H, shape); return T + dma_extra_capacity((unsigned)T); }
+static size_t dma_digest_offset(int W, int H, int shape) { return (dma_entry_capacity(W, H, shape) * sizeof(int4) + 255) & ~(size_t)255; }
 static size_t dma_nofit_offset(int W, int H, int shape)
 {
-    return dma_digest_offset(W, H, shape) + dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+    return dma_digest_offset(W, H, shape) + dma_entry_capacity(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
 }
 static size_t dma_list_offset(int W, int H, int shape) { return dma_nofit_offset(W, H, shape) + 256; }     // tiles that do not fit
 size_t dma_tiles_bytes(int W, int H, int shape) { return dma_list_offset(W, H, shape) + dma_tile_count(W, H, shape) * sizeof(unsigned); }
 size_t dma_tile_count_of(int W, int H, int shape) { return dma_tile_count(W, H, shape); }
+unsigned dma_extra_entries_capacity(int W, int H, int shape) { return dma_extra_capacity((unsigned)dma_tile_count(W, H, shape)); }
 
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
                             unsigned *nofit_host, hipStream_t s)
@@ -226,6 +272,8 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
     unsigned *nofit = reinterpret_cast<unsigned *>(b + dma_nofit_offset(W, H, shape));
     unsigned *nofit_list = reinterpret_cast<unsigned *>(b + dma_list_offset(W, H, shape));
     hipError_t e = hipMemsetAsync(nofit, 0, kDmaTileStats * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(boxes, 0, dma_entry_capacity(W, H, shape) * sizeof(int4), s);     // (unused extra entries: no waves, nothing to fetch)
     if (e != hipSuccess) return e;
     const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
     const dim3 grid((unsigned)dma_tile_count(W, H, shape));
@@ -249,6 +297,7 @@ struct DmaJob {
     const int4 *boxes;
     const unsigned *digest;
     unsigned digest_bytes;
+    unsigned entries;            // tiles + the extra parts of split tiles (dma_tiles_kernel)
     float *phase;
     uint8_t *valid;              // null: the flag is folded into the phase (NaN), see launch_mf_decode
 };
@@ -496,10 +545,28 @@ __device__ __host__ constexpr int dma_wait_count(int p)
 constexpr int kSubBands = 4;
 struct DmaPool {
     int pb;                              // tiles per band
-    int per;                             // pool-local indices: kSubBands * pb
-    __device__ __host__ static DmaPool of(int T) { DmaPool p; p.pb = (T + 8 * kSubBands - 1) / (8 * kSubBands); p.per = kSubBands * p.pb; return p; }
-    // pool-local index l of XCD x -> tile (>= T: beyond the image, and so is every larger l)
-    __device__ int tile(int x, int l) const { const int k = l / pb; return (k * 8 + x) * pb + (l - k * pb); }
+    int per;                             // pool-local indices of a whole pool: kSubBands * pb
+    int T, E;                            // tiles; entries (tiles + the extra parts of split tiles, see dma_tiles_kernel)
+    int per_x;                           // ... of THIS XCD's pool that are tiles of the image (the last band may be short)
+    __device__ __host__ static DmaPool of(int T, int E = 0, int x = 0)
+    {
+        DmaPool p;
+        p.pb = (T + 8 * kSubBands - 1) / (8 * kSubBands); p.per = kSubBands * p.pb; p.T = T; p.E = E > T ? E : T;
+        p.per_x = 0;
+        for (int k = 0; k < kSubBands; k++) {
+            const int left = T - (k * 8 + x) * p.pb;
+            p.per_x += left < 0 ? 0 : left > p.pb ? p.pb : left;
+        }
+        return p;
+    }
+    // pool-local index l of XCD x -> entry, or -1 behind the pool's last one (and behind every larger l): first the pool's tiles
+    // band by band, then its share of the extra entries (dealt round-robin over the XCDs: parts of corner tiles, few)
+    __device__ int entry(int x, int l) const
+    {
+        if (l < per_x) { const int k = l / pb; return (k * 8 + x) * pb + (l - k * pb); }
+        const int e = T + (l - per_x) * 8 + x;
+        return e < E ? e : -1;
+    }
 };
 constexpr int kSchedStride = 16;                             // one counter per 64-byte line
 constexpr int kSchedDone = 2 * 8 * kSchedStride;             // sched[kSchedDone]: workgroups that have left the kernel
@@ -551,24 +618,31 @@ constexpr int kDmaSentinel = 0x7FFFFFFF;        // wrapped phase of the referenc
 struct DmaSched {
     unsigned *ctr;                       // the pool's ticket counter
     const int4 *boxes;                   // the camera's box table
-    int pitch, W, H, crow, ccol, xcd, T, first_ticket;
+    int pitch, W, H, crow, ccol, xcd, first_ticket;
     unsigned tkt_lds;                    // LDS address of the ticket slot
+    unsigned wave_bit;                   // 1 << (this wave's index): its bit in an entry's wave mask
     DmaPool pool;
     bool chunk_live;                     // this thread owns a chunk of the plane images
     bool wave0;
-    int nxt;                             // the tile after the current one (valid once pick_up() ran in the current tile)
+    int nxt;                             // the entry after the current one (valid once pick_up() ran in the current tile)
     bool has_next;
-    unsigned voff_next;                  // this thread's chunk of that tile's box
+    unsigned voff_next;                  // this thread's chunk of that entry's box
+    int nxt_ty, nxt_tx;                  // ... its tile
+    bool nxt_act;                        // ... and whether this wave decodes anything of it
 
-    // this thread's chunk of tile t's source box: the buffer offset its DMAs fetch from (or the out-of-range offset: zeros)
-    __device__ __forceinline__ unsigned box_voff(int t) const
+    // this thread's chunk of entry t's source box: the buffer offset its DMAs fetch from (or the out-of-range offset: zeros);
+    // also the entry's tile and whether this wave belongs to the entry's part
+    __device__ __forceinline__ unsigned box_voff(int t, int &ty, int &tx, bool &act) const
     {
         // t is wave-uniform: an explicit SCALAR load (hipcc emits a vector load for boxes[t], and waiting for that would drain the
         // vector-memory queue, i.e. the DMAs in flight)
         i32x4 b;
         asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(b) : "s"(boxes + __builtin_amdgcn_readfirstlane(t)) : "memory");
+        const int chunks = b.z & 0xFF, rows = b.w & 0xFF;
+        tx = (int)((unsigned)b.z >> 8); ty = (int)(((unsigned)b.w >> 8) & 0xFFFFu);
+        act = (((unsigned)b.w >> 24) & wave_bit) != 0u;
         const int gx = b.x + 16 * ccol, gy = b.y + crow;
-        const bool in = chunk_live && crow < b.w && ccol < b.z && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const bool in = chunk_live && crow < rows && ccol < chunks && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     }
     // wave 0, one phase before pick_up(): draw (before the phase's tap loop) and publish (behind it) the next tile's ticket
@@ -587,10 +661,11 @@ struct DmaSched {
         unsigned tk;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tk) : "v"(tkt_lds) : "memory");
         const int nl = first_ticket + (int)__builtin_amdgcn_readfirstlane(tk);
-        const int nt = pool.tile(xcd, nl);
-        has_next = nl < pool.per && nt < T;
-        nxt = has_next ? nt : 0;
-        voff_next = has_next ? box_voff(nxt) : kDmaInvalid;
+        const int ne = pool.entry(xcd, nl);
+        has_next = ne >= 0;
+        nxt = has_next ? ne : 0;
+        voff_next = box_voff(nxt, nxt_ty, nxt_tx, nxt_act);
+        if (!has_next) { voff_next = kDmaInvalid; nxt_act = false; }
     }
 };
 
@@ -784,17 +859,43 @@ struct DmaDecode {
         }
     }
 
-    template <int K0>
-    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur)
+    // phase P of an entry this wave decodes nothing of (the entry is a PART of a tile -- see dma_tiles_kernel -- and the wave is
+    // not among its waves): the barriers, its share of the DMAs, wave 0's ticket; the previous tile's outputs leave as usual
+    template <int K0, int P>
+    __device__ __forceinline__ void idle_phase(unsigned voff_cur)
     {
-        const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
-        phase<K0, 0>(ty, tx, voff_cur);
-        phase<K0, 1>(ty, tx, voff_cur);
-        phase<K0, 2>(ty, tx, voff_cur);
-        phase<K0, 3>(ty, tx, voff_cur);
-        phase<K0, 4>(ty, tx, voff_cur);
-        phase<K0, 5>(ty, tx, voff_cur);
-        phase<K0, 6>(ty, tx, voff_cur);
+        if (plane_wave) wait_vm<dma_wait_count<PX, A, PLANE_DMAS>(P)>();
+        else if (P == 0) wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");
+        unsigned ticket = 0;
+        if (P == 1) ticket = sc.draw();
+        if constexpr (P == 2) sc.pick_up();
+        if (P == kDmaDigestPhase) issue_digest((unsigned)sc.nxt, sc.has_next);
+        issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? sc.voff_next : voff_cur);
+        if constexpr (P == 0) { if (out_pending) flush(); out_pending = false; }
+        if (P == 1) sc.publish(ticket);
+    }
+
+    template <int K0>
+    __device__ __forceinline__ void tile(int ty, int tx, bool act, unsigned voff_cur)
+    {
+        if (act) {                       // (wave-uniform; every wave of a whole tile)
+            phase<K0, 0>(ty, tx, voff_cur);
+            phase<K0, 1>(ty, tx, voff_cur);
+            phase<K0, 2>(ty, tx, voff_cur);
+            phase<K0, 3>(ty, tx, voff_cur);
+            phase<K0, 4>(ty, tx, voff_cur);
+            phase<K0, 5>(ty, tx, voff_cur);
+            phase<K0, 6>(ty, tx, voff_cur);
+        } else {
+            idle_phase<K0, 0>(voff_cur);
+            idle_phase<K0, 1>(voff_cur);
+            idle_phase<K0, 2>(voff_cur);
+            idle_phase<K0, 3>(voff_cur);
+            idle_phase<K0, 4>(voff_cur);
+            idle_phase<K0, 5>(voff_cur);
+            idle_phase<K0, 6>(voff_cur);
+        }
     }
 };
 
@@ -848,8 +949,9 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     const int xcd = (int)(blockIdx.x & 7u), nbx = (int)(nblk >> 3);
     const int ji = (int)((blockIdx.x >> 3) % (unsigned)njobs), lb = (int)((blockIdx.x >> 3) / (unsigned)njobs);
     const int T = tiles_x * tiles_y;
-    d.sc.pool = DmaPool::of(T);
-    if (lb >= d.sc.pool.per || d.sc.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
+    d.sc.pool = DmaPool::of(T, (int)jobs.j[ji].entries, xcd);
+    int cur = d.sc.pool.entry(xcd, lb);
+    if (cur < 0) {                                          // (whole workgroup) nothing to do
         if (threadIdx.x == 0) dma_sched_leave(sched);
         return;
     }
@@ -874,8 +976,9 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
     d.sc.crow = chunk / Gm::CMAX; d.sc.ccol = chunk - d.sc.crow * Gm::CMAX;
     d.sc.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
-    d.sc.xcd = xcd; d.sc.T = T; d.sc.first_ticket = nbx;
+    d.sc.xcd = xcd; d.sc.first_ticket = nbx;
     d.sc.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    d.sc.wave_bit = 1u << __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     d.sc.tkt_lds = d.lds0 + (unsigned)Dec::TKT_OFF;
 
 #if defined(SLR_DMA_CLOCKPROBE)      // experiment: every workgroup's life on the 100 MHz constant clock (+ shader cycles) -> phase buffer of job 0
@@ -889,15 +992,16 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     d.rs_valid = __builtin_amdgcn_make_buffer_rsrc((void *)jobs.j[ji].valid, 0, HASVALID ? (int)((unsigned)W * (unsigned)H) : 0, 0x00020000);
     d.sc.boxes = jobs.j[ji].boxes;
     d.sc.ctr = sched + (ji * 8 + xcd) * kSchedStride;
-    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid;
-    int cur = d.sc.pool.tile(xcd, lb);
+    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid; d.sc.nxt_ty = d.sc.nxt_tx = 0; d.sc.nxt_act = false;
 #if defined(SLR_DMA_CLOCKPROBE)
     int it = 0;
 #define SLR_DMA_COUNT(x) ((x)++)
 #else
 #define SLR_DMA_COUNT(x) ((void)0)
 #endif
-    unsigned voff_cur = d.sc.box_voff(cur);
+    int cur_ty, cur_tx;
+    bool cur_act;
+    unsigned voff_cur = d.sc.box_voff(cur, cur_ty, cur_tx, cur_act);
     // prologue = what the last phases of a previous tile would have issued: digest, plane DMAs of phases 0 .. A-1
     d.out_pending = false;
     d.ok = 0;
@@ -909,10 +1013,11 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
         // the phase-0 buffer index advances by 7 mod D from tile to tile: D tiles per round of this loop
 #define SLR_DMA_TILE(K0)                                                                                       \
         {                                                                                                      \
-            d.template tile<K0>(cur, tiles_x, voff_cur);                                                       \
+            d.template tile<K0>(cur_ty, cur_tx, cur_act, voff_cur);                                            \
             SLR_DMA_COUNT(it);                                                                                 \
             if (!d.sc.has_next) break;                                                                         \
             cur = d.sc.nxt; voff_cur = d.sc.voff_next;                                                         \
+            cur_ty = d.sc.nxt_ty; cur_tx = d.sc.nxt_tx; cur_act = d.sc.nxt_act;                                \
         }
         SLR_DMA_TILE(0)
         SLR_DMA_TILE(7 % Dec::D)
@@ -1029,9 +1134,10 @@ static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, u
     j.base = pl.p[0]; j.pstride = (unsigned)st; j.fringe_skip = (unsigned)skip; j.stack_bytes = (unsigned)bytes;
     j.boxes = reinterpret_cast<const int4 *>(b);
     j.digest = reinterpret_cast<const unsigned *>(b + dma_digest_offset(W, H, shape));
-    const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+    const size_t dg = dma_entry_capacity(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
     if (dg >= (1ull << 31)) return false;
     j.digest_bytes = (unsigned)dg;
+    j.entries = (unsigned)dma_tile_count(W, H, shape);      // (+ the extra parts: the launcher adds them)
     j.phase = phase; j.valid = valid;
     return true;
 }
@@ -1080,8 +1186,10 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
     for (int c = 0; c < n; c++)
         if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
     DmaJobs j;
-    for (int c = 0; c < n; c++)
+    for (int c = 0; c < n; c++) {
         if (!dma_job(pl[c], pitch, W, H, phase[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
+        if (fix) j.j[c].entries += fix->extras[c];
+    }
     if (n == 1) j.j[1] = j.j[0];
     const bool hv = valid[0] != nullptr;
     for (int c = 1; c < n; c++) if ((valid[c] != nullptr) != hv) return hipSuccess;
@@ -1129,6 +1237,7 @@ struct GrayDmaJob {
     const int4 *boxes;
     const unsigned *digest;
     unsigned digest_bytes;
+    unsigned entries;            // tiles + the extra parts of split tiles (dma_tiles_kernel)
     int32_t *code_x, *code_y;    // code_y may be null
     uint8_t *valid;              // may be null (the consumer reads validity off code_x == -1)
     float *phase;                // hybrid stacks only (invalid pixels: NaN)
@@ -1295,7 +1404,7 @@ struct GrayDma {
     // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
     // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
     template <int B, bool FIRST>
-    __device__ __forceinline__ void phase(int k, int ty, int tx, unsigned voff_cur)
+    __device__ __forceinline__ void phase(int k, int ty, int tx, bool act, unsigned voff_cur)
     {
         if (plane_wave || FIRST) wait_vm<0>();              // (a wave without chunks only waits for its share of the digest)
         asm volatile("s_barrier" ::: "memory");
@@ -1309,6 +1418,15 @@ struct GrayDma {
         issue_planes(last ? 0 : k + 1, B ^ 1, last ? sc.voff_next : voff_cur);
         if constexpr (FIRST) {
             if (out_pending) flush();
+            out_pending = false;
+        }
+        // act (wave-uniform): this wave belongs to the part of the tile that the entry decodes (see dma_tiles_kernel); the other waves
+        // keep the barriers, fetch their chunks and (wave 0) draw the next ticket
+        if (!act) {
+            if constexpr (FIRST) sc.publish(ticket);
+            return;
+        }
+        if constexpr (FIRST) {
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
             mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
 #pragma unroll
@@ -1343,16 +1461,15 @@ struct GrayDma {
         if (HYB && last) { out_ty = ty; out_tx = tx; out_pending = true; }
     }
     template <int K>
-    __device__ __forceinline__ void tile(int cur, int tiles_x, unsigned voff_cur)
+    __device__ __forceinline__ void tile(int ty, int tx, bool act, unsigned voff_cur)
     {
-        const int ty = cur / tiles_x, tx = cur - ty * tiles_x;
-        phase<K, true>(0, ty, tx, voff_cur);
+        phase<K, true>(0, ty, tx, act, voff_cur);
         int k = 1;
         for (; k + 1 < nq; k += 2) {
-            phase<K ^ 1, false>(k, ty, tx, voff_cur);
-            phase<K, false>(k + 1, ty, tx, voff_cur);
+            phase<K ^ 1, false>(k, ty, tx, act, voff_cur);
+            phase<K, false>(k + 1, ty, tx, act, voff_cur);
         }
-        if (k < nq) phase<K ^ 1, false>(k, ty, tx, voff_cur);
+        if (k < nq) phase<K ^ 1, false>(k, ty, tx, act, voff_cur);
     }
 };
 
@@ -1396,8 +1513,9 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     const int xcd = (int)(blockIdx.x & 7u), nbx = (int)(nblk >> 3);
     const int ji = (int)((blockIdx.x >> 3) % (unsigned)njobs), lb = (int)((blockIdx.x >> 3) / (unsigned)njobs);
     const int T = tiles_x * tiles_y;
-    d.sc.pool = DmaPool::of(T);
-    if (lb >= d.sc.pool.per || d.sc.pool.tile(xcd, lb) >= T) {    // (whole workgroup) nothing to do
+    d.sc.pool = DmaPool::of(T, (int)jobs.j[ji].entries, xcd);
+    int cur = d.sc.pool.entry(xcd, lb);
+    if (cur < 0) {                                          // (whole workgroup) nothing to do
         if (threadIdx.x == 0) dma_sched_leave(sched);
         return;
     }
@@ -1429,14 +1547,16 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     const int chunk = Dec::SPLIT ? (int)threadIdx.x % Gm::NCH : (int)threadIdx.x;
     d.sc.crow = chunk / Gm::CMAX; d.sc.ccol = chunk - d.sc.crow * Gm::CMAX;
     d.sc.chunk_live = Dec::SPLIT || chunk < Gm::NCH;
-    d.sc.xcd = xcd; d.sc.T = T; d.sc.first_ticket = nbx;
+    d.sc.xcd = xcd; d.sc.first_ticket = nbx;
     d.sc.wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0u;
+    d.sc.wave_bit = 1u << __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     d.sc.tkt_lds = d.lds0 + (unsigned)Dec::TKT_OFF;
     d.sc.ctr = sched + (ji * 8 + xcd) * kSchedStride;
-    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid;
+    d.sc.nxt = 0; d.sc.has_next = false; d.sc.voff_next = kDmaInvalid; d.sc.nxt_ty = d.sc.nxt_tx = 0; d.sc.nxt_act = false;
 
-    int cur = d.sc.pool.tile(xcd, lb);
-    unsigned voff_cur = d.sc.box_voff(cur);
+    int cur_ty, cur_tx;
+    bool cur_act;
+    unsigned voff_cur = d.sc.box_voff(cur, cur_ty, cur_tx, cur_act);
     d.out_pending = false;
     d.issue_digest((unsigned)cur, true);                    // prologue = what the last phase of a previous tile would have issued
     d.issue_planes(0, 0, voff_cur);
@@ -1444,9 +1564,10 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     for (;;) {
 #define SLR_GDMA_TILE(K0)                                                                                      \
         {                                                                                                      \
-            d.template tile<K0>(cur, tiles_x, voff_cur);                                                       \
+            d.template tile<K0>(cur_ty, cur_tx, cur_act, voff_cur);                                            \
             if (!d.sc.has_next) break;                                                                         \
             cur = d.sc.nxt; voff_cur = d.sc.voff_next;                                                         \
+            cur_ty = d.sc.nxt_ty; cur_tx = d.sc.nxt_tx; cur_act = d.sc.nxt_act;                                \
         }
         SLR_GDMA_TILE(0)
         if constexpr (ODD) SLR_GDMA_TILE(1)
@@ -1471,9 +1592,10 @@ static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, 
     j.base = pl.p[0]; j.pstride = (unsigned)st; j.stack_bytes = (unsigned)bytes;
     j.boxes = reinterpret_cast<const int4 *>(b);
     j.digest = reinterpret_cast<const unsigned *>(b + dma_digest_offset(W, H, shape));
-    const size_t dg = dma_tile_count(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
+    const size_t dg = dma_entry_capacity(W, H, shape) * (size_t)(dma_shape_tw(shape) * dma_shape_th(shape)) * 4;
     if (dg >= (1ull << 31)) return false;
     j.digest_bytes = (unsigned)dg;
+    j.entries = (unsigned)dma_tile_count(W, H, shape);      // (+ the extra parts: the launcher adds them)
     j.code_x = cx; j.code_y = cy; j.valid = valid; j.phase = nullptr;
     return true;
 }
@@ -1522,8 +1644,10 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     if (ncol + nrow < 2) return hipSuccess;                 // (a tile needs two phases: the next digest arrives during the second)
     const int np = 2 + 2 * ncol + 2 * nrow;
     GrayDmaJobs j;
-    for (int c = 0; c < n; c++)
+    for (int c = 0; c < n; c++) {
         if (!gray_dma_job(pl[c], np, pitch, W, H, code_x[c], code_y[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
+        if (fix) j.j[c].entries += fix->extras[c];
+    }
     if (n == 1) j.j[1] = j.j[0];
     *done = true;
     constexpr int NPP = SLR_GRAY_DMA_NPP;
@@ -1581,6 +1705,7 @@ hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, 
         if (!gray_dma_job(pl[c], np, pitch, W, H, code_x[c], nullptr, nullptr, tiles[c], shape, j.j[c])) return hipSuccess;
         if (((uintptr_t)phase[c] % 16) != 0) return hipSuccess;
         j.j[c].phase = phase[c];
+        if (fix) j.j[c].entries += fix->extras[c];
     }
     if (n == 1) j.j[1] = j.j[0];
     *done = true;

@@ -135,6 +135,8 @@ DmaFixup dma_fixup_of(const slr_ctx *c, int a, int b)
     const int cams[2] = {a, b};
     for (int k = 0; k < 2; k++) {
         f.map_xy[k] = c->d_map_xy[cams[k]]; f.map_frac[k] = c->d_map_frac[cams[k]]; f.nofit[k] = c->dma_stats[cams[k]][0];
+        const unsigned cap = dma_extra_entries_capacity(c->map_w, c->map_h, c->opt_dma_shape), used = c->dma_stats[cams[k]][7];
+        f.extras[k] = used < cap ? used : cap;
     }
     return f;
 }
@@ -664,6 +666,8 @@ int slr_get_rectify_info(slr_ctx *c, int cam, slr_rectify_info *out)
         out->dma_tiles = (unsigned)dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape);
         out->dma_nofit_tiles = st[0];
         for (int k = 0; k < 3; k++) { out->quads_by_class[k] = st[1 + k]; out->waves_by_mode[k] = st[4 + k]; }
+        const unsigned cap = dma_extra_entries_capacity(c->map_w, c->map_h, c->opt_dma_shape);
+        out->dma_extra_entries = st[7] < cap ? st[7] : cap;
     } else {
         out->dma_nofit_tiles = 0xFFFFFFFFu;                 // no LDS-DMA tables for these maps (W % 16 != 0)
     }

@@ -114,11 +114,13 @@ hipError_t launch_tile_boxes(const int16_t *map_xy, const uint16_t *map_frac, in
 // `buf` (dma_tiles_bytes) and copies the number of tiles whose box does not fit the form to *nofit_host (valid after the
 // stream is synchronised).  launch_mf_rect_decode_dma: one camera (n == 1) or both cameras of a frame (n == 2) in one
 // launch; *done = false -> the stack layout / image width does not allow this form, nothing was launched.
-// nofit_host[kDmaTileStats]: 0 = tiles whose box does not fit; 1..3 = quads of read class 0 / 1 / 2 (fitting tiles); 4..6 = (tile,
-// wave) pairs whose wave-uniform read mode is 0 / 1 / 2; 7 = unused
+// nofit_host[kDmaTileStats]: 0 = tiles no split makes fit (the gather fix-up rewrites them); 1..3 = quads of read class 0 / 1 / 2;
+// 4..6 = (entry, wave) pairs whose wave-uniform read mode is 0 / 1 / 2; 7 = extra entries allocated for the parts of split tiles
+// (may overshoot dma_extra_entries_capacity: clamp)
 constexpr int kDmaTileStats = 8;
 size_t     dma_tiles_bytes(int W, int H, int shape);
 size_t     dma_tile_count_of(int W, int H, int shape);
+unsigned   dma_extra_entries_capacity(int W, int H, int shape);
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
                             unsigned *nofit_host, hipStream_t s);
 // the tiles whose source box does not fit the form (launch_dma_tiles counted and listed them) are rewritten by a gather pass
@@ -127,6 +129,7 @@ struct DmaFixup {
     const int16_t *map_xy[2];
     const uint16_t *map_frac[2];
     unsigned nofit[2];
+    unsigned extras[2];          // entries of the tile tables behind the tiles themselves: the extra parts of split tiles
 };
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,

@@ -386,7 +386,7 @@ def test_fullsize_verged_rig_maps_from_stereo_rectify(ctx, oracle, synth, scene,
     # no silent drop to round 1's forms: the LDS-DMA form keeps these maps, the few corner tiles whose boxes it does not hold
     # (keystone) go through its gather fix-up pass
     assert all(i["mf_form"] == 7 and 4 * i["dma_nofit_tiles"] <= i["dma_tiles"] for i in info), info
-    assert theta < 0.25 or sum(i["dma_nofit_tiles"] for i in info) > 0                       # (the fix-up pass did run)
+    assert sum(i["dma_extra_entries"] for i in info) > 0                                     # (tiles were decoded in parts)
     # the Gray fused decode on the same maps (its own fix-up kernel)
     g = synth.render_gray_stack(W, H, 1024, seed=9, noise=2, device=st.device)
     ncol = synth.gray_num_bits(1024)
