@@ -95,6 +95,7 @@ constexpr unsigned kDmaZeroEntry = 1024u << 18;
 // of them).  A tile that no split makes fit goes to the gather fix-up list.
 // box int4 of an entry: x0 (multiple of 16, may be negative), y0, z = chunks per row | tx << 8, w = rows | ty << 8 | wave mask << 24;
 // chunks == 0: nothing to fetch; mask == 0: an unused extra entry (the table is zeroed first).
+constexpr unsigned kDmaPromote = 2, kDmaNoPromote = 5;       // flagged pixel positions from which a wave's three-row quads become per-pixel quads
 constexpr int kDmaStatExtras = 7;                            // statistics word: extra entries allocated (may overshoot the capacity)
 __device__ __host__ constexpr unsigned dma_extra_capacity(unsigned T) { return T / 2; }
 
@@ -102,7 +103,7 @@ template <int TW, int TH, int NT>
 __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
                                                        int W, int H, int tiles_x, int4 *__restrict__ boxes,
                                                        unsigned *__restrict__ digest, unsigned *__restrict__ nofit,
-                                                       unsigned *__restrict__ nofit_list)
+                                                       unsigned *__restrict__ nofit_list, unsigned promote)
 {
     typedef DmaGeom<TW, TH, NT> Gm;
     constexpr int NW = Gm::NWAVES;
@@ -213,7 +214,25 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             const int q = 4 * p + i;
             if (fits && sxs[q] != 0x7FFFFFFF && (sxs[q] - x0) - 4 * c0 > 6) wide = true;
         }
-        const unsigned cls = wide ? 2u : (r1 > r0 ? 1u : 0u);
+        unsigned cls = wide ? 2u : (r1 > r0 ? 1u : 0u);
+        // The decode reads a wave's taps in ONE mode.  The three-row mode blends a third row for every pixel POSITION (0 .. 3 of a
+        // quad) at which some lane's pixel lies in its quad's lower row pair: +4 VALU instructions per position, plane pair and
+        // pixel, in a kernel that is bound by VALU issue.  The per-pixel mode costs LDS reads instead (32 instead of 12 dwords per
+        // quad and plane pair: another unit -- as long as not most waves do it).  From `promote` flagged positions on, the wave's
+        // straddling quads are filed as class 2, i.e. the wave takes the per-pixel mode.  launch_dma_tiles decides: on maps where
+        // few waves straddle (the near-identity bench maps: 27 %) promoting them is worth 2-3 % (120.2 -> 117.4 us); where most
+        // do (keystone maps of verged rigs: 59-66 %) the LDS unit saturates (0.1 rad rig 140 -> 158 us), so there nothing is
+        // promoted (profiles/exp/r03/b22_promote.txt).
+        {
+            unsigned flagged = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int q = 4 * p + i;
+                const bool low = cls == 1u && fits && sxs[q] != 0x7FFFFFFF && (sys[q] - y0) - r0 == 1;
+                flagged += __ballot(low) != 0ull ? 1u : 0u;
+            }
+            if (flagged >= promote && cls == 1u) cls = 2u;
+        }
         tcls = cls > tcls ? cls : tcls;
         if (fits) {                                         // statistics (slr_get_rectify_info): quads per class
             const unsigned long long b1 = __ballot(cls == 1u), b2 = __ballot(cls == 2u);
@@ -263,7 +282,7 @@ size_t dma_tiles_bytes(int W, int H, int shape) { return dma_list_offset(W, H, s
 size_t dma_tile_count_of(int W, int H, int shape) { return dma_tile_count(W, H, shape); }
 unsigned dma_extra_entries_capacity(int W, int H, int shape) { return dma_extra_capacity((unsigned)dma_tile_count(W, H, shape)); }
 
-hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
+hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape, bool promote,
                             unsigned *nofit_host, hipStream_t s)
 {
     char *b = reinterpret_cast<char *>(buf);
@@ -277,7 +296,7 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
     if (e != hipSuccess) return e;
     const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
     const dim3 grid((unsigned)dma_tile_count(W, H, shape));
-#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit, nofit_list)
+#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit, nofit_list, promote ? kDmaPromote : kDmaNoPromote)
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
     e = hipGetLastError();

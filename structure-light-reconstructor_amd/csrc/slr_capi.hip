@@ -618,8 +618,17 @@ static int build_dma_tiles(slr_ctx *c, int cam)
     c->dma_shape_built[cam] = -1;
     if (W % 16 != 0) return SLR_OK;                         // the form needs whole 16-byte chunks per row
     if (!c->d_dma_tiles[cam]) SLR_HIP(c, hipMalloc(&c->d_dma_tiles[cam], dma_tiles_bytes(W, H, c->opt_dma_shape)));
-    SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape,
+    // first with the three-row read mode for every wave whose quads straddle source rows; when few waves do (at most 35 %: mild
+    // maps), again with the heavily straddling ones promoted to per-pixel reads (launch_dma_tiles; the decision needs the count)
+    SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape, false,
                                 c->dma_stats[cam], c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    const unsigned long long waves = (unsigned long long)c->dma_stats[cam][4] + c->dma_stats[cam][5] + c->dma_stats[cam][6];
+    if (c->dma_stats[cam][5] > 0 && 100ull * c->dma_stats[cam][5] <= 35ull * waves) {
+        SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape, true,
+                                    c->dma_stats[cam], c->stream));
+        SLR_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->dma_shape_built[cam] = c->opt_dma_shape;
     return SLR_OK;
 }

@@ -122,6 +122,7 @@ size_t     dma_tiles_bytes(int W, int H, int shape);
 size_t     dma_tile_count_of(int W, int H, int shape);
 unsigned   dma_extra_entries_capacity(int W, int H, int shape);
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
+                            bool promote /* waves whose quads straddle source rows at several pixel positions read per pixel */,
                             unsigned *nofit_host, hipStream_t s);
 // the tiles whose source box does not fit the form (launch_dma_tiles counted and listed them) are rewritten by a gather pass
 // behind the main kernel: it needs the camera's original maps and the count
