@@ -5,9 +5,11 @@
 // Loader.  PNG inflate runs at ~200 MB/s per core: ~60 ms per 4096x3000 plane, 1.7 s for the 28 images of one
 // multi-frequency scan when done one file after the other as the reference does -- three orders of magnitude more than the GPU
 // path.  Here the files of a scan are decoded by a pool of host threads (one file per task) STRAIGHT INTO page-locked memory
-// (slr_host_alloc), plane after plane in the layout the C ABI stages from, and a series of scans is pipelined over two slots
-// (two contexts with SLR_OPT_ASYNC_HOST): while the GPU uploads / reconstructs / downloads scan i out of slot i % 2, the pool
-// decodes scan i + 1 into the other slot.  The steady state costs max(decode, upload + kernels + download) per scan.
+// (slr_host_alloc), plane after plane in the layout the C ABI stages from, and a series of scans is pipelined: two contexts with
+// SLR_OPT_ASYNC_HOST alternate on the GPU side (upload / reconstruct / download of scan i while scan i + 1 is enqueued), and
+// background threads inflate up to three scans AHEAD into four page-locked input slots (round 3; round 2 decoded one scan ahead:
+// one plane's inflate, ~60 ms on one core, was the time per scan).  The steady state costs max(decode / 3, upload + kernels +
+// download) per scan.
 #include "duke.hpp"
 
 #include <stdlib.h>
@@ -302,8 +304,8 @@ bool MFReconstruct::runReconstruction()
 }
 
 // A series of scans of one project (same cameras, same calibration): scan_sns[i] -> sink(sn, cloud); the sink owns the cloud.
-// Two slots alternate; see the file header.  false (and lastError) at the first scan that fails; clouds already handed to the
-// sink stay there.
+// Two contexts alternate on the GPU side, up to three scans are being inflated ahead of them; see the file header.  false (and
+// lastError) at the first scan that fails; clouds already handed to the sink stay there.
 bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, const std::function<bool(int, PointCloudImage *)> &sink)
 {
     if (!camerasLoaded || !sr) { lastError = "calibration not loaded"; return false; }
@@ -320,7 +322,32 @@ bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, co
     }
     const int W = cameraWidth, H = cameraHeight, n = numberOfImgs;
     const size_t plane = (size_t)W * H, cells = (size_t)scan_w * scan_h;
-    struct Slot { Pinned in, cloud; int sn = -1; bool busy = false; } slot[2];
+    // Input slots: page-locked buffers that background threads inflate scans into AHEAD of the GPU.  Two scans can be on the GPU
+    // (the two contexts), so with kInSlots buffers kInSlots - 1 scans are being decoded or wait decoded while one is consumed:
+    // the 28 files of ONE scan keep 28 cores busy for the ~60 ms one 12 MB plane takes to inflate, so a single scan ahead bounds
+    // the series at that time per scan (round 2: 100 ms); several scans ahead divide it.
+    constexpr int kInSlots = 4;
+    const int ns = two ? kInSlots : 1;
+    struct InSlot { Pinned buf; std::thread th; bool ok = false; std::string err; };
+    std::vector<InSlot> ins((size_t)ns);
+    struct Joiner {                                           // no path may leave a loader thread behind
+        std::vector<InSlot> &v;
+        ~Joiner() { for (auto &in : v) if (in.th.joinable()) in.th.join(); }
+    } joiner{ins};
+    auto start_load = [&](size_t i) {
+        InSlot &in = ins[i % (size_t)ns];
+        if (in.th.joinable()) in.th.join();
+        in.ok = false; in.err.clear();
+        const std::string pl = scan_prefix(scan_sns[i], 'L'), pr = scan_prefix(scan_sns[i], 'R');
+        in.th = std::thread([this, &in, pl, pr, n, W, H]() {
+            try {
+                const std::string prefix[2] = {pl, pr};
+                in.ok = load_pair(scanFolder, prefix, imgSuffix, n, W, H, in.buf, in.err);
+            } catch (const std::exception &ex) { in.ok = false; in.err = std::string("loader: ") + ex.what(); }
+            catch (...) { in.ok = false; in.err = "loader: unknown exception"; }
+        });
+    };
+    struct Slot { Pinned cloud; int sn = -1; bool busy = false; } slot[2];
     auto finish = [&](int s) -> bool {                       // wait for slot s and hand its cloud over
         if (!slot[s].busy) return true;
         slot[s].busy = false;
@@ -331,17 +358,22 @@ bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, co
         return sink(slot[s].sn, pc);
     };
     bool ok = true;
+    size_t next = 0;                                         // first scan whose decode has not been started
     for (size_t i = 0; i < scan_sns.size() && ok; i++) {
         const int s = (int)(i & 1) * (two ? 1 : 0);
-        ok = finish(s);                                      // scan i - 2 used this slot
+        ok = finish(s);                                      // scan i - 2 used this context: its input slot is free again
         if (!ok) break;
+        // input slots in use right now: scan i - 1 (on the GPU) and the scans i .. next - 1 already decoding
+        while (next < scan_sns.size() && next < i + (size_t)ns - (i > 0 ? 1 : 0) && (ns > 1 || next == i)) start_load(next++);
         Slot &sl = slot[s];
+        InSlot &in = ins[i % (size_t)ns];
+        if (in.th.joinable()) in.th.join();                  // (decoded while the GPU worked on the scans before)
+        if (!in.ok) { lastError = in.err; ok = false; break; }
         setScan(scan_sns[i]);
         if (!sl.cloud.ensure(cells * 13)) { lastError = "out of page-locked memory"; ok = false; break; }
-        if (!load_pair(scanFolder, imgPrefix, imgSuffix, n, W, H, sl.in, lastError)) { ok = false; break; }   // overlaps the other slot's GPU work
         if (!configure(cx[s], scan_sns[i])) { ok = false; break; }
         const uint8_t *pl[2][SLR_MF_PLANES];
-        for (int c = 0; c < 2; c++) for (int k = 0; k < SLR_MF_PLANES; k++) pl[c][k] = sl.in.u8() + ((size_t)c * n + k) * plane;
+        for (int c = 0; c < 2; c++) for (int k = 0; k < SLR_MF_PLANES; k++) pl[c][k] = in.buf.u8() + ((size_t)c * n + k) * plane;
         if (slr_reconstruct_mf_cloud(cx[s], pl[0], pl[1], W, W, H, blackThreshold, 1, scan_w, scan_h, (float *)sl.cloud.p,
                                      sl.cloud.u8() + cells * 12, SLR_MEM_HOST) != SLR_OK) {
             lastError = slr_last_error(cx[s]); warn("Reconstruct", lastError); ok = false; break;
