@@ -33,6 +33,11 @@ assert done == N, err.value
 t0 = time.perf_counter()
 done = host.duke_run_series(proj.encode(), 0, 1, SW, SH, W, H, 40, 0, b".png", None, None, None, err, 512)
 t_one = time.perf_counter() - t0                              # fixed cost (contexts, maps, tables, pinned buffers) + one scan
+NH = max(N // 2, 4)                                           # a shorter series that already pins every input slot
+t0 = time.perf_counter()
+done = host.duke_run_series(proj.encode(), 0, NH, SW, SH, W, H, 40, 0, b".png", None, None, None, err, 512)
+t_half = time.perf_counter() - t0
+assert done == NH, err.value
 t0 = time.perf_counter()
 for sn in range(N):
     es = np.zeros((SH, SW, 3), np.float32); ec = np.zeros((SH, SW), np.uint8)
@@ -47,6 +52,9 @@ for i in range(14):
 t_dec1 = (time.perf_counter() - t0) / 14
 print("series of %d: %.1f ms in all, a series of 1: %.1f ms -> %.1f ms per additional scan (steady state of the pipeline)" %
       (N, t_series * 1e3, t_one * 1e3, (t_series - t_one) / (N - 1) * 1e3))
+if N > NH:
+    print("series of %d: %.1f ms -> %.1f ms per scan between the two series lengths (every slot pinned in both)" %
+          (NH, t_half * 1e3, (t_series - t_half) / (N - NH) * 1e3))
 print("one by one: %.1f ms per scan (new objects, contexts and maps per scan, as slr_cli without --series)" % (t_single / N * 1e3))
 print("PNG inflate of one 4096x3000 plane on one core: %.1f ms -> 28 files / %d cores" % (t_dec1 * 1e3, os.cpu_count()))
 print("clouds identical: True; valid cells per scan:", [int((sc[k] > 0).sum()) for k in range(N)])

@@ -201,6 +201,8 @@ private:
     void setScan(int sn);
     bool configure(slr_ctx *c, int sn);
     slr_ctx *ctx2 = nullptr;
+    struct SeriesBuffers;                                    // page-locked input / output slots of runReconstructionSeries, kept
+    SeriesBuffers *series = nullptr;                         // across calls (pinning 4 x 344 MB costs more than decoding a scan)
     int scanSN = 0, numberOfImgs = 14, blackThreshold = 40, whiteThreshold = 0;
     int cameraWidth = 0, cameraHeight = 0, scan_w = 0, scan_h = 0;
     std::string savePath_, calibFolder[2], scanFolder[2], imgPrefix[2];

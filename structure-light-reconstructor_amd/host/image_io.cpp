@@ -7,6 +7,7 @@
 #include "duke.hpp"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -19,23 +20,6 @@ namespace {
 constexpr size_t kMaxFileBytes = (size_t)1 << 31;        // 2 GiB: nothing this path reads is larger
 constexpr long long kMaxPixels = 1ll << 28;              // 268 Mpixel (16384 x 16384)
 
-bool slurp(const std::string &path, std::vector<uint8_t> &out, std::string &err)
-{
-    FILE *f = fopen(path.c_str(), "rb");
-    if (!f) { err = "cannot open " + path; return false; }
-    bool ok = false;
-    if (fseek(f, 0, SEEK_END) == 0) {
-        const long n = ftell(f);
-        if (n >= 0 && (size_t)n <= kMaxFileBytes && fseek(f, 0, SEEK_SET) == 0) {
-            out.resize((size_t)n);
-            ok = n == 0 || fread(out.data(), 1, (size_t)n, f) == (size_t)n;
-        }
-    }
-    fclose(f);
-    if (!ok) err = "cannot read " + path;
-    return ok;
-}
-
 uint32_t be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
 bool dims_ok(long long w, long long h, int want_w, int want_h, std::string &err)
@@ -46,8 +30,9 @@ bool dims_ok(long long w, long long h, int want_w, int want_h, std::string &err)
 }
 
 // ---- PGM ---------------------------------------------------------------------------------------------------------------
-bool pgm_header(const std::vector<uint8_t> &buf, int &w, int &h, size_t &data_pos, std::string &err)
+bool pgm_header(const uint8_t *buf_p, size_t buf_n, int &w, int &h, size_t &data_pos, std::string &err)
 {
+    struct { const uint8_t *p; size_t n; size_t size() const { return n; } uint8_t operator[](size_t i) const { return p[i]; } } buf{buf_p, buf_n};
     size_t pos = 2;
     long long vals[3] = {0, 0, 0};
     for (int got = 0; got < 3;) {
@@ -77,14 +62,15 @@ int paeth(int a, int b, int c)
     return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
 }
 
-// chunk walk: IHDR first, every chunk's CRC verified, IDAT payloads concatenated
-bool png_chunks(const std::vector<uint8_t> &buf, PngInfo &info, std::vector<uint8_t> &idat, std::string &err)
+// chunk walk: IHDR first, every chunk's CRC verified, the IDAT payloads listed in file order (not copied)
+struct Span { const uint8_t *p; size_t n; };
+bool png_chunks(const uint8_t *buf, size_t size, PngInfo &info, std::vector<Span> &idat, std::string &err)
 {
     size_t pos = 8;
     bool have_ihdr = false, have_iend = false;
-    while (pos + 12 <= buf.size()) {
+    while (pos + 12 <= size) {
         const uint32_t len = be32(&buf[pos]);
-        if (len > 0x7FFFFFFFu || (size_t)len > buf.size() - pos - 12) { err = "PNG chunk runs past the end of the file"; return false; }
+        if (len > 0x7FFFFFFFu || (size_t)len > size - pos - 12) { err = "PNG chunk runs past the end of the file"; return false; }
         const uint8_t *type = &buf[pos + 4], *data = &buf[pos + 8];
         if ((uint32_t)crc32(crc32(0L, type, 4), data, len) != be32(data + len)) { err = "PNG chunk CRC mismatch"; return false; }
         if (!memcmp(type, "IHDR", 4)) {
@@ -95,7 +81,7 @@ bool png_chunks(const std::vector<uint8_t> &buf, PngInfo &info, std::vector<uint
             if (data[10] != 0 || data[11] != 0) { err = "unknown PNG compression / filter method"; return false; }
             have_ihdr = true;
         } else if (!have_ihdr) { err = "PNG does not start with IHDR"; return false; }
-        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+        else if (!memcmp(type, "IDAT", 4)) { if (len) idat.push_back(Span{data, (size_t)len}); }
         else if (!memcmp(type, "IEND", 4)) { have_iend = true; break; }
         else if (!(type[0] & 0x20)) { if (memcmp(type, "PLTE", 4)) { err = "unknown critical PNG chunk"; return false; } }
         pos += 12 + (size_t)len;
@@ -106,89 +92,159 @@ bool png_chunks(const std::vector<uint8_t> &buf, PngInfo &info, std::vector<uint
     return true;
 }
 
-// inflate exactly `want` bytes (more in the stream = corrupt; trailing bytes after the zlib stream are ignored, as libpng does)
-bool inflate_exact(const std::vector<uint8_t> &in, std::vector<uint8_t> &out, size_t want, std::string &err)
-{
-    out.resize(want + 1);                                // one spare byte detects an over-long stream
+// the zlib stream spread over the IDAT chunks, inflated a band of scanlines at a time: a 12-Mpixel plane never exists as
+// one filtered buffer (that buffer, freshly mapped per file by dozens of loader threads, cost more in page faults than
+// the inflate itself).  The stream must hold exactly the bytes IHDR announces: more or fewer = corrupt; bytes after the
+// end of the zlib stream are ignored, as libpng does.
+struct Inflater {
     z_stream z;
-    memset(&z, 0, sizeof z);
-    if (inflateInit(&z) != Z_OK) { err = "zlib init failed"; return false; }
-    z.next_in = const_cast<Bytef *>(in.data()); z.avail_in = (uInt)in.size();
-    z.next_out = out.data(); z.avail_out = (uInt)out.size();
-    const int r = inflate(&z, Z_FINISH);
-    const size_t got = z.total_out;
-    inflateEnd(&z);
-    if (r != Z_STREAM_END || got != want) { err = "PNG image data does not inflate to the size IHDR announces"; return false; }
-    out.resize(want);
-    return true;
-}
+    const std::vector<Span> &in;
+    size_t si = 0;
+    bool live = false, ended = false;
+    explicit Inflater(const std::vector<Span> &spans) : in(spans) { memset(&z, 0, sizeof z); }
+    ~Inflater() { if (live) inflateEnd(&z); }
+    bool start() { live = inflateInit(&z) == Z_OK; return live; }
+    size_t read(uint8_t *out, size_t n)                      // up to n bytes; fewer only at the end of the stream (or on an error)
+    {
+        size_t done = 0;
+        while (done < n && !ended) {
+            if (z.avail_in == 0) {
+                if (si == in.size()) break;
+                z.next_in = const_cast<Bytef *>(in[si].p);
+                z.avail_in = (uInt)in[si].n;                 // (a chunk is < 2^31 bytes: png_chunks)
+                si++;
+            }
+            const size_t ask = n - done < ((size_t)1 << 30) ? n - done : ((size_t)1 << 30);
+            z.next_out = out + done; z.avail_out = (uInt)ask;
+            const int r = inflate(&z, Z_NO_FLUSH);
+            done += ask - z.avail_out;
+            if (r == Z_STREAM_END) ended = true;
+            else if (r != Z_OK && r != Z_BUF_ERROR) break;
+            else if (r == Z_BUF_ERROR && z.avail_in != 0 && z.avail_out != 0) break;
+        }
+        return done;
+    }
+    bool finished()                                          // true when not one byte more comes out and the stream closed properly
+    {
+        uint8_t spare;
+        return read(&spare, 1) == 0 && ended;
+    }
+};
 
-// one (sub-)image of pw x ph pixels: undo the scanline filters in place, then grey-convert into dst at
-// (x0 + i*dx, y0 + j*dy).  Returns the bytes consumed from `raw`.
-size_t png_pass(uint8_t *raw, const PngInfo &f, int pw, int ph, uint8_t *dst, int x0, int y0, int dx, int dy)
+// `rows` scanlines of a (sub-)image pw pixels wide, filtered, at `raw`: undo the filters in place (`prev` = the line above,
+// unfiltered, or null on the first line) and grey-convert into dst at (x0 + i*dx, y + j*dy).  Returns the last line.
+const uint8_t *png_rows(uint8_t *raw, const PngInfo &f, int pw, int rows, const uint8_t *prev, uint8_t *dst, int x0, int y, int dx, int dy)
 {
     const int bps = f.depth / 8, bpp = f.channels * bps;
     const size_t stride = (size_t)pw * bpp;
-    const uint8_t *prev = nullptr;
-    for (int j = 0; j < ph; j++) {
+    for (int j = 0; j < rows; j++) {
         uint8_t *line = raw + (stride + 1) * j;
         const int ft = line[0];
         uint8_t *cur = line + 1;
-        for (size_t i = 0; i < stride; i++) {
-            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev ? prev[i] : 0, c = (prev && i >= (size_t)bpp) ? prev[i - bpp] : 0;
-            int x = cur[i];
-            switch (ft) { case 1: x += a; break; case 2: x += b; break; case 3: x += (a + b) >> 1; break; case 4: x += paeth(a, b, c); break; default: break; }
-            cur[i] = (uint8_t)x;
+        const size_t head = stride < (size_t)bpp ? stride : (size_t)bpp;
+        switch (ft) {
+        case 1:
+            for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+            break;
+        case 2:
+            if (prev) for (size_t i = 0; i < stride; i++) cur[i] = (uint8_t)(cur[i] + prev[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + ((prev ? prev[i] : 0) >> 1));
+            if (prev) for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + ((cur[i - bpp] + prev[i]) >> 1));
+            else for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + (cur[i - bpp] >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < head; i++) cur[i] = (uint8_t)(cur[i] + paeth(0, prev ? prev[i] : 0, 0));
+            if (prev) for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - bpp], prev[i], prev[i - bpp]));
+            else for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - bpp], 0, 0));
+            break;
+        default: break;                                      // 0, and (as before) anything a corrupt file puts there
         }
-        uint8_t *out = dst + (size_t)(y0 + j * dy) * f.w + x0;
-        for (int i = 0; i < pw; i++) {
-            const uint8_t *p = cur + (size_t)i * bpp;
-            out[(size_t)i * dx] = f.channels <= 2 ? p[0] : (uint8_t)((p[0] * 4899 + p[bps] * 9617 + p[2 * bps] * 1868 + 8192) >> 14);
-        }
+        uint8_t *out = dst + (size_t)(y + j * dy) * f.w + x0;
+        if (bpp == 1 && dx == 1) memcpy(out, cur, (size_t)pw);
+        else
+            for (int i = 0; i < pw; i++) {
+                const uint8_t *p = cur + (size_t)i * bpp;
+                out[(size_t)i * dx] = f.channels <= 2 ? p[0] : (uint8_t)((p[0] * 4899 + p[bps] * 9617 + p[2 * bps] * 1868 + 8192) >> 14);
+            }
         prev = cur;
     }
-    return (stride + 1) * (size_t)ph;
+    return prev;
 }
 
-bool decode_png_into(const std::vector<uint8_t> &buf, int want_w, int want_h, uint8_t *dst, std::vector<uint8_t> *own, int &w, int &h,
+bool decode_png_into(const uint8_t *buf, size_t size, int want_w, int want_h, uint8_t *dst, std::vector<uint8_t> *own, int &w, int &h,
                      std::string &err)
 {
     PngInfo f;
-    std::vector<uint8_t> idat, raw;
-    if (!png_chunks(buf, f, idat, err) || !dims_ok(f.w, f.h, want_w, want_h, err)) return false;
+    std::vector<Span> idat;
+    if (!png_chunks(buf, size, f, idat, err) || !dims_ok(f.w, f.h, want_w, want_h, err)) return false;
     static const int ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
     const size_t bpp = (size_t)f.channels * (f.depth / 8);
-    size_t want = 0;
-    if (f.interlace) {
-        for (int p = 0; p < 7; p++) {
-            const int pw = (f.w - ax0[p] + adx[p] - 1) / adx[p], ph = (f.h - ay0[p] + ady[p] - 1) / ady[p];
-            if (pw > 0 && ph > 0) want += ((size_t)pw * bpp + 1) * ph;
-        }
-    } else want = ((size_t)f.w * bpp + 1) * f.h;
-    if (!inflate_exact(idat, raw, want, err)) return false;
+    const char *bad = "PNG image data does not inflate to the size IHDR announces";
     if (own) { own->resize((size_t)f.w * f.h); dst = own->data(); }
-    if (f.interlace) {
-        size_t off = 0;
-        for (int p = 0; p < 7; p++) {
-            const int pw = (f.w - ax0[p] + adx[p] - 1) / adx[p], ph = (f.h - ay0[p] + ady[p] - 1) / ady[p];
-            if (pw > 0 && ph > 0) off += png_pass(raw.data() + off, f, pw, ph, dst, ax0[p], ay0[p], adx[p], ady[p]);
+    Inflater inf(idat);
+    if (!inf.start()) { err = "zlib init failed"; return false; }
+    const size_t line = (size_t)f.w * bpp + 1;               // the widest scanline of any pass
+    constexpr size_t kBand = (size_t)256 << 10;              // filtered bytes in flight: L2-resident
+    const int band_rows = (int)(kBand / line > 0 ? kBand / line : 1);
+    std::vector<uint8_t> band(line * (size_t)band_rows), above(line);
+    const int passes = f.interlace ? 7 : 1;
+    for (int p = 0; p < passes; p++) {
+        const int x0 = f.interlace ? ax0[p] : 0, y0 = f.interlace ? ay0[p] : 0, dx = f.interlace ? adx[p] : 1, dy = f.interlace ? ady[p] : 1;
+        const int pw = (f.w - x0 + dx - 1) / dx, ph = (f.h - y0 + dy - 1) / dy;
+        if (pw <= 0 || ph <= 0) continue;
+        const size_t pline = (size_t)pw * bpp + 1;
+        const uint8_t *prev = nullptr;
+        for (int j = 0; j < ph; j += band_rows) {
+            const int rows = ph - j < band_rows ? ph - j : band_rows;
+            if (inf.read(band.data(), pline * rows) != pline * rows) { err = bad; return false; }
+            const uint8_t *last = png_rows(band.data(), f, pw, rows, prev, dst, x0, y0 + j * dy, dx, dy);
+            memcpy(above.data(), last, pline - 1);           // the band buffer is about to be overwritten
+            prev = above.data();
         }
-    } else png_pass(raw.data(), f, f.w, f.h, dst, 0, 0, 1, 1);
+    }
+    if (!inf.finished()) { err = bad; return false; }
     w = f.w; h = f.h;
     return true;
 }
 
+// a file's bytes, not zero-filled first (std::vector::resize would touch every page twice)
+struct FileBytes {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    ~FileBytes() { free(p); }
+};
+
+bool slurp(const std::string &path, FileBytes &out, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long n = ftell(f);
+        if (n >= 0 && (size_t)n <= kMaxFileBytes && fseek(f, 0, SEEK_SET) == 0) {
+            out.p = (uint8_t *)malloc((size_t)n + 1);
+            out.n = (size_t)n;
+            ok = out.p && (n == 0 || fread(out.p, 1, (size_t)n, f) == (size_t)n);
+        }
+    }
+    fclose(f);
+    if (!ok) err = "cannot read " + path;
+    return ok;
+}
+
 bool decode_any(const std::string &path, int want_w, int want_h, uint8_t *dst, std::vector<uint8_t> *own, int &w, int &h, std::string &err)
 {
-    std::vector<uint8_t> buf;
+    FileBytes buf;
     if (!slurp(path, buf, err)) return false;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (buf.size() >= 8 && !memcmp(buf.data(), sig, 8)) return decode_png_into(buf, want_w, want_h, dst, own, w, h, err);
-    if (buf.size() >= 3 && buf[0] == 'P' && buf[1] == '5') {
+    if (buf.n >= 8 && !memcmp(buf.p, sig, 8)) return decode_png_into(buf.p, buf.n, want_w, want_h, dst, own, w, h, err);
+    if (buf.n >= 3 && buf.p[0] == 'P' && buf.p[1] == '5') {
         size_t pos = 0;
-        if (!pgm_header(buf, w, h, pos, err) || !dims_ok(w, h, want_w, want_h, err)) return false;
-        if (own) { own->assign(buf.begin() + pos, buf.begin() + pos + (size_t)w * h); }
-        else memcpy(dst, buf.data() + pos, (size_t)w * h);
+        if (!pgm_header(buf.p, buf.n, w, h, pos, err) || !dims_ok(w, h, want_w, want_h, err)) return false;
+        if (own) { own->assign(buf.p + pos, buf.p + pos + (size_t)w * h); }
+        else memcpy(dst, buf.p + pos, (size_t)w * h);
         return true;
     }
     err = "not a PNG or binary PGM: " + path;

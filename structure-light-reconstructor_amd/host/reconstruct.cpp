@@ -2,22 +2,30 @@
 // the public call sequence of the reference; every per-pixel loop is ONE call into libslr_hip.so) and the scan-directory reader
 // in front of them (reconstruct.cpp:158-164, mfreconstruct.cpp:119-125).
 //
-// Loader.  PNG inflate runs at ~200 MB/s per core: ~60 ms per 4096x3000 plane, 1.7 s for the 28 images of one
+// Loader.  PNG inflate runs at ~300 MB/s per core: ~40 ms per 4096x3000 plane, 1.2 s for the 28 images of one
 // multi-frequency scan when done one file after the other as the reference does -- three orders of magnitude more than the GPU
 // path.  Here the files of a scan are decoded by a pool of host threads (one file per task) STRAIGHT INTO page-locked memory
 // (slr_host_alloc), plane after plane in the layout the C ABI stages from, and a series of scans is pipelined: two contexts with
-// SLR_OPT_ASYNC_HOST alternate on the GPU side (upload / reconstruct / download of scan i while scan i + 1 is enqueued), and
-// background threads inflate up to three scans AHEAD into four page-locked input slots (round 3; round 2 decoded one scan ahead:
-// one plane's inflate, ~60 ms on one core, was the time per scan).  The steady state costs max(decode / 3, upload + kernels +
-// download) per scan.
+// SLR_OPT_ASYNC_HOST alternate on the GPU side (upload / reconstruct / download of scan i while scan i + 1 is enqueued), and ONE
+// pool of as many threads as the process may run (cpu_budget(): affinity mask and cgroup quota, not the machine's core count)
+// drains the files of the next two or three scans in order into page-locked input slots.  The steady state costs
+// max(28 files x inflate / threads, upload + kernels + download) per scan: with a 16-CPU quota that is the inflate, ~72 ms.
 #include "duke.hpp"
 
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <fstream>
+#include <mutex>
 #include <sstream>
 #include <thread>
+
+#include <sched.h>
 
 namespace duke {
 
@@ -38,13 +46,45 @@ struct Pinned {
     uint8_t *u8() const { return (uint8_t *)p; }
 };
 
-unsigned loader_threads(int n)
+// CPUs this process can actually run on: the affinity mask and -- for work that goes on for longer than a scheduler period
+// (`sustained`: a series) -- the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us), not the core count of the machine: 84 inflate
+// threads under a 16-CPU quota are throttled and finish LATER than 16 are.  One scan's files fit inside one period's quota,
+// and a burst of 2 n threads does finish them sooner (measured: 70 ms vs 114 ms with 16), so one-shot loads ignore the quota.
+unsigned cpu_budget(bool sustained)
 {
     unsigned nt = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0 && (unsigned)c < nt) nt = (unsigned)c; }
+    long long quota = -1, period = 100000;
+    if (sustained) {
+        std::ifstream f("/sys/fs/cgroup/cpu.max");
+        std::string q;
+        if (f >> q >> period) { if (q != "max") quota = atoll(q.c_str()); }
+        else {
+            std::ifstream fq("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), fp("/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+            if (!(fq >> quota) || !(fp >> period)) quota = -1;
+        }
+    }
+    if (quota > 0 && period > 0) { const unsigned c = (unsigned)((quota + period - 1) / period); if (c >= 1 && c < nt) nt = c; }
+    return nt < 1 ? 1 : nt;
+}
+
+unsigned loader_threads(int n, bool sustained = false)
+{
+    unsigned nt = cpu_budget(sustained);
     if (const char *e = getenv("SLR_LOADER_THREADS")) nt = (unsigned)atoi(e);
     if (nt < 1) nt = 1;
     if (nt > (unsigned)n) nt = (unsigned)(n > 0 ? n : 1);
     return nt;
+}
+
+bool imread_scan_file(const std::string &stem, const std::string &suffix, int w, int h, uint8_t *out, std::string &err)
+{
+    std::string e1, e2;
+    if (imread_gray_into(stem + suffix, w, h, out, e1)) return true;
+    if (suffix != ".pgm" && imread_gray_into(stem + ".pgm", w, h, out, e2)) return true;
+    err = e1.compare(0, 11, "cannot open") == 0 ? "Scan Images not found! (" + stem + suffix + ")" : e1;
+    return false;
 }
 
 // n images <folder[cam]><prefix[cam]><i><suffix> per camera (".pgm" is tried when the configured suffix is missing) of w x h
@@ -63,11 +103,7 @@ bool load_stacks_into(const std::string folder[2], const std::string prefix[2], 
                 const int cam = t / n, i = t - cam * n;
                 std::ostringstream p;
                 p << folder[cam] << prefix[cam] << i;
-                std::string e1, e2;
-                uint8_t *out = dst + (size_t)t * w * h;
-                if (imread_gray_into(p.str() + suffix, w, h, out, e1)) continue;
-                if (suffix != ".pgm" && imread_gray_into(p.str() + ".pgm", w, h, out, e2)) continue;
-                errs[(size_t)t] = e1.compare(0, 11, "cannot open") == 0 ? "Scan Images not found! (" + p.str() + suffix + ")" : e1;
+                imread_scan_file(p.str(), suffix, w, h, dst + (size_t)t * w * h, errs[(size_t)t]);
             } catch (const std::exception &ex) {             // bad_alloc and the like must not leave a worker thread
                 errs[(size_t)t] = std::string("image decoder: ") + ex.what();
             } catch (...) {
@@ -86,6 +122,94 @@ bool load_stacks_into(const std::string folder[2], const std::string prefix[2], 
         if (!errs[(size_t)t].empty()) { err = errs[(size_t)t]; warn("Load Images", err); return false; }
     return true;
 }
+
+// The decoder of a series: `threads` workers drain ONE queue of files in the order the scans were announced, so the files of
+// scan i + 2 start the moment a worker runs out of scan i + 1's (no idle tail per scan) and never more threads run than the
+// process has CPUs for.  A ScanLoad is one scan's 2 n files into one page-locked buffer (pinned by the first worker to arrive).
+struct ScanLoad {
+    Pinned *buf = nullptr;
+    std::string folder[2], prefix[2], suffix;
+    int n = 0, w = 0, h = 0, sn = -1;
+    std::mutex m;
+    std::condition_variable cv;
+    int left = 0;                                            // files not decoded yet
+    int pinned = 0;                                          // 0 not tried, 1 ok, -1 failed
+    std::vector<std::string> errs;
+    double t_start = 0, t_end = 0;
+    void arm(int files) { std::lock_guard<std::mutex> g(m); left = files; pinned = 0; errs.assign((size_t)files, std::string()); }
+    void wait() { std::unique_lock<std::mutex> g(m); cv.wait(g, [this]() { return left == 0; }); }
+    bool ok(std::string &err)                                // after wait(): the first failing file in (camera, index) order
+    {
+        for (auto &e : errs) if (!e.empty()) { err = e; warn("Load Images", err); return false; }
+        return true;
+    }
+};
+
+class FilePool {
+public:
+    explicit FilePool(unsigned threads)
+    {
+        try { for (unsigned t = 0; t < threads; t++) th_.emplace_back([this]() { run(); }); }
+        catch (...) { /* fewer workers than hoped; with none, submit() decodes inline */ }
+    }
+    ~FilePool()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; q_.clear(); }   // (nobody waits for a scan once the series is over)
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void submit(ScanLoad *l)
+    {
+        const int files = 2 * l->n;
+        l->arm(files);
+        if (th_.empty()) { for (int t = 0; t < files; t++) one(l, t); return; }
+        { std::lock_guard<std::mutex> g(m_); for (int t = 0; t < files; t++) q_.push_back(Job{l, t}); }
+        cv_.notify_all();
+    }
+private:
+    struct Job { ScanLoad *l; int t; };
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static void one(ScanLoad *l, int t)
+    {
+        std::string err;
+        try {
+            const size_t plane = (size_t)l->w * l->h;
+            {
+                std::lock_guard<std::mutex> g(l->m);         // the first file of a scan pins the slot; the others wait here for it
+                if (l->pinned == 0) { l->t_start = now(); l->pinned = l->buf->ensure(2 * (size_t)l->n * plane) ? 1 : -1; }
+                if (l->pinned < 0) err = "out of page-locked memory";
+            }
+            if (err.empty()) {
+                const int cam = t / l->n, i = t - cam * l->n;
+                std::ostringstream p;
+                p << l->folder[cam] << l->prefix[cam] << i;
+                imread_scan_file(p.str(), l->suffix, l->w, l->h, l->buf->u8() + (size_t)t * plane, err);
+            }
+        } catch (const std::exception &ex) { err = std::string("image decoder: ") + ex.what(); }
+        catch (...) { err = "image decoder: unknown exception"; }
+        std::lock_guard<std::mutex> g(l->m);
+        l->errs[(size_t)t].swap(err);
+        if (--l->left == 0) { l->t_end = now(); l->cv.notify_all(); }
+    }
+    void run()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [this]() { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                j = q_.front(); q_.pop_front();
+            }
+            one(j.l, j.t);
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Job> q_;
+    bool stop_ = false;
+    std::vector<std::thread> th_;
+};
 
 bool ensure_ctx(slr_ctx *&ctx, std::string &err)
 {
@@ -236,9 +360,13 @@ bool Reconstruct::runReconstruction()
 }
 
 // ---- MFReconstruct -------------------------------------------------------------------------------------------------------------
+constexpr int kInSlots = 4;
+struct MFReconstruct::SeriesBuffers { Pinned in[kInSlots], cloud[2]; };
+
 MFReconstruct::MFReconstruct() { cameras = new VirtualCamera[2]; points3DProjView = nullptr; }
 MFReconstruct::~MFReconstruct()
 {
+    delete series;
     delete points3DProjView;
     delete sr;
     delete[] cameras;
@@ -322,63 +450,64 @@ bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, co
     }
     const int W = cameraWidth, H = cameraHeight, n = numberOfImgs;
     const size_t plane = (size_t)W * H, cells = (size_t)scan_w * scan_h;
-    // Input slots: page-locked buffers that background threads inflate scans into AHEAD of the GPU.  Two scans can be on the GPU
-    // (the two contexts), so with kInSlots buffers kInSlots - 1 scans are being decoded or wait decoded while one is consumed:
-    // the 28 files of ONE scan keep 28 cores busy for the ~60 ms one 12 MB plane takes to inflate, so a single scan ahead bounds
-    // the series at that time per scan (round 2: 100 ms); several scans ahead divide it.
-    constexpr int kInSlots = 4;
-    const int ns = two ? kInSlots : 1;
-    struct InSlot { Pinned buf; std::thread th; bool ok = false; std::string err; };
-    std::vector<InSlot> ins((size_t)ns);
-    struct Joiner {                                           // no path may leave a loader thread behind
-        std::vector<InSlot> &v;
-        ~Joiner() { for (auto &in : v) if (in.th.joinable()) in.th.join(); }
-    } joiner{ins};
+    // Input slots: page-locked buffers the pool inflates scans into AHEAD of the GPU.  One slot is being consumed (scan i - 1, on
+    // the GPU) while the others are decoded or wait decoded; two scans ahead keep every worker busy across scan boundaries, a
+    // third pays only where one scan's 2 n files cannot occupy the CPUs there are.
+    const unsigned cpus = loader_threads(1 << 20, two);
+    const int ahead = !two ? 1 : (cpus > (unsigned)(2 * 2 * n) ? 3 : 2);
+    const int ns = two ? std::min(kInSlots, ahead + 1) : 1;
+    if (!series) series = new SeriesBuffers();
+    std::vector<ScanLoad> ins((size_t)ns);
+    for (int k = 0; k < ns; k++) ins[(size_t)k].buf = &series->in[k];
+    FilePool pool(std::min(cpus, (unsigned)(2 * n * ahead))); // (destroyed before `ins`, which its workers write to)
     auto start_load = [&](size_t i) {
-        InSlot &in = ins[i % (size_t)ns];
-        if (in.th.joinable()) in.th.join();
-        in.ok = false; in.err.clear();
-        const std::string pl = scan_prefix(scan_sns[i], 'L'), pr = scan_prefix(scan_sns[i], 'R');
-        in.th = std::thread([this, &in, pl, pr, n, W, H]() {
-            try {
-                const std::string prefix[2] = {pl, pr};
-                in.ok = load_pair(scanFolder, prefix, imgSuffix, n, W, H, in.buf, in.err);
-            } catch (const std::exception &ex) { in.ok = false; in.err = std::string("loader: ") + ex.what(); }
-            catch (...) { in.ok = false; in.err = "loader: unknown exception"; }
-        });
+        ScanLoad &in = ins[i % (size_t)ns];
+        in.folder[0] = scanFolder[0]; in.folder[1] = scanFolder[1];
+        in.prefix[0] = scan_prefix(scan_sns[i], 'L'); in.prefix[1] = scan_prefix(scan_sns[i], 'R');
+        in.suffix = imgSuffix; in.n = n; in.w = W; in.h = H; in.sn = scan_sns[i];
+        pool.submit(&in);
     };
-    struct Slot { Pinned cloud; int sn = -1; bool busy = false; } slot[2];
+    struct Slot { Pinned *cloud = nullptr; int sn = -1; bool busy = false; } slot[2];
+    slot[0].cloud = &series->cloud[0]; slot[1].cloud = &series->cloud[1];
     auto finish = [&](int s) -> bool {                       // wait for slot s and hand its cloud over
         if (!slot[s].busy) return true;
         slot[s].busy = false;
         if (slr_synchronize(cx[s]) != SLR_OK) { lastError = slr_last_error(cx[s]); warn("Reconstruct", lastError); return false; }
         PointCloudImage *pc = new PointCloudImage(scan_w, scan_h, false);
-        memcpy(pc->points.data(), slot[s].cloud.p, cells * 12);
-        memcpy(pc->numOfPointsForPixel.data(), slot[s].cloud.u8() + cells * 12, cells);
+        memcpy(pc->points.data(), slot[s].cloud->p, cells * 12);
+        memcpy(pc->numOfPointsForPixel.data(), slot[s].cloud->u8() + cells * 12, cells);
         return sink(slot[s].sn, pc);
     };
     bool ok = true;
     size_t next = 0;                                         // first scan whose decode has not been started
+    const bool trace = getenv("SLR_SERIES_TRACE") != nullptr;   // per-scan wall times of the stages below, on stderr
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t i = 0; i < scan_sns.size() && ok; i++) {
         const int s = (int)(i & 1) * (two ? 1 : 0);
+        const double t0 = now();
         ok = finish(s);                                      // scan i - 2 used this context: its input slot is free again
         if (!ok) break;
+        const double t1 = now();
         // input slots in use right now: scan i - 1 (on the GPU) and the scans i .. next - 1 already decoding
         while (next < scan_sns.size() && next < i + (size_t)ns - (i > 0 ? 1 : 0) && (ns > 1 || next == i)) start_load(next++);
         Slot &sl = slot[s];
-        InSlot &in = ins[i % (size_t)ns];
-        if (in.th.joinable()) in.th.join();                  // (decoded while the GPU worked on the scans before)
-        if (!in.ok) { lastError = in.err; ok = false; break; }
+        ScanLoad &in = ins[i % (size_t)ns];
+        in.wait();                                           // (decoded while the GPU worked on the scans before)
+        const double t2 = now();
+        if (!in.ok(lastError)) { ok = false; break; }
         setScan(scan_sns[i]);
-        if (!sl.cloud.ensure(cells * 13)) { lastError = "out of page-locked memory"; ok = false; break; }
+        if (!sl.cloud->ensure(cells * 13)) { lastError = "out of page-locked memory"; ok = false; break; }
         if (!configure(cx[s], scan_sns[i])) { ok = false; break; }
         const uint8_t *pl[2][SLR_MF_PLANES];
-        for (int c = 0; c < 2; c++) for (int k = 0; k < SLR_MF_PLANES; k++) pl[c][k] = in.buf.u8() + ((size_t)c * n + k) * plane;
-        if (slr_reconstruct_mf_cloud(cx[s], pl[0], pl[1], W, W, H, blackThreshold, 1, scan_w, scan_h, (float *)sl.cloud.p,
-                                     sl.cloud.u8() + cells * 12, SLR_MEM_HOST) != SLR_OK) {
+        for (int c = 0; c < 2; c++) for (int k = 0; k < SLR_MF_PLANES; k++) pl[c][k] = in.buf->u8() + ((size_t)c * n + k) * plane;
+        if (slr_reconstruct_mf_cloud(cx[s], pl[0], pl[1], W, W, H, blackThreshold, 1, scan_w, scan_h, (float *)sl.cloud->p,
+                                     sl.cloud->u8() + cells * 12, SLR_MEM_HOST) != SLR_OK) {
             lastError = slr_last_error(cx[s]); warn("Reconstruct", lastError); ok = false; break;
         }
         sl.sn = scan_sns[i]; sl.busy = true;
+        if (trace)
+            fprintf(stderr, "[series] scan %d: previous cloud %.1f ms, wait for the decoder %.1f ms (its files took %.1f ms on %u threads), "
+                    "submit %.1f ms\n", scan_sns[i], t1 - t0, t2 - t1, in.t_end - in.t_start, std::min(cpus, (unsigned)(2 * n * ahead)), now() - t2);
     }
     // drain in scan order
     const int last = (int)((scan_sns.size() - 1) & 1) * (two ? 1 : 0);

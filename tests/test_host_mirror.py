@@ -56,8 +56,9 @@ def test_matrix_text_io_keeps_the_float_round_trip(host, tmp_path):
     assert host.duke_load_matrix(str(tmp_path / "missing.txt").encode(), 3, 3, _p(out)) == -1
 
 
-def _png_bytes(img, filt):
-    """minimal PNG writer with a chosen filter type per row (exercises the decoder's unfilter paths)"""
+def _png_bytes(img, filt, idat_split=0):
+    """minimal PNG writer with a chosen filter type per row (exercises the decoder's unfilter paths); idat_split > 0 cuts the
+    zlib stream into IDAT chunks of that many bytes"""
     h, w = img.shape
     raw = bytearray()
     prev = np.zeros(w, np.int32)
@@ -81,8 +82,31 @@ def _png_bytes(img, filt):
 
     def chunk(t, d):
         return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
-    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
-            chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    z = zlib.compress(bytes(raw))
+    idat = chunk(b"IDAT", z) if not idat_split else b"".join(chunk(b"IDAT", z[i:i + idat_split]) for i in range(0, len(z), idat_split))
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + idat + chunk(b"IEND", b"")
+
+
+def test_png_banded_decode(host, tmp_path):
+    """the decoder inflates a band of scanlines at a time: an image taller than one band (256 KiB of filtered bytes), every
+    filter type crossing the band edges, the zlib stream cut into many IDAT chunks (one of them a single byte)"""
+    rng = np.random.default_rng(6)
+    h, w = 301, 3001                                         # 87 rows per band -> 4 bands, the last one partial
+    img = (rng.integers(0, 40, size=(h, w)) + np.linspace(0, 200, w)[None, :]).astype(np.uint8)
+    for filt, split in (([4, 3, 2, 1, 0, 2, 4], 0), ([3, 4], 4099), ([2], 1 << 14), ([1, 4, 4], 1)):
+        if split == 1:
+            img_s, name = img[:9, :40].copy(), "one.png"     # every IDAT chunk one byte long
+        else:
+            img_s, name = img, "band%d.png" % split
+        open(tmp_path / name, "wb").write(_png_bytes(img_s, filt, split))
+        out = np.zeros_like(img_s)
+        ww, hh = C.c_int(0), C.c_int(0)
+        assert host.duke_imread(str(tmp_path / name).encode(), _p(out), out.size, C.byref(ww), C.byref(hh)) == 1
+        assert (ww.value, hh.value) == (img_s.shape[1], img_s.shape[0]) and np.array_equal(out, img_s)
+    good = _png_bytes(img, [4, 1], 5000)
+    cut = good[:len(good) * 2 // 3]                          # whole chunks missing from the middle on: no IEND
+    open(tmp_path / "cut.png", "wb").write(cut)
+    assert host.duke_imread(str(tmp_path / "cut.png").encode(), _p(out), out.size, C.byref(ww), C.byref(hh)) == 0
 
 
 def test_png_and_pgm_io(host, tmp_path):
