@@ -472,44 +472,6 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
 //   * the table gathers, the f64 arithmetic and the stores of a thread's 4 pixels are branch-free (unmatched pixels compute on
 //     column 0's table entry and are replaced by zeros at the end).
 // ------------------------------------------------------------------------------------------------------
-// Exclusive scan over a workgroup of BLOCK threads (the lean match kernels' index build): every wave scans itself with DPP lane
-// shifts (row_shr 1 / 2 / 4 / 8, then row_bcast 15 and 31: six VALU steps, no LDS crossbar), the (at most 16) wave totals cross in
-// LDS behind ONE barrier and every wave scans them for itself -- in place of hipcub::BlockScan, whose warp-scans form spends two
-// barriers.  result = op(init, v[0], ..., v[tid - 1]) (init must be op's identity); *total = the reduction over the workgroup.
-// wave_tot: LDS, BLOCK / 64 words, free for reuse after the caller's next barrier.
-template <int CTRL, int ROW_MASK, typename T>
-__device__ __forceinline__ T dpp_or(T identity, T v)       // the DPP source lane's v, or `identity` where there is none / the row is masked
-{
-    return (T)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-template <int BLOCK, typename T, typename Op>
-__device__ __forceinline__ T wg_exclusive_scan(T v, T init, Op op, T *wave_tot, T *total)
-{
-    static_assert(sizeof(T) == 4, "32-bit DPP");
-    constexpr int NW = BLOCK / 64;
-    static_assert(NW >= 1 && NW <= 16, "the wave totals are scanned inside one DPP row");
-    const int lane = (int)(threadIdx.x & 63u);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    T inc = v;
-    inc = op(dpp_or<0x111, 0xF>(init, inc), inc);           // row_shr:1
-    inc = op(dpp_or<0x112, 0xF>(init, inc), inc);           // row_shr:2
-    inc = op(dpp_or<0x114, 0xF>(init, inc), inc);           // row_shr:4
-    inc = op(dpp_or<0x118, 0xF>(init, inc), inc);           // row_shr:8   -> inclusive inside each row of 16
-    inc = op(dpp_or<0x142, 0xA>(init, inc), inc);           // row_bcast:15 into rows 1 and 3
-    inc = op(dpp_or<0x143, 0xC>(init, inc), inc);           // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
-    if (lane == 63) wave_tot[wv] = inc;
-    __syncthreads();
-    T t = wave_tot[lane < NW ? lane : NW - 1];
-    t = op(dpp_or<0x111, 0xF>(init, t), t);
-    if (NW > 2) t = op(dpp_or<0x112, 0xF>(init, t), t);
-    if (NW > 4) t = op(dpp_or<0x114, 0xF>(init, t), t);
-    if (NW > 8) t = op(dpp_or<0x118, 0xF>(init, t), t);
-    if (total) *total = (T)__builtin_amdgcn_readlane((int)t, NW - 1);
-    const T base = wv > 0 ? (T)__builtin_amdgcn_readlane((int)t, wv > 0 ? wv - 1 : 0) : init;
-    const T excl = dpp_or<0x138, 0xF>(init, inc);           // wave_shr:1: the wave's own exclusive prefix (lane 0: init)
-    return op(base, excl);
-}
-
 struct K4Lean {
     double q3, q7, q11, q14, q15;      // Q's five entries that are not structural zeros / ones
     double T[12];                      // matCoordTrans widened to f64 (exact)

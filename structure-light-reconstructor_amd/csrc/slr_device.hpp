@@ -181,8 +181,13 @@ hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, 
                               uint32_t *items, hipStream_t s);
 // unit view rays of every camera pixel, [H][W][3] per camera (calibration constants, cached by the context)
 hipError_t launch_ray_tables(const DevCalib &cal, int W, int H, float *raysL, float *raysR, hipStream_t s);
+// `list`: ray_list_words(scan_w * scan_h) words of scratch (the cells ordered by bucket lengths), made by launch_ray_list from
+// the offsets alone (it also zeroes the cells without pairs) and read by launch_ray_triangulate
+size_t ray_list_words(size_t cells);
+size_t ray_items_words(size_t cam_pixels);             // both cameras' items + the padding K6 reads into
+hipError_t launch_ray_list(const uint32_t *offs, int scan_w, int scan_h, uint32_t *list, float *xyz_sum, uint8_t *count, hipStream_t s);
 hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const DevCalib &cal, int scan_w, int scan_h,
-                                  int W, const float *raysL, const float *raysR, float *xyz_sum, uint8_t *count,
+                                  int W, const float *raysL, const float *raysR, const uint32_t *list, float *xyz_sum, uint8_t *count,
                                   hipStream_t s);
 
 // ordered prefix index / compaction of a u8 flag image (kernels_compact.hip): enumeration row-major or column-major over an
@@ -197,5 +202,45 @@ hipError_t launch_pc_from_grid(const float *xyz, const uint8_t *has, const uint8
                                int scan_w, int scan_h, float *pc_sum, uint8_t *pc_count, uint8_t *pc_color,
                                hipStream_t s);
 hipError_t launch_pc_get(const float *pc_sum, const uint8_t *pc_count, size_t n, float *out, hipStream_t s);
+
+#if defined(__HIPCC__)
+// Exclusive scan over a workgroup of BLOCK threads (the lean match kernels' index build, K6's bucket places): every wave scans itself with DPP lane
+// shifts (row_shr 1 / 2 / 4 / 8, then row_bcast 15 and 31: six VALU steps, no LDS crossbar), the (at most 16) wave totals cross in
+// LDS behind ONE barrier and every wave scans them for itself -- in place of hipcub::BlockScan, whose warp-scans form spends two
+// barriers.  result = op(init, v[0], ..., v[tid - 1]) (init must be op's identity); *total = the reduction over the workgroup.
+// wave_tot: LDS, BLOCK / 64 words, free for reuse after the caller's next barrier.
+template <int CTRL, int ROW_MASK, typename T>
+__device__ __forceinline__ T dpp_or(T identity, T v)       // the DPP source lane's v, or `identity` where there is none / the row is masked
+{
+    return (T)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int BLOCK, typename T, typename Op>
+__device__ __forceinline__ T wg_exclusive_scan(T v, T init, Op op, T *wave_tot, T *total)
+{
+    static_assert(sizeof(T) == 4, "32-bit DPP");
+    constexpr int NW = BLOCK / 64;
+    static_assert(NW >= 1 && NW <= 16, "the wave totals are scanned inside one DPP row");
+    const int lane = (int)(threadIdx.x & 63u);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    T inc = v;
+    inc = op(dpp_or<0x111, 0xF>(init, inc), inc);           // row_shr:1
+    inc = op(dpp_or<0x112, 0xF>(init, inc), inc);           // row_shr:2
+    inc = op(dpp_or<0x114, 0xF>(init, inc), inc);           // row_shr:4
+    inc = op(dpp_or<0x118, 0xF>(init, inc), inc);           // row_shr:8   -> inclusive inside each row of 16
+    inc = op(dpp_or<0x142, 0xA>(init, inc), inc);           // row_bcast:15 into rows 1 and 3
+    inc = op(dpp_or<0x143, 0xC>(init, inc), inc);           // row_bcast:31 into rows 2 and 3 -> inclusive over the wave
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    T t = wave_tot[lane < NW ? lane : NW - 1];
+    t = op(dpp_or<0x111, 0xF>(init, t), t);
+    if (NW > 2) t = op(dpp_or<0x112, 0xF>(init, t), t);
+    if (NW > 4) t = op(dpp_or<0x114, 0xF>(init, t), t);
+    if (NW > 8) t = op(dpp_or<0x118, 0xF>(init, t), t);
+    if (total) *total = (T)__builtin_amdgcn_readlane((int)t, NW - 1);
+    const T base = wv > 0 ? (T)__builtin_amdgcn_readlane((int)t, wv > 0 ? wv - 1 : 0) : init;
+    const T excl = dpp_or<0x138, 0xF>(init, inc);           // wave_shr:1: the wave's own exclusive prefix (lane 0: init)
+    return op(base, excl);
+}
+#endif
 
 }  // namespace slr

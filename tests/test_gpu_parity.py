@@ -517,6 +517,39 @@ def test_ray_count_wraps_like_uchar(ctx, oracle, synth):
     assert ecnt[0, 3] > 0               # the aliased bucket (x=3, y=0)
 
 
+def test_ray_buckets_of_every_form(ctx, oracle, synth):
+    """K6 has three forms: buckets of up to 16 items (sorting network, one wave per 64 cells), longer ones staged through LDS
+    256 cells at a time (up to 3072 items per camera and run), and one cell beyond that on a single lane.  One frame with
+    all three -- a left bucket of ~3800 pixels, buckets of 600 and of 17..40, and ordinary ones of 1..16 -- against the oracle."""
+    W, H, scan_w, scan_h = 96, 48, 40, 16
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    rng = np.random.default_rng(12)
+    cx = np.zeros((H, W), np.int32)
+    cy = np.zeros((H, W), np.int32)
+    cx[:, 13:] = 7; cy[:, 13:] = 2                           # cell (2,7): 83 x 46 pixels of the left camera
+    cxL, cyL = cx.copy(), cy.copy()
+    cxL[:2, :] = rng.integers(0, scan_w, size=(2, W)); cyL[:2, :] = scan_h - 1      # ordinary buckets in the last cell row
+    v = np.ones((H, W), np.uint8)
+    cxR, cyR = cx.copy(), cy.copy()
+    far = rng.random((H, W)) < 0.5
+    cxR[far] = rng.integers(0, scan_w, size=int(far.sum())); cyR[far] = scan_h - 1   # ~60 pixels per cell there: staged
+    mid = (~far) & (rng.random((H, W)) < 0.3)
+    cxR[mid] = rng.integers(0, 12, size=int(mid.sum())); cyR[mid] = 5                # and a row of cells with a few each
+    cxL[2:4, :] = rng.integers(0, 12, size=(2, W)); cyL[2:4, :] = 5
+    vR = (rng.random((H, W)) < 0.35).astype(np.uint8)
+    offL, itL = oracle.gray_bucket(cxL, cyL, v, scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(cxR, cyR, vR, scan_w, scan_h)
+    lenL, lenR = np.diff(offL), np.diff(offR)
+    both = (lenL > 0) & (lenR > 0)
+    assert (lenL[both] > 3072).any() and ((lenR[both] > 16) & (lenR[both] < 3072)).any() and ((lenL[both] <= 16) & (lenR[both] <= 16)).any()
+    assert ((lenR[both] > 12) & (lenR[both] <= 16) & (lenL[both] <= 16)).any(), "want a right bucket of 13..16 (the register rows)"
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.ray_triangulate(cxL, cyL, v, cxR, cyR, vR, scan_w, scan_h)
+    assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # PointCloudImage adaptor (Q11) and whole-path drop-ins
 # ---------------------------------------------------------------------------------------------------------
