@@ -128,7 +128,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* Test knobs (results never change).  SLR_OPT_DEBUG_RECT_RESIDENT: n > 0 = run the persistent fused decodes on n workgroups
  * (many tiles per workgroup), 0 = as many as are resident.  SLR_OPT_DEBUG_FLAGS: bit 0 = fused decode reads the caller's map
  * entries instead of the digest, bit 1 = per-plane pointers instead of one buffer descriptor, bit 2 = the general Gray-code match
- * kernel for every row (instead of only the rows its lean form defers).  SLR_OPT_DEBUG_K4_STOP exists only
+ * kernel for every row (instead of only the rows its lean form defers), bit 3 = slr_reconstruct_gray decodes into code
+ * arrays and counts the buckets in a second kernel (instead of one fused kernel per camera).  SLR_OPT_DEBUG_K4_STOP exists only
  * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9

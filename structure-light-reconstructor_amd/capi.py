@@ -23,7 +23,7 @@ OPT_RECT_DMA_SHAPE = 6         # tile / threads of form 7 (LDS-DMA fused decode)
                                # 3 = 128x16/512, 4 = 128x8/256, 5 = 256x4/256, 6 = 128x16/256
 OPT_RECT_DMA_DEPTH = 7         # phases of LDS-DMA in flight ahead of the decode: 1 or 2
 OPT_DEBUG_RECT_RESIDENT = 8    # tests: workgroups of the persistent fused decodes (0 = resident set)
-OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form
+OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form, bit 2 no lean K5, bit 3 no fused decode+count
 OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
 OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel

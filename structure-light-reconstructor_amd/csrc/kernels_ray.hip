@@ -18,6 +18,7 @@
 // Buckets are numbered by their PointCloudImage cell  j*scan_w + i  (bucket ac = i*scan_h + j  <->  cell (j,i)),
 // so the triangulation kernel reads its ranges and writes its sums fully coalesced.
 #include "slr_device.hpp"
+#include "decode_common.hpp"
 
 #include <hipcub/hipcub.hpp>
 #include <math.h>
@@ -65,6 +66,125 @@ __global__ __launch_bounds__(256) void ray_count_kernel(const int32_t *__restric
             rank_of[p] = cell != kNoBucket ? rank : 0u;
         }
     }
+}
+
+// pass 1 fused into the GRAY_ONLY decode (round 3): gray_decode_kernel<4, false>'s loop (kernels_decode.hip; reconstruct.cpp:
+// 349-407) followed by ray_count_kernel's cell / rank assignment, so that the codes never travel through HBM (9 bytes per pixel
+// written and read again) and one launch per camera is gone.  A thread decodes 4 consecutive pixels, so a run of equal cells
+// spans pixels of a thread AND lanes: heads are found per pixel (the first pixel against the previous lane's last), a head's
+// run ends at the next head in its thread or at the first head of the next lane that has one, and the pixels in front of a
+// thread's first head take their places from the last head of the nearest lane below that has one.  One atomic per run.
+__global__ __launch_bounds__(256) void gray_decode_count_kernel(GrayPlanes pl, int n_col_bits, int n_row_bits, int pitch, int W, int H,
+                                                                int black_thr, int white_thr, int scan_w, int scan_h,
+                                                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ cell_of,
+                                                                uint32_t *__restrict__ rank_of)
+{
+    const unsigned gpr = (unsigned)W / 4u, total = gpr * (unsigned)H, nb = (unsigned)scan_w * (unsigned)scan_h;
+    const unsigned lane = threadIdx.x & 63u;
+    // (the trip count is wave-uniform: the loop body uses wave-wide operations)
+    for (unsigned g0 = blockIdx.x * 256u + (threadIdx.x & ~63u); g0 < total; g0 += gridDim.x * 256u) {
+        const unsigned g = g0 + lane;
+        const bool live = g < total;
+        const unsigned gg = live ? g : total - 1;
+        const unsigned row = gg / gpr, col0 = (gg - row * gpr) * 4u;
+        const size_t so = (size_t)row * pitch + col0, m = (size_t)row * W + col0;
+        auto fetch = [&](int plane) -> unsigned { return __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(pl.p[plane] + so)); };
+        const unsigned wv = fetch(0), bv = fetch(1);
+        int gx[4] = {0, 0, 0, 0}, gy[4] = {0, 0, 0, 0}, err[4] = {0, 0, 0, 0};
+        for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
+            const unsigned a = fetch(2 * c + 2), b = fetch(2 * c + 3);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
+                const int df = v1 - v2;
+                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gx[i] = (gx[i] << 1) | (v1 > v2 ? 1 : 0);
+            }
+        }
+        for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
+            const unsigned a = fetch(2 * c + 2 + 2 * n_col_bits), b = fetch(2 * c + 3 + 2 * n_col_bits);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
+                const int df = v1 - v2;
+                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
+                gy[i] = (gy[i] << 1) | (v1 > v2 ? 1 : 0);
+            }
+        }
+        unsigned cell[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int mask = ((int)((wv >> (8 * i)) & 0xFF) - (int)((bv >> (8 * i)) & 0xFF) > black_thr) ? 1 : 0;
+            int x = gx[i], y = gy[i];
+            x ^= x >> 1; x ^= x >> 2; x ^= x >> 4; x ^= x >> 8;     // graycodes.cpp:116-128
+            y ^= y >> 1; y ^= y >> 2; y ^= y >> 4; y ^= y >> 8;
+            const int e = err[i] | ((y > scan_h || x > scan_w) ? 1 : 0);   // reconstruct.cpp:364 (Q9 '>')
+            cell[i] = kNoBucket;
+            if (live && (mask & (e ^ 1))) {
+                const unsigned long long k = (unsigned long long)(unsigned)x * (unsigned)scan_h + (unsigned)y;
+                if (k < nb) {                                  // Q9: ac >= scan_w*scan_h is an OOB write -> dropped
+                    const unsigned ci = (unsigned)k / (unsigned)scan_h, cj = (unsigned)k - ci * (unsigned)scan_h;
+                    cell[i] = cj * (unsigned)scan_w + ci;
+                }
+            }
+        }
+        // runs of equal cells over the wave's 256 pixels (pixel p = 4 lane + i)
+        const unsigned prev = __shfl_up(cell[3], 1);
+        const bool head[4] = {lane == 0 || cell[0] != prev, cell[1] != cell[0], cell[2] != cell[1], cell[3] != cell[2]};
+        const int first_head = head[0] ? 0 : head[1] ? 1 : head[2] ? 2 : head[3] ? 3 : 4;
+        const int last_head = head[3] ? 3 : head[2] ? 2 : head[1] ? 1 : head[0] ? 0 : -1;
+        const unsigned long long any = __ballot(last_head >= 0);                    // (lane 0 is in it)
+        const unsigned long long above = lane == 63u ? 0ull : any & ~((2ull << lane) - 1ull);
+        const unsigned next_lane = above ? (unsigned)__builtin_ctzll(above) : 64u;
+        const unsigned next_first = (unsigned)__shfl(first_head, (int)(next_lane & 63u));
+        const unsigned end_after = next_lane < 64u ? 4u * next_lane + next_first : 256u;   // where the run of this thread's last head ends
+        unsigned first[4] = {0, 0, 0, 0};                       // per head: the place of its run's first pixel
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (head[i] && cell[i] != kNoBucket) {
+                unsigned end = end_after;
+#pragma unroll
+                for (int j = 3; j > i; j--) if (head[j]) end = 4u * lane + (unsigned)j;
+                first[i] = atomicAdd(&cnt[cell[i]], end - (4u * lane + (unsigned)i));
+            }
+        const unsigned my_last_first = last_head == 3 ? first[3] : last_head == 2 ? first[2] : last_head == 1 ? first[1] : first[0];
+        const unsigned long long below = any & ((1ull << lane) - 1ull);
+        const unsigned from_lane = below ? 63u - (unsigned)__builtin_clzll(below) : 0u;
+        const unsigned from_first = (unsigned)__shfl(my_last_first, (int)from_lane);
+        const unsigned from_pos = 4u * from_lane + (unsigned)__shfl(last_head, (int)from_lane);
+        unsigned rank[4];
+        unsigned cur_first = from_first, cur_pos = from_pos;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (head[i]) { cur_first = first[i]; cur_pos = 4u * lane + (unsigned)i; }
+            rank[i] = cell[i] != kNoBucket ? cur_first + (4u * lane + (unsigned)i - cur_pos) : 0u;
+        }
+        if (live) {
+            i32x4 o; o.x = (int)cell[0]; o.y = (int)cell[1]; o.z = (int)cell[2]; o.w = (int)cell[3];
+            i32x4 q; q.x = (int)rank[0]; q.y = (int)rank[1]; q.z = (int)rank[2]; q.w = (int)rank[3];
+            *reinterpret_cast<i32x4 *>(cell_of + m) = o;
+            *reinterpret_cast<i32x4 *>(rank_of + m) = q;
+        }
+    }
+}
+
+// whether gray_decode_count_kernel applies: dword loads of 4 pixels, 16-byte stores
+bool ray_decode_count_applies(const GrayPlanes &pl, int nplanes, int n_row_bits, int pitch, int W, int H)
+{
+    if (n_row_bits < 1 || W % 4 != 0 || pitch % 4 != 0 || (long long)W * H >= (1ll << 30) || (long long)H * pitch >= (1ll << 32)) return false;
+    for (int p = 0; p < nplanes; p++) if ((uintptr_t)pl.p[p] % 4 != 0) return false;
+    return true;
+}
+
+hipError_t launch_gray_decode_count(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H, int black_thr,
+                                    int white_thr, int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of,
+                                    hipStream_t s)
+{
+    const size_t groups = (size_t)(W / 4) * H;
+    const unsigned blocks = (unsigned)((groups + 255) / 256 < 16384 ? (groups + 255) / 256 : 16384);
+    SLR_LAUNCH(gray_decode_count_kernel, dim3(blocks), dim3(256), 0, s, pl, n_col_bits, n_row_bits, pitch, W, H, black_thr, white_thr,
+               scan_w, scan_h, cnt, cell_of, rank_of);
+    return hipGetLastError();
 }
 
 // pass 2 (after the scan): item (col<<16 | row) -> items[offs[cell] + rank]

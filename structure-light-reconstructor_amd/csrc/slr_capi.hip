@@ -379,9 +379,12 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
     return SLR_OK;
 }
 
+// GRAY_ONLY from the planes: the decode is fused into the bucket histogram (gray_decode_count_kernel) when the stack allows it
+struct RayPlanes { const uint8_t *const *pl[2]; int ncol, nrow, pitch, black_thr, white_thr; };
+
 int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *vL, const int32_t *cxR,
              const int32_t *cyR, const uint8_t *vR, int W, int H, int scan_w, int scan_h, float *xyz_sum,
-             uint8_t *count)
+             uint8_t *count, const RayPlanes *planes = nullptr)
 {
     const size_t n = (size_t)W * H;
     const unsigned long long nb = (unsigned long long)scan_w * scan_h;
@@ -411,7 +414,18 @@ int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *
     void *cell2;
     SLR_TRY(get_scratch(c, S_RAY_CELL2, n * 4, &cell2));
     uint32_t *cellR = (uint32_t *)cell2;
-    { ProfScope ps(c, K_RAY_COUNT);
+    if (planes) {
+        const int np = 2 + 2 * planes->ncol + 2 * planes->nrow;
+        for (int cam = 0; cam < 2; cam++) {
+            GrayPlanes gp;
+            for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) gp.p[i] = i < np ? planes->pl[cam][i] : nullptr;
+            ProfScope ps(c, K_GRAY_DECODE, true);
+            SLR_HIP(c, launch_gray_decode_count(gp, planes->ncol, planes->nrow, planes->pitch, W, H, planes->black_thr, planes->white_thr,
+                                                scan_w, scan_h, (uint32_t *)cnt + (cam ? nb : 0), cam ? cellR : cellL, cam ? rankR : rankL,
+                                                c->stream));
+        }
+    } else {
+      ProfScope ps(c, K_RAY_COUNT);
       SLR_HIP(c, launch_ray_count(cxL, cyL, vL, W, H, scan_w, scan_h, (uint32_t *)cnt, cellL, rankL, c->stream));
       SLR_HIP(c, launch_ray_count(cxR, cyR, vR, W, H, scan_w, scan_h, (uint32_t *)cnt + nb, cellR, rankR, c->stream)); }
     { ProfScope ps(c, K_RAY_SCAN);
@@ -1308,6 +1322,15 @@ int slr_reconstruct_gray(slr_ctx *c, const uint8_t *const *planesL, const uint8_
     SLR_TRY(st.planes(planesL, np, pitch, H, dl));
     SLR_TRY(st.planes(planesR, np, pitch, H, dr));
     SLR_TRY(st.out(xyz_sum, nb * 12, &dx)); SLR_TRY(st.out(count, nb, &dc));
+    {   // the decode inside the bucket histogram: the codes never reach HBM
+        GrayPlanes gl, gr;
+        for (int i = 0; i < SLR_MAX_GRAY_PLANES; i++) { gl.p[i] = i < np ? dl[i] : nullptr; gr.p[i] = i < np ? dr[i] : nullptr; }
+        if (!tl_debug.no_decode_count && ray_decode_count_applies(gl, np, nrow, pitch, W, H) && ray_decode_count_applies(gr, np, nrow, pitch, W, H)) {
+            const RayPlanes rp = {{dl, dr}, ncol, nrow, pitch, black_thr, white_thr};
+            SLR_TRY(core_ray(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, W, H, scan_w, scan_h, (float *)dx, (uint8_t *)dc, &rp));
+            return st.finish();
+        }
+    }
     SLR_TRY(get_scratch(c, S_CODEX_L, n * 4, &cxl)); SLR_TRY(get_scratch(c, S_CODEY_L, n * 4, &cyl));
     SLR_TRY(get_scratch(c, S_VALID_L, n, &vl));
     SLR_TRY(get_scratch(c, S_CODEX_R, n * 4, &cxr)); SLR_TRY(get_scratch(c, S_CODEY_R, n * 4, &cyr));
@@ -1605,10 +1628,11 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 7) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..7");
+            if (value < 0 || value > 15) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..15");
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
             c->debug.no_ge_lean = (value & 4) != 0;
+            c->debug.no_decode_count = (value & 8) != 0;
             return SLR_OK;
 #ifdef SLR_DEBUG_HOOKS
         case SLR_OPT_DEBUG_K4_STOP:

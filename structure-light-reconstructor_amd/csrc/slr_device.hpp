@@ -65,6 +65,7 @@ struct DebugKnobs {
     bool no_tiled_map = false;   // fused decode: read the caller's 6-byte map entries instead of the digest
     bool no_buffer_form = false; // fused decode: per-plane pointers instead of one buffer descriptor
     bool no_ge_lean = false;     // K5: the general kernel for every row
+    bool no_decode_count = false;// GRAY_ONLY: separate decode and bucket-histogram kernels
     int k4_stop = 0;
 };
 extern thread_local DebugKnobs tl_debug;
@@ -177,6 +178,11 @@ size_t     ray_scan_temp_bytes(size_t n);
 hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
                             int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of, hipStream_t s);
 hipError_t launch_ray_scan(const uint32_t *cnt, uint32_t *offs, size_t n, void *temp, size_t temp_bytes, hipStream_t s);
+// GRAY_ONLY: decode + pass 1 in one kernel (cell_of / rank_of straight from the planes), when the stack allows dword loads
+bool ray_decode_count_applies(const GrayPlanes &pl, int nplanes, int n_row_bits, int pitch, int W, int H);
+hipError_t launch_gray_decode_count(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H, int black_thr,
+                                    int white_thr, int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of,
+                                    hipStream_t s);
 hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, int W, int H, const uint32_t *offs,
                               uint32_t *items, hipStream_t s);
 // unit view rays of every camera pixel, [H][W][3] per camera (calibration constants, cached by the context)

@@ -661,6 +661,33 @@ def test_reconstruct_ge_and_gray_whole_path(ctx, oracle, synth):
     assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz)
 
 
+@pytest.mark.parametrize("W,H,scan_w,scan_h,white", [(256, 160, 64, 40, 0), (1000, 37, 300, 33, 3), (260, 50, 70, 20, 0), (2048, 300, 640, 100, 2)])
+def test_gray_only_fused_decode_and_count(ctx, oracle, synth, slr, W, H, scan_w, scan_h, white):
+    """slr_reconstruct_gray decodes inside the bucket histogram (one kernel per camera, runs of equal cells over a thread's 4
+    pixels and over lanes): against the oracle chain and against the two-kernel form (SLR_OPT_DEBUG_FLAGS bit 3); widths that
+    are no multiple of 256 pixels (waves straddling rows), shadows, a white threshold, codes beyond the projector (Q9)"""
+    calib, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=58, noise=3, rows=True).numpy().copy()
+    st[0, 2:, H // 3:H // 2, W // 4:W // 2] = 255                   # codes past scan_w / scan_h: dropped or aliased like ac() does
+    st[1, 3::2, : H // 5, : W // 3] = 0
+    dec = [oracle.gray_decode(st[c], ncol, nrow, BLACK, white, scan_w, scan_h) for c in range(2)]
+    offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    assert (ecnt > 0).sum() > 50
+    got = {}
+    for flags in (0, 8):
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
+        try:
+            got[flags] = ctx.reconstruct_gray(st[0], st[1], ncol, nrow, BLACK, white, scan_w, scan_h)
+        finally:
+            ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+        assert bits_equal(got[flags][1], ecnt) and bits_equal(got[flags][0], exyz), flags
+
+
 # ---------------------------------------------------------------------------------------------------------
 # error behaviour (reference: bool + QMessageBox; here: status codes, never an abort)
 # ---------------------------------------------------------------------------------------------------------
