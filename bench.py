@@ -60,7 +60,8 @@ ALG_BYTES = {
     "slr_hybrid_rectify_decode_pair": 100.0,
     # GRAY_ONLY, per st-px of the CAMERA image (the projector's 1280x1024 cells add 29 B each = 3 B per camera pixel here)
     "slr_ray_triangulate": 35.0,       # 2 x (4 item + 12 ray) read + per cell 16 offsets read + 13 sum/count write
-    "slr_ray_count": 34.0,             # both cameras: 2 x (4 + 4 code + 1 valid read, 4 cell + 4 rank write)
+    "slr_ray_count": 34.0,             # both cameras: 2 x (4 + 4 code + 1 valid read, 4 cell + 4 rank write); inside
+                                       # slr_reconstruct_gray it is part of the decode kernel since round 3 (no such launch)
 }
 
 # rocprofv3 kernel-name prefixes of the profiler names above (roofline.traffic)
@@ -72,9 +73,9 @@ DEVICE_KERNEL = {
     "slr_gray_rectify_decode": ("gray_rect_decode_dma_kernel", "gray_rect_decode_lds_kernel"),
     "slr_gray_rectify_decode_pair": ("gray_rect_decode_dma_kernel", "gray_rect_decode_lds_kernel"),
     "slr_hybrid_rectify_decode_pair": ("gray_rect_decode_dma_kernel",),
-    "slr_gray_decode": ("gray_decode_kernel",),
+    "slr_gray_decode": ("gray_decode_kernel", "gray_decode_count_kernel"),
     "slr_ge_match_triangulate": ("ge_match_lean_kernel", "ge_match_kernel"),
-    "slr_ray_triangulate": ("ray_triangulate_kernel",),
+    "slr_ray_triangulate": ("ray_triangulate_small_kernel", "ray_triangulate_staged_kernel"),
     "slr_ray_count": ("ray_count_kernel",),
 }
 
