@@ -123,13 +123,16 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * 3 = 128x16 / 512 (default), 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
  * the decode, 1 (double buffer) or 2 (triple buffer, the default). */
+/* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2
+ * -- are compiled into the library with `make FORMS=all` only; a default build answers SLR_ERR_UNSUPPORTED to these values. */
 #define SLR_OPT_RECT_DMA_SHAPE 6
 #define SLR_OPT_RECT_DMA_DEPTH 7
 /* Test knobs (results never change).  SLR_OPT_DEBUG_RECT_RESIDENT: n > 0 = run the persistent fused decodes on n workgroups
  * (many tiles per workgroup), 0 = as many as are resident.  SLR_OPT_DEBUG_FLAGS: bit 0 = fused decode reads the caller's map
  * entries instead of the digest, bit 1 = per-plane pointers instead of one buffer descriptor, bit 2 = the general Gray-code match
  * kernel for every row (instead of only the rows its lean form defers), bit 3 = slr_reconstruct_gray decodes into code
- * arrays and counts the buckets in a second kernel (instead of one fused kernel per camera).  SLR_OPT_DEBUG_K4_STOP exists only
+ * arrays and counts the buckets in a second kernel (instead of one fused kernel per camera), bit 4 = the LDS-tiled fused Gray
+ * decode takes its 64 x 4 tiles (the form of stacks of 42 planes and more) whatever the plane count.  SLR_OPT_DEBUG_K4_STOP exists only
  * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9

@@ -1,5 +1,6 @@
 """Per-kernel micro-benchmark (HIP-event timed through the library's own profiler) used while tuning.
-usage: python profiles/microbench.py [W H reps]   -- prints one line per kernel/variant."""
+usage: python profiles/microbench.py [W H reps]   -- prints one line per kernel/variant.
+(Round 1/2 tool: it times the forms that lost their measurements too, so it needs a library built with `make FORMS=all`.)"""
 import importlib
 import os
 import sys

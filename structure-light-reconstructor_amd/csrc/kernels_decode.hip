@@ -853,6 +853,7 @@ __global__ __launch_bounds__(NT, (NT == 512 ? 6 : ROUNDS == 1 && STRIDED ? 5 : 4
     }
 }
 
+#ifdef SLR_ALL_FORMS
 // ------------------------------------------------------------------------------------------------------
 // fused K1+K2, sliding-window form (SLR_OPT_RECT_DECODE_ALGO = 3): the pipelined kernel above re-reads the two halo
 // rows of every 64 x 8 tile from HBM (1.13..1.17x the ideal traffic).  Here a workgroup walks DOWN a tile column and
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(256, 5) void mf_rect_decode_ring_kernel(RectJobs jo
         ld = ldn;
     }
 }
+#endif  // SLR_ALL_FORMS
 
 static unsigned pick_blocks(size_t groups)
 {
@@ -1104,6 +1106,9 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
                                   const float *atan_lut, int rect_algo, hipStream_t s)
 {
     int tiles_x = (W + kTileW - 1) / kTileW;
+    // (forms 2, 3 and 4 are measured-dominated -- DESIGN section 9 -- and compiled with -DSLR_ALL_FORMS only; without it
+    // slr_set_option refuses them)
+#ifdef SLR_ALL_FORMS
     if (rect_algo == 3) {                                // sliding-window form
         const int tiles_y8 = (H + kMidTileH - 1) / kMidTileH;
         RectJobs jr;
@@ -1133,11 +1138,16 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
                            pitch, W, H, black_thr, atan_lut, tiles_x, tiles_y8, seg_len);
         return hipGetLastError();
     }
-    // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
-    // than one per tile
     const bool mid = rect_algo != 2;                     // default: 64 x 8 tiles, one prefetch round; 2: 64 x 16, two
     const bool wide8 = rect_algo == 5;                   // 5: 128 x 8 tiles, 512 threads, one round, pre-digested map
     const bool wide = rect_algo == 4 || wide8;           // 4: 128 x 8 tiles (pairs of 64 x 8 table entries), two rounds
+#else
+    constexpr bool mid = true;                           // 6 (and whatever else arrives here): 64 x 8 tiles, one prefetch round
+    const bool wide8 = rect_algo == 5;                   // 5: 128 x 8 tiles, 512 threads, one round, pre-digested map
+    const bool wide = wide8;
+#endif
+    // persistent workgroups: as many as are resident at once (a multiple of 8 per job for the XCD bands), never more
+    // than one per tile
     const int th = mid ? kMidTileH : kTileH;
     const int tiles_yy = (H + th - 1) / th;
     if (wide) tiles_x = (W + 2 * kTileW - 1) / (2 * kTileW);
@@ -1174,12 +1184,14 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         const hipError_t e =
             wide8 ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 2, true, 512>, 512, dyn)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>, 512, dyn)) :
+#ifdef SLR_ALL_FORMS
             wide ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>, 256, dyn)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>, 256, dyn)) :
-            mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>, 256, dyn)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>, 256, dyn))
-                : (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, dyn)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, false>, 256, dyn));
+            !mid ? (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, true>, 256, dyn)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kTileH, 2, false>, 256, dyn)) :
+#endif
+                  (strided ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>, 256, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>, 256, dyn));
         if (e != hipSuccess || per_cu < 1) per_cu = 4;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         resident_slot = per_cu * cus;
@@ -1200,20 +1212,22 @@ static hipError_t launch_rect_lds(const RectJob *jobs, int njobs, int pitch, int
         else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 2, true, 512>), grid, dim3(512), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
+#ifdef SLR_ALL_FORMS
     else if (wide) {
         if (strided) SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 2, true, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
         else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 2, false, 2>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
+    else if (!mid) { if (strided) SLR_RECT_LAUNCH(kTileH, 2, true); else SLR_RECT_LAUNCH(kTileH, 2, false); }
+#endif
     else if (mid && j.j[0].pk_t) {
         if (strided) SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, true, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
         else         SLR_LAUNCH((mf_rect_decode_lds_kernel<kMidTileH, 1, false, 1, true>), grid, dim3(256), (size_t)budget + 16, s, j, njobs,
                                         pitch, W, H, black_thr, atan_lut, tiles_x, tiles_yy, budget);
     }
-    else if (mid) { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
-    else     { if (strided) SLR_RECT_LAUNCH(kTileH, 2, true); else SLR_RECT_LAUNCH(kTileH, 2, false); }
+    else { if (strided) SLR_RECT_LAUNCH(kMidTileH, 1, true); else SLR_RECT_LAUNCH(kMidTileH, 1, false); }
 #undef SLR_RECT_LAUNCH
     return hipGetLastError();
 }
@@ -1549,7 +1563,7 @@ hipError_t launch_gray_decode(const GrayPlanes &pl, int n_col_bits, int n_row_bi
         const int tiles_x = (W + kTileW - 1) / kTileW;
         // 64 x 8 tiles when a typical box (72 source bytes x 11 rows) of all planes fits 32 KB, else 64 x 4; the LDS
         // request is sized for a generous box of this plane count (boxes beyond it take the per-tile gather fallback)
-        const bool mid = (size_t)nplanes * 72 * 11 <= 32 * 1024 && rect_algo != 2;
+        const bool mid = (size_t)nplanes * 72 * 11 <= 32 * 1024 && rect_algo != 2 && !tl_debug.gray_small_tiles;
         const int th = mid ? kMidTileH : kGrayTileH;
         size_t want = (size_t)nplanes * 76 * (mid ? 12 : 7);
         want = want < 8 * 1024 ? 8 * 1024 : (want > 32 * 1024 ? 32 * 1024 : want);

@@ -1063,6 +1063,8 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         const int vec_ok = (k4_stop << 8) | (int)((W % 4 == 0) && ((uintptr_t)phaseL % 16 == 0) && ((uintptr_t)phaseR % 16 == 0) &&
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
                            ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
+    // (the sorted form, algo 2, is measured-dominated by the binned one: compiled with -DSLR_ALL_FORMS only)
+#ifdef SLR_ALL_FORMS
 #define SLR_SORTED(BLOCK, IPT)                                                                                     \
     do {                                                                                                           \
         if (algo == 2)                                                                                             \
@@ -1072,6 +1074,11 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             SLR_LAUNCH((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL,   \
                                phaseR, validR, W, H, row0, cal, vec_ok, undL, undRx, xyz, has, match_k);           \
     } while (0)
+#else
+#define SLR_SORTED(BLOCK, IPT)                                                                                     \
+    SLR_LAUNCH((mf_match_binned_kernel<BLOCK, IPT>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, W, H, row0, cal, \
+               vec_ok, undL, undRx, xyz, has, match_k)
+#endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
         if (algo == 0 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
@@ -1096,7 +1103,9 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         else if (W <= 1024) SLR_SORTED(256, 4);
         else if (W <= 2048) SLR_SORTED(1024, 2);
         else if (W <= 4096) SLR_SORTED(1024, 4);
+#ifdef SLR_ALL_FORMS
         else if (algo == 2) SLR_SORTED(1024, 8);
+#endif
         else                                                 // wider rows: the right row in chunks of 4096 columns
             SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
                                cal, vec_ok, undL, undRx, xyz, has, match_k);

@@ -61,6 +61,9 @@ struct DmaGeom {
 constexpr int kDmaShapes = 7;
 static int dma_shape_tw(int shape) { return shape == 3 || shape == 4 || shape == 6 ? 128 : 256; }
 static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape == 6 ? 16 : shape == 5 ? 4 : 8; }
+// (shapes 2, 4, 5 and 6 are measured-dominated -- DESIGN section 9 -- and compiled with -DSLR_ALL_FORMS only; without it
+// slr_set_option refuses them)
+#ifdef SLR_ALL_FORMS
 #define SLR_DMA_SHAPE_SWITCH(shape, X)                  \
     switch (shape) {                                    \
     case 1:  X(256, 8, 512); break;                     \
@@ -71,6 +74,14 @@ static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape ==
     case 6:  X(128, 16, 256); break;                    \
     default: X(256, 16, 512); break;                    \
     }
+#else
+#define SLR_DMA_SHAPE_SWITCH(shape, X)                  \
+    switch (shape) {                                    \
+    case 1:  X(256, 8, 512); break;                     \
+    case 3:  X(128, 16, 512); break;                    \
+    default: X(256, 16, 512); break;                    \
+    }
+#endif
 
 // map digest, one dword per destination pixel, [tile][thread][pass][pixel of the quad] (a thread's PX entries are contiguous):
 //   [12:2]  dword index of the tap's upper left byte in a plane's LDS image: (sy - y0) * (CMAX * 4) + ((sx - x0) >> 2)
@@ -1677,8 +1688,10 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
             : launch_gray_dma_variant<TW, TH, NT, NPP, false>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)
     switch (shape) {
     case 1:  SLR_GDMA_X(256, 8, 512); break;
+#ifdef SLR_ALL_FORMS
     case 4:  SLR_GDMA_X(128, 8, 256); break;
     case 5:  SLR_GDMA_X(256, 4, 256); break;
+#endif
     default: SLR_GDMA_X(128, 16, 512); break;
     }
 #undef SLR_GDMA_X
@@ -1692,8 +1705,10 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
                            cnt, tiles_x, code_x[c], code_y[c], valid[c])
         switch (shape) {
         case 1:  SLR_GDMA_X(256, 8, 512); break;
+#ifdef SLR_ALL_FORMS
         case 4:  SLR_GDMA_X(128, 8, 256); break;
         case 5:  SLR_GDMA_X(256, 4, 256); break;
+#endif
         default: SLR_GDMA_X(128, 16, 512); break;
         }
 #undef SLR_GDMA_X

@@ -1602,6 +1602,9 @@ int slr_set_option(slr_ctx *c, int option, int value)
     switch (option) {
         case SLR_OPT_MF_MATCH_ALGO:
             if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..3");
+#ifndef SLR_ALL_FORMS
+            if (value == 2) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 2 (sorted form) is compiled with -DSLR_ALL_FORMS only");
+#endif
             c->opt_mf_match_algo = value;
             return SLR_OK;
         case SLR_OPT_MF_DECODE_VEC:
@@ -1611,10 +1614,16 @@ int slr_set_option(slr_ctx *c, int option, int value)
             return SLR_OK;
         case SLR_OPT_RECT_DECODE_ALGO:
             if (value < 0 || value > 7) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DECODE_ALGO must be 0..7");
+#ifndef SLR_ALL_FORMS
+            if (value >= 2 && value <= 4) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_RECT_DECODE_ALGO = 2, 3, 4 are compiled with -DSLR_ALL_FORMS only");
+#endif
             c->opt_rect_algo = value;
             return SLR_OK;
         case SLR_OPT_RECT_DMA_SHAPE:
             if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_SHAPE must be 0..6");
+#ifndef SLR_ALL_FORMS
+            if (value == 2 || value >= 4) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_RECT_DMA_SHAPE = 2, 4, 5, 6 are compiled with -DSLR_ALL_FORMS only");
+#endif
             if (value != c->opt_dma_shape) {
                 c->opt_dma_shape = value;
                 SLR_TRY(use_device(c));
@@ -1628,11 +1637,12 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 15) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..15");
+            if (value < 0 || value > 31) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..31");
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
             c->debug.no_ge_lean = (value & 4) != 0;
             c->debug.no_decode_count = (value & 8) != 0;
+            c->debug.gray_small_tiles = (value & 16) != 0;
             return SLR_OK;
 #ifdef SLR_DEBUG_HOOKS
         case SLR_OPT_DEBUG_K4_STOP:

@@ -66,6 +66,7 @@ struct DebugKnobs {
     bool no_buffer_form = false; // fused decode: per-plane pointers instead of one buffer descriptor
     bool no_ge_lean = false;     // K5: the general kernel for every row
     bool no_decode_count = false;// GRAY_ONLY: separate decode and bucket-histogram kernels
+    bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
     int k4_stop = 0;
 };
 extern thread_local DebugKnobs tl_debug;

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import bits_equal, calib_parts, np_of
+from util import bits_equal, calib_parts, forms, np_of
 
 pytestmark = pytest.mark.gpu
 W, H, BLACK = 4096, 3000, 40
@@ -125,15 +125,16 @@ def test_fullsize_mf_match_forms_agree_and_oracle_rows(ctx, oracle, scene, slr):
         ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
     dec = [ctx.mf_decode(st[cam], BLACK, rectify_cam=cam) for cam in range(2)]
     out = {}
-    for algo in (3, 2, 1):
+    algos = forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (3, 2, 1), required=(3, 1))   # (2, the sorted form: FORMS=all builds)
+    for algo in algos:
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         out[algo] = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
     ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
     ctx.synchronize()
-    for algo in (2, 3):
+    for algo in algos:
         for a, b in zip(out[1], out[algo]):
             assert torch.equal(a, b)                   # whole frame: indexed forms == literal sweep, bit for bit
-    xyz, has, mk = [np_of(t) for t in out[2]]
+    xyz, has, mk = [np_of(t) for t in out[3]]
     assert 0.05 < has.mean() < 1.0
     camL, camR, Q, T = calib_parts(oracle, calib)
     phL, vL, phR, vR = [np_of(t) for t in (dec[0][0], dec[0][1], dec[1][0], dec[1][1])]
@@ -143,7 +144,7 @@ def test_fullsize_mf_match_forms_agree_and_oracle_rows(ctx, oracle, scene, slr):
     # whole-path entry point == the three stages
     x2, h2 = ctx.reconstruct_mf(st[0], st[1], BLACK, True)
     ctx.synchronize()
-    assert torch.equal(x2, out[2][0]) and torch.equal(h2, out[2][1])
+    assert torch.equal(x2, out[3][0]) and torch.equal(h2, out[3][1])
 
 
 def test_fullsize_gray_decode_and_ge(ctx, oracle, synth, scene):

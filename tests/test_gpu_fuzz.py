@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import bits_equal, calib_parts, np_of
+from util import bits_equal, calib_parts, forms, np_of
 
 pytestmark = pytest.mark.gpu
 BLACK = 40
@@ -48,7 +48,7 @@ def test_fuzz_decode_and_fused_rectify(ctx, oracle, synth, slr, seed):
     ctx.set_rectify_maps(0, np.ascontiguousarray(mx), np.ascontiguousarray(mf))
     rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
     eph, ev = oracle.mf_decode(rect, BLACK)
-    for algo in (0, 1, 2, 3, 4, 5, 6):
+    for algo in forms(ctx, slr, slr.capi.OPT_RECT_DECODE_ALGO, (0, 1, 2, 3, 4, 5, 6), required=(0, 1, 5, 6)):
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
         ph, v = ctx.mf_decode(planes, BLACK, W=W, rectify_cam=0)
         ctx.synchronize()
@@ -80,11 +80,13 @@ def test_fuzz_gray_decode_and_fused_rectify(ctx, oracle, synth, slr, seed):
     ctx.set_rectify_maps(1, mxt.numpy(), mft.numpy())
     rect = np.stack([oracle.remap_u8(raw[p], mxt.numpy(), mft.numpy()) for p in range(n)])
     ex, ey, ev = oracle.gray_decode(rect, ncol, nrow, BLACK, wt, scan_w, scan_h)
-    for algo in (0, 1, 2, 5, 6):
+    for algo, flags in ((0, 0), (1, 0), (6, 16), (5, 0), (6, 0)):     # auto, direct gather, LDS tiles 64x4 (debug flag), 128x8, 64x8
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
         cx, cy, v = ctx.gray_decode(planes, ncol, nrow, BLACK, wt, scan_w, scan_h, W=W, rectify_cam=1)
         ctx.synchronize()
-        assert bits_equal(np_of(v), ev) and bits_equal(np_of(cx), ex), (W, H, ncol, nrow, algo)
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+        assert bits_equal(np_of(v), ev) and bits_equal(np_of(cx), ex), (W, H, ncol, nrow, algo, flags)
     ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
     del keep
 
@@ -103,7 +105,7 @@ def test_fuzz_match_kernels(ctx, oracle, synth, slr, seed):
     phR = (rng.integers(-50, 400, (H, W)) * q).astype(np.float32)
     vL = (rng.random((H, W)) < 0.85).astype(np.uint8); vR = (rng.random((H, W)) < 0.85).astype(np.uint8)
     exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
-    for algo in (0, 1, 2):
+    for algo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 1, 2, 3), required=(0, 1, 3)):
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
         assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz), (W, H, algo)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import bits_equal, calib_parts, np_of
+from util import bits_equal, calib_parts, forms, np_of
 
 pytestmark = pytest.mark.gpu
 BLACK = 40
@@ -34,7 +34,7 @@ def test_k4_lean_vs_general_and_oracle(ctx, slr, oracle, synth, W, H, with_T, q)
     phL[1 % H, 9] = np.nan; phR[1 % H, 11] = np.nan
     exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
     try:
-        for algo in (0, 3, 2):                                          # lean (auto), general binned, sorted
+        for algo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 3, 2), required=(0, 3)):   # lean (auto), general binned, sorted (FORMS=all)
             ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
             xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
             assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz), (W, algo)
@@ -116,7 +116,7 @@ def test_gray_dma_form(dma_ctx, slr, oracle, synth, W, H, sw, sh, rows, resident
         ex, ey, ev = _gray_expect(oracle, raw, mxn, mfn, nc, nr, 3, sw, sh)
         dev = st[cam].cuda()
         ran = 0
-        for shape in (1, 3, 4, 5):
+        for shape in forms(ctx, slr, slr.capi.OPT_RECT_DMA_SHAPE, (1, 3, 4, 5), default=3, required=(1, 3)):
             ctx.set_option(slr.capi.OPT_RECT_DMA_SHAPE, shape)
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 7)                    # strict: an error if the form does not run
             ctx.set_rectify_maps(cam, mxn, mfn)

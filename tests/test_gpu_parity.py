@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_float_parity, bits_equal, calib_parts, np_of
+from util import assert_float_parity, bits_equal, calib_parts, forms, np_of
 
 pytestmark = pytest.mark.gpu
 
@@ -159,7 +159,7 @@ def test_remap_and_fused_rectify_decode(ctx, oracle, synth, slr, W, H):
         ctx.synchronize()
         assert np.array_equal(np_of(gdev), rect[5])
         exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
-        for algo in (0, 1, 2, 3, 4, 5, 6):                                    # LDS tiles 64x8, gather, LDS tiles 64x16, LDS ring, LDS tiles 128x8
+        for algo in forms(ctx, slr, slr.capi.OPT_RECT_DECODE_ALGO, (0, 1, 2, 3, 4, 5, 6), required=(0, 1, 5, 6)):   # auto, gather, [64x16, ring, 128x8 two rounds: FORMS=all], 128x8, 64x8
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=cam)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
@@ -185,7 +185,7 @@ def test_fused_rectify_decode_wild_maps(ctx, oracle, synth, slr):
         ctx.set_rectify_maps(0, np.ascontiguousarray(mx), mf)
         rect = np.stack([oracle.remap_u8(raw[p], mx, mf) for p in range(14)])
         exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
-        for algo in (0, 1, 2, 3, 4, 5, 6):
+        for algo in forms(ctx, slr, slr.capi.OPT_RECT_DECODE_ALGO, (0, 1, 2, 3, 4, 5, 6), required=(0, 1, 5, 6)):
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), algo
@@ -210,7 +210,7 @@ def test_fused_rectify_decode_pipeline_many_tiles_per_workgroup(ctx, oracle, syn
     exp_ph, exp_v = oracle.mf_decode(rect, BLACK)
     for res in ("8", "16", "40"):
         ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, int(res))
-        for algo in (0, 2, 3, 4, 5, 6):
+        for algo in forms(ctx, slr, slr.capi.OPT_RECT_DECODE_ALGO, (0, 2, 3, 4, 5, 6), required=(0, 5, 6)):
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
             ph, v = ctx.mf_decode(raw, BLACK, rectify_cam=0)
             assert bits_equal(v, exp_v) and bits_equal(ph, exp_ph), (res, algo)
@@ -299,10 +299,12 @@ def test_gray_rectify_decode(ctx, oracle, synth, slr):
         raw = st[cam].numpy()
         rect = np.stack([oracle.remap_u8(raw[p], mx.numpy(), mf.numpy()) for p in range(raw.shape[0])])
         ex, _, ev = oracle.gray_decode(rect, ncol, 0, BLACK, 4, scan_w, 0)
-        for algo in (0, 1, 2, 5, 6):                                 # auto, direct gather, LDS tiles 64x4, 128x8, 64x8
+        for algo, flags in ((0, 0), (1, 0), (6, 16), (5, 0), (6, 0)):   # auto, direct gather, LDS tiles 64x4 (debug flag), 128x8, 64x8
             ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, algo)
+            ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
             cx, _, v = ctx.gray_decode(raw, ncol, 0, BLACK, 4, scan_w, 0, rectify_cam=cam)
-            assert bits_equal(cx, ex) and bits_equal(v, ev), algo
+            ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+            assert bits_equal(cx, ex) and bits_equal(v, ev), (algo, flags)
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
     # rows too (GRAY_ONLY never rectifies in the reference, but the entry point allows it), odd size, wild map
     W2, H2, sw, sh = 132, 37, 100, 90
@@ -394,11 +396,12 @@ def test_mf_match_sweep_and_indexed_forms_agree(ctx, oracle, synth, slr, W):
     vL[11] = 0
     exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
     out = {}
-    for algo in (1, 2, 3, 0):
+    algos = forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (1, 2, 3, 0), required=(0, 1, 3))
+    for algo in algos:
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         out[algo] = ctx.mf_triangulate(phL, vL, phR, vR)
     ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
-    for algo in (1, 2, 3, 0):
+    for algo in algos:
         xyz, has, mk = out[algo]
         assert bits_equal(mk, emk), "algo %d" % algo
         assert bits_equal(has, ehas) and bits_equal(xyz, exyz), "algo %d" % algo
@@ -619,8 +622,8 @@ def test_reconstruct_mf_under_every_decode_and_match_form(ctx, oracle, synth, sl
             dec.append(oracle.mf_decode(pl, BLACK))
         assert (dec[0][1] == 0).sum() > 500 and (dec[0][1] == 1).sum() > 500
         exyz, ehas, _ = oracle.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], camL, camR, Q, T)
-        for ralgo in ((0, 1, 2, 3, 4, 5, 6) if rectify else (0,)):
-            for malgo in (0, 1, 2, 3):
+        for ralgo in (forms(ctx, slr, slr.capi.OPT_RECT_DECODE_ALGO, (0, 1, 2, 3, 4, 5, 6), required=(0, 1, 5, 6)) if rectify else (0,)):
+            for malgo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 1, 2, 3), required=(0, 1, 3)):
                 ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, ralgo)
                 ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, malgo)
                 xyz, has = ctx.reconstruct_mf(st[0], st[1], BLACK, rectify)

@@ -24,9 +24,9 @@ def test_soak_production_vs_independent_device_forms(ctx, synth, slr):
         st = synth.render_mf_stack(W, H, seed=5000 + f, noise=f % 4, device=dev).unsqueeze(0).contiguous()
         ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 0); ctx.set_option(cap.OPT_MF_MATCH_ALGO, 0)
         xyz, has = ctx.reconstruct_mf_batch(st, 40, True)                      # pair launch + binned K4
-        ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 1 if f % 2 else 3)            # gather / ring forms, one camera per launch
+        ctx.set_option(cap.OPT_RECT_DECODE_ALGO, 1 if f % 2 else 6)            # gather / 64 x 8 LDS tiles, one camera per launch
         dec = [ctx.mf_decode(st[0, cam], 40, rectify_cam=cam) for cam in range(2)]
-        ctx.set_option(cap.OPT_MF_MATCH_ALGO, 2)                               # radix-sorted form
+        ctx.set_option(cap.OPT_MF_MATCH_ALGO, 1 if f % 4 == 0 else 3)          # literal sweep / general binned form
         ex, eh, _ = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
         ctx.synchronize()
         assert torch.equal(has[0], eh) and torch.equal(xyz[0], ex), f

@@ -93,7 +93,7 @@ def test_gpu_mfn_then_match_triangulate(ctx, oracle, synth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 3])
 def test_gpu_row_bands_equal_the_whole_frame(ctx, oracle, synth, slr, algo):
     """config-5 sharding: decode + match of row bands (slr_mf_triangulate_rows: absolute rows for the reprojection and the
     undistortion tables) concatenated == the whole frame in one call == the oracle, for every K4 form"""

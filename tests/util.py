@@ -42,3 +42,20 @@ def np_of(t):
     if hasattr(t, "detach"):
         return t.detach().cpu().numpy()
     return np.asarray(t)
+
+
+def forms(ctx, slr, opt, values, default=0, required=()):
+    """the values of a form option (SLR_OPT_RECT_DECODE_ALGO / _RECT_DMA_SHAPE / _MF_MATCH_ALGO) this build of the library has:
+    the measured-dominated forms are compiled with `make FORMS=all` only and answer SLR_ERR_UNSUPPORTED otherwise; `required`
+    values must be there.  Leaves the option at `default`."""
+    ok = []
+    for v in values:
+        try:
+            ctx.set_option(opt, v)
+            ok.append(v)
+        except slr.capi.SlrError as e:
+            assert e.status == slr.capi.ERR_UNSUPPORTED and v not in required, (opt, v, str(e))
+    ctx.set_option(opt, default)
+    for v in required:
+        assert v in ok, (opt, v)
+    return ok
