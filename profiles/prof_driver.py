@@ -77,15 +77,16 @@ if "ge" in WHAT:
     for _ in range(REPS):
         ctx.reconstruct_ge(g[0], g[1], ncol, 40, 0, W, True, False)                                # GRAY_EPI as bench.py --mode ge: pair launch + K5
 if "ray" in WHAT:
-    # GRAY_ONLY: column + row bits, counting sort by projector cell, ray-ray triangulation (scan area = camera area)
+    # GRAY_ONLY as bench.py --mode gray: column + row bits of a 1280 x 1024 projector under the 4096 x 3000 cameras (~10 camera
+    # pixels per projector cell and camera); decode fused into the bucket histogram, scan, scatter beside K6's list kernels, K6
     calib2, _ = synth.make_calibration(W, H, baseline=400.0, theta=0.6)
     ctx.set_calibration(calib2)
-    g2 = synth.render_gray_stack(W, H, W, H, seed=1234, device=dev, rows=True)
-    nc, nr = synth.gray_num_bits(W), synth.gray_num_bits(H)
+    SW, SH = int(os.environ.get("SLR_SCAN_W", "1280")), int(os.environ.get("SLR_SCAN_H", "1024"))
+    g2 = synth.render_gray_stack(W, H, SW, SH, seed=1234, device=dev, rows=True)
+    nc, nr = synth.gray_num_bits(SW), synth.gray_num_bits(SH)
     torch.cuda.synchronize()
-    d2 = [ctx.gray_decode(g2[cam], nc, nr, 40, 0, W, H) for cam in range(2)]
     for _ in range(REPS):
-        ctx.ray_triangulate(d2[0][0], d2[0][1], d2[0][2], d2[1][0], d2[1][1], d2[1][2], W, H)
+        ctx.reconstruct_gray(g2[0], g2[1], nc, nr, 40, 0, SW, SH)
 ctx.synchronize()
 ctx.close()
 print("prof_driver done")

@@ -59,7 +59,9 @@ PROFILER_NAME = [
     ("mf_match_lean_kernel", "slr_mf_match_triangulate"), ("ge_match_lean_kernel", "slr_ge_match_triangulate"),
     ("gray:gray_decode_kernel<4, false>", "slr_gray_decode"), ("ray:gray_decode_kernel<4, false>", "slr_gray_decode[columns+rows]"), ("mf_match_binned_kernel", "slr_mf_match_triangulate[general binned form]"),
     ("ge_match_kernel", "slr_ge_match_triangulate[general form]"), ("ray_count_kernel", "slr_ray_count"),
-    ("ray_scatter_kernel", "slr_ray_scatter"), ("ray_triangulate_kernel", "slr_ray_triangulate"),
+    ("ray:gray_decode_count_kernel", "slr_gray_decode[columns+rows, bucket histogram inside]"),
+    ("ray_scatter_kernel", "slr_ray_scatter"), ("ray_triangulate_small_kernel", "slr_ray_triangulate"),
+    ("ray_triangulate_staged_kernel", "slr_ray_triangulate[long buckets]"), ("ray_key_", "slr_ray_triangulate[work list]"),
 ]
 
 
