@@ -268,6 +268,12 @@ int slr_pointcloud_from_grid(slr_ctx *ctx, const float *xyz, const uint8_t *has,
 int slr_pointcloud_get(slr_ctx *ctx, const float *pc_sum, const uint8_t *pc_count, size_t n,
                        float *out, slr_mem mem);
 
+/* Utilities::line_lineIntersection (utilities.cpp:399-425) over arrays: the line through p1[3] along v1[i][3] against the line
+ * through p2[3] along v2[i][3]; out[i][3] = the midpoint of their closest points, ok[i] = 0 (and out = 0) where the reference
+ * returns false (|a c - b b| < 0.1).  The function slr_ray_triangulate / slr_reconstruct_gray evaluate per pixel pair. */
+int slr_line_line_intersections(slr_ctx *ctx, size_t n, const float *p1, const float *p2, const float *v1, const float *v2,
+                                float *out, uint8_t *ok, slr_mem mem);
+
 /* ---- whole-path drop-ins ----------------------------------------------------------------------------
  * One call per stereo frame = the body of run*Reconstruction between imread and MeshCreator.
  * rectify != 0: planes are RAW camera images and the ctx maps are applied (fused); 0: already rectified. */

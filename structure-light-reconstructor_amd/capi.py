@@ -39,7 +39,7 @@ SYMBOLS = [
     "slr_get_rectify_maps", "slr_get_rectify_info", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
     "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
-    "slr_ge_triangulate", "slr_ray_triangulate", "slr_pointcloud_from_grid", "slr_pointcloud_get",
+    "slr_ge_triangulate", "slr_ray_triangulate", "slr_line_line_intersections", "slr_pointcloud_from_grid", "slr_pointcloud_get",
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
     "slr_prefix_index", "slr_compact_points",
     "slr_host_alloc", "slr_host_free",
@@ -438,6 +438,15 @@ class Context:
         self._chk(self.lib.slr_pointcloud_get(self.h, _ptr(pc_sum), _ptr(pc_count), C.c_size_t(n), _ptr(out),
                                               C.c_int(mem)))
         return out
+
+    def line_line_intersections(self, p1, p2, v1, v2):
+        """slr_line_line_intersections: p1, p2 [3]; v1, v2 [n][3] f32 (host arrays) -> (out [n][3], ok [n])"""
+        a = [np.ascontiguousarray(x, np.float32) for x in (p1, p2, v1, v2)]
+        n = a[2].shape[0]
+        out = np.zeros((n, 3), np.float32); ok = np.zeros(n, np.uint8)
+        self._chk(self.lib.slr_line_line_intersections(self.h, C.c_size_t(n), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                                       _ptr(out), _ptr(ok), C.c_int(MEM_HOST)))
+        return out, ok
 
     # -- whole-path drop-ins
     def reconstruct_mf(self, planesL, planesR, black_thr, rectify, W=None, xyz=None, has=None):

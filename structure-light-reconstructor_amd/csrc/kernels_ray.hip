@@ -318,14 +318,14 @@ __device__ __forceinline__ float dot3(const float a[3], const float b[3])
 // quotient comes near the denormals, the exponents differ by 96 or more, or the numerator's biased exponent is <= 23).  Inside
 // that range the refined reciprocal is the same for the three divisions, so it is computed once and every quotient takes the
 // same five instructions the compiler's sequence would have run: bit-identical results, 18 instructions and one v_rcp instead
-// of 33 and three.  Outside the range (a numerator below 2^-100, among them the zeros; anything above 2^60) the plain division
-// runs.  -DSLR_RAY_PLAIN_DIV builds the plain divisions everywhere.
-// (b, c, a over denom = a c - b b with |denom| >= 0.1: a and c are sums of squares, so a, c < 2^30 bounds denom and |b| by 2^60
-// from above and a, c by 2^-34 from below; only b can be small.)
+// of 33 and three.  Outside the range (b below 2^-60, among them the zeros; a or c from 2^12 on) the plain division runs.  -DSLR_RAY_PLAIN_DIV builds the plain divisions everywhere.
+// (b, c, a over denom = a c - b b with |denom| >= 0.1: a and c are sums of squares, so a, c < 2^12 bounds denom and |b| by 2^24
+// from above and a, c by 2^-16 from below; only b can be small, and from 2^-60 on its quotient (>= 2^-84) and the remainders
+// of the two corrections (>= 2^-108) are normal numbers.)
 __device__ __forceinline__ void div3(float b, float c, float a, float den, float &qb, float &qc, float &qa)
 {
 #ifndef SLR_RAY_PLAIN_DIV
-    if (fabsf(b) >= 0x1p-100f && fmaxf(a, c) < 0x1p30f) {    // (NaNs fail the comparisons)
+    if (fabsf(b) >= 0x1p-60f && fmaxf(a, c) < 0x1p12f) {     // (NaNs fail the comparisons)
         float r = __builtin_amdgcn_rcpf(den);
         const float e = __builtin_fmaf(-den, r, 1.0f);
         r = __builtin_fmaf(e, r, r);
@@ -363,6 +363,31 @@ __device__ __forceinline__ bool line_line(const float p1[3], const float v1[3], 
         out[k] = 0.5f * (u + w);
     }
     return true;
+}
+
+// Utilities::line_lineIntersection over arrays (utilities.cpp:399-425): n lines through p1 along v1[i] against n lines through p2
+// along v2[i] -- the function K6 runs per pixel pair, exposed so that it (and its shared-reciprocal divisions) can be checked on
+// rays K6's calibrated unit rays never produce: perpendicular, nearly parallel, tiny, huge
+__global__ __launch_bounds__(256) void line_line_kernel(size_t n, const float *__restrict__ p1, const float *__restrict__ p2,
+                                                        const float *__restrict__ v1, const float *__restrict__ v2,
+                                                        float *__restrict__ out, uint8_t *__restrict__ ok)
+{
+    const float a[3] = {p1[0], p1[1], p1[2]}, b[3] = {p2[0], p2[1], p2[2]};
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) {
+        const float r1[3] = {v1[3 * i], v1[3 * i + 1], v1[3 * i + 2]}, r2[3] = {v2[3 * i], v2[3 * i + 1], v2[3 * i + 2]};
+        float X[3] = {0.0f, 0.0f, 0.0f};
+        const bool hit = line_line(a, r1, b, r2, X);
+        out[3 * i] = hit ? X[0] : 0.0f; out[3 * i + 1] = hit ? X[1] : 0.0f; out[3 * i + 2] = hit ? X[2] : 0.0f;
+        ok[i] = hit ? 1 : 0;
+    }
+}
+
+hipError_t launch_line_line(size_t n, const float *p1, const float *p2, const float *v1, const float *v2, float *out, uint8_t *ok,
+                            hipStream_t s)
+{
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? ((n + 255) / 256 ? (n + 255) / 256 : 1) : 8192);
+    SLR_LAUNCH(line_line_kernel, dim3(blocks), dim3(256), 0, s, n, p1, p2, v1, v2, out, ok);
+    return hipGetLastError();
 }
 
 // restore the reference's push order inside one bucket: ascending (col,row) == ascending packed item

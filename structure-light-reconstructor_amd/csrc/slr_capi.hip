@@ -973,6 +973,20 @@ int slr_pointcloud_get(slr_ctx *c, const float *pc_sum, const uint8_t *pc_count,
     return st.finish();
 }
 
+int slr_line_line_intersections(slr_ctx *c, size_t n, const float *p1, const float *p2, const float *v1, const float *v2, float *out,
+                                uint8_t *ok, slr_mem mem)
+{
+    if (!c || !p1 || !p2 || !v1 || !v2 || !out || !ok) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return SLR_OK;
+    SLR_TRY(use_device(c));
+    Stage st(c, mem);
+    const void *a, *b, *d, *e; void *o, *k;
+    SLR_TRY(st.in(p1, 12, &a)); SLR_TRY(st.in(p2, 12, &b)); SLR_TRY(st.in(v1, n * 12, &d)); SLR_TRY(st.in(v2, n * 12, &e));
+    SLR_TRY(st.out(out, n * 12, &o)); SLR_TRY(st.out(ok, n, &k));
+    SLR_HIP(c, launch_line_line(n, (const float *)a, (const float *)b, (const float *)d, (const float *)e, (float *)o, (uint8_t *)k, c->stream));
+    return st.finish();
+}
+
 // ---- whole-path drop-ins ----------------------------------------------------------------------------------
 // both cameras' (rectifying) decode of one stereo frame: ONE launch when an LDS-tiled fused form applies, else one per camera.
 // vL / vR null: the valid flag travels INSIDE the phase (invalid pixels carry a NaN, which K4 never matches).

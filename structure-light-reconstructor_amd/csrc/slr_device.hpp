@@ -179,6 +179,8 @@ size_t     ray_scan_temp_bytes(size_t n);
 hipError_t launch_ray_count(const int32_t *code_x, const int32_t *code_y, const uint8_t *valid, int W, int H,
                             int scan_w, int scan_h, uint32_t *cnt, uint32_t *cell_of, uint32_t *rank_of, hipStream_t s);
 hipError_t launch_ray_scan(const uint32_t *cnt, uint32_t *offs, size_t n, void *temp, size_t temp_bytes, hipStream_t s);
+hipError_t launch_line_line(size_t n, const float *p1, const float *p2, const float *v1, const float *v2, float *out, uint8_t *ok,
+                            hipStream_t s);
 // GRAY_ONLY: decode + pass 1 in one kernel (cell_of / rank_of straight from the planes), when the stack allows dword loads
 bool ray_decode_count_applies(const GrayPlanes &pl, int nplanes, int n_row_bits, int pitch, int W, int H);
 hipError_t launch_gray_decode_count(const GrayPlanes &pl, int n_col_bits, int n_row_bits, int pitch, int W, int H, int black_thr,

@@ -498,6 +498,52 @@ def test_ray_triangulate_parity(ctx, oracle, synth, W, H, scan_w, scan_h, with_T
     assert bits_equal(got, oracle.pointcloud_get(exyz, ecnt))
 
 
+def test_line_line_intersections_on_rays_of_every_scale(ctx, oracle):
+    """Utilities::line_lineIntersection as K6 evaluates it (three quotients over one refined reciprocal inside a guarded exponent
+    range, the plain division outside): unit rays, rays scaled by 2^-40 .. 2^20, nearly and exactly perpendicular ones (b -> 0),
+    nearly parallel ones around the 0.1 threshold -- bit for bit against the f32 expression (NumPy, one rounding per operation,
+    itself checked against the C oracle on a sample)"""
+    rng = np.random.default_rng(77)
+    n = 400000
+    f = np.float32
+    def unit(m):
+        v = rng.standard_normal((m, 3)); return v / np.linalg.norm(v, axis=1, keepdims=True)
+    v1 = unit(n); v2 = unit(n)
+    q = n // 8
+    v1[q:2 * q] *= np.exp2(rng.integers(-40, 21, (q, 1))); v2[q:2 * q] *= np.exp2(rng.integers(-40, 21, (q, 1)))
+    w = np.cross(v1[2 * q:3 * q], unit(q)); w /= np.linalg.norm(w, axis=1, keepdims=True)
+    v2[2 * q:3 * q] = w + v1[2 * q:3 * q] * np.exp2(rng.integers(-140, -10, (q, 1)).astype(np.float64))   # b from ~2^-140 up
+    v2[3 * q:3 * q + q // 2] = np.cross(v1[3 * q:3 * q + q // 2], np.array([0.0, 0.0, 1.0]))              # axis-aligned cases: b == 0 exactly
+    v1[3 * q:3 * q + q // 2] = np.round(v1[3 * q:3 * q + q // 2] * 4) / 4
+    v2[3 * q:3 * q + q // 2] = np.cross(v1[3 * q:3 * q + q // 2], np.array([0.0, 0.0, 1.0]))
+    ang = np.arcsin(np.sqrt(np.linspace(0.08, 0.12, q)))                                                 # sin^2 around 0.1
+    v2[4 * q:5 * q] = v1[4 * q:5 * q] * np.cos(ang)[:, None] + np.cross(v1[4 * q:5 * q], unit(q)) * np.sin(ang)[:, None]
+    v1[5 * q:6 * q] *= np.exp2(rng.integers(5, 40, (q, 1))); v2[5 * q:6 * q] *= np.exp2(rng.integers(-30, 0, (q, 1)))
+    v1 = v1.astype(f); v2 = v2.astype(f)
+    p1 = np.array([3.5, -20.25, 1000.0], f); p2 = np.array([-410.0, 7.0, 955.5], f)
+    with np.errstate(all="ignore"):
+        d3 = lambda a, b: (f(0) + a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]   # utilities.cpp:399-425, f32 per operation
+        v12 = p1 - p2
+        a = d3(v1, v1); c = d3(v2, v2); b = d3(v1, v2); d = d3(v12[None], v1); e = d3(v12[None], v2)
+        den = a * c - b * b
+        hit = ~(np.abs(den) < f(0.1))
+        s_ = (b / den) * e - (c / den) * d
+        t_ = -(b / den) * d + (a / den) * e
+        exp = f(0.5) * ((p1[None] + s_[:, None] * v1) + (p2[None] + t_[:, None] * v2))
+    exp[~hit] = 0
+    for i in rng.integers(0, n, 3000):                       # the NumPy expression is the oracle's
+        ok_i, o_i = oracle.line_line_intersection(p1, v1[i], p2, v2[i])
+        assert ok_i == bool(hit[i])
+        if ok_i and np.isfinite(o_i).all(): assert bits_equal(o_i, exp[i]), i
+    out, ok = ctx.line_line_intersections(p1, p2, v1, v2)
+    assert np.array_equal(ok != 0, hit)
+    fin = np.isfinite(exp).all(axis=1)
+    assert fin.sum() > 0.9 * n and (hit & fin).sum() > 0.5 * n
+    assert bits_equal(out[fin], exp[fin])
+    assert np.array_equal(np.isnan(out[~fin]), np.isnan(exp[~fin]))
+    assert (np.abs(b[hit]) < 2.0 ** -60).sum() > 1000 and (b[hit] == 0).sum() > 100, "want the plain-division side of the guard too"
+
+
 def test_ray_count_wraps_like_uchar(ctx, oracle, synth):
     """> 255 pairs in one bucket: the u8 counter wraps and the next hit restarts the sum (pointcloudimage.cpp:90-95)"""
     W, H, scan_w, scan_h = 40, 20, 4, 4
