@@ -937,12 +937,14 @@ constexpr int dma_waves_per_simd()
     return w > 8 ? 8 : w < 1 ? 1 : w;
 }
 
-// (a thread's state does not fit the 64 VGPRs of 8 waves per SIMD without spilling: capped at 6 like the Gray kernel)
+// (a thread's state does not fit the 64 VGPRs of 8 waves per SIMD without spilling: capped at 6 like the Gray kernel; with separate
+// valid bytes -- the single-camera entry -- it does not fit the 80 of 6 either: 9 spilled registers whose reloads drain the DMA
+// queue, so that variant runs 4 waves per SIMD on 96 registers, 78.5 -> 75.9 us per camera)
 template <int LDS_BYTES, int NT>
 constexpr int mf_dma_waves() { return dma_waves_per_simd<LDS_BYTES, NT>() > 6 ? 6 : dma_waves_per_simd<LDS_BYTES, NT>(); }
 
 template <int TW, int TH, int NT, int A, bool HASVALID>
-__global__ __launch_bounds__(NT, (mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
+__global__ __launch_bounds__(NT, (HASVALID ? 4 : mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
 void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
                                int tiles_x, int tiles_y, unsigned *__restrict__ sched)
 {
