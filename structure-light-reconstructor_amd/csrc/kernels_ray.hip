@@ -416,13 +416,14 @@ __device__ __forceinline__ void load_ray(const float *__restrict__ rays, uint32_
 // triangulation kernels take their cells from that list: the lanes of a wave have the same trip counts (lengths above 31 share
 // a key and diverge as before).  Cells without pairs get their zeros here and are not listed.  The sort is not stable across
 // workgroups (places inside a key are handed out by atomics); cells are independent, so the results do not depend on it.
-// It needs the bucket offsets only, not the items: the context runs it beside the scatter kernels on a second stream.
+// It needs the bucket offsets only, not the items: its workgroups ride in the scatter kernels' launches (ray_scatter_list_kernel).
 // (Sorting each 4096-cell segment on its own, one kernel and no global atomics, made the list in the same 34 us and the
 // triangulation 25 % slower: waves straddling two keys, heavy waves starting late.  profiles/exp/r03/k6_segment_sort_form.hip.txt)
 constexpr unsigned kKeyLen = 32, kKeys = kKeyLen * kKeyLen;
 constexpr unsigned kNetLen = 16;                             // buckets of up to 16 items: the sorting-network form of K6
 constexpr unsigned kBins = 2 * kKeys;                        // cells with a bucket beyond kNetLen items first, then the others
-constexpr unsigned kKeyCells = 1024;                         // cells per workgroup of the two list kernels (4 per thread)
+constexpr unsigned kKeyCells = 4096;                         // cells per workgroup of the list work (16 per thread): few workgroups, so that
+                                                             // they leave the wave slots of the launch to the scatter they ride with
 
 __device__ __forceinline__ unsigned cell_key(const uint32_t *__restrict__ offs, unsigned nb, unsigned b)
 {
@@ -452,15 +453,15 @@ __device__ __forceinline__ void wave_count_key(uint32_t *cnt, unsigned key, unsi
 }
 
 // hist[k] = cells with key k, hist[kBins] = listed cells in all, hist[kBins + 1] = those of them with a bucket beyond kNetLen
-__global__ __launch_bounds__(256) void ray_key_hist_kernel(const uint32_t *__restrict__ offs, unsigned nb, uint32_t *__restrict__ hist,
-                                                           float *__restrict__ xyz_sum, uint8_t *__restrict__ count)
+__device__ __forceinline__ void ray_key_hist_block(unsigned blk, const uint32_t *__restrict__ offs, unsigned nb, uint32_t *__restrict__ hist,
+                                                   float *__restrict__ xyz_sum, uint8_t *__restrict__ count)
 {
     __shared__ uint32_t h[kBins + 2];
     for (unsigned k = threadIdx.x; k < kBins + 2; k += 256) h[k] = 0;
     unsigned key[kKeyCells / 256];
 #pragma unroll
     for (unsigned m = 0; m < kKeyCells / 256; m++) {
-        const unsigned b = blockIdx.x * kKeyCells + m * 256 + threadIdx.x;
+        const unsigned b = blk * kKeyCells + m * 256 + threadIdx.x;
         key[m] = b < nb ? cell_key(offs, nb, b) : kBins;
         if (b < nb && key[m] == kBins) { xyz_sum[3 * (size_t)b] = 0.0f; xyz_sum[3 * (size_t)b + 1] = 0.0f; xyz_sum[3 * (size_t)b + 2] = 0.0f; count[b] = 0; }
     }
@@ -477,15 +478,15 @@ __global__ __launch_bounds__(256) void ray_key_hist_kernel(const uint32_t *__res
 }
 
 // order[start(key) + place] = cell; cursor[] (zeroed) hands out the places of a key, one range per workgroup and key
-__global__ __launch_bounds__(256) void ray_key_order_kernel(const uint32_t *__restrict__ offs, unsigned nb, const uint32_t *__restrict__ hist,
-                                                            uint32_t *__restrict__ cursor, uint32_t *__restrict__ order)
+__device__ __forceinline__ void ray_key_order_block(unsigned blk, const uint32_t *__restrict__ offs, unsigned nb, const uint32_t *__restrict__ hist,
+                                                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ order)
 {
     __shared__ uint32_t start[kBins], cnt[kBins], part[4];
     const unsigned t = threadIdx.x;
     unsigned key[kKeyCells / 256], place[kKeyCells / 256];
 #pragma unroll
     for (unsigned m = 0; m < kKeyCells / 256; m++) {
-        const unsigned b = blockIdx.x * kKeyCells + m * 256 + t;
+        const unsigned b = blk * kKeyCells + m * 256 + t;
         key[m] = b < nb ? cell_key(offs, nb, b) : kBins;
         place[m] = 0;
     }
@@ -503,7 +504,32 @@ __global__ __launch_bounds__(256) void ray_key_order_kernel(const uint32_t *__re
     __syncthreads();
 #pragma unroll
     for (unsigned m = 0; m < kKeyCells / 256; m++)
-        if (key[m] < kBins) order[start[key[m]] + place[m]] = blockIdx.x * kKeyCells + m * 256 + t;
+        if (key[m] < kBins) order[start[key[m]] + place[m]] = blk * kKeyCells + m * 256 + t;
+}
+
+// K3' pass 2 and K6's work list in ONE launch per camera: the list needs the bucket offsets only, and its workgroups wait on
+// LDS atomics and global latencies while the scatter's stream 16 bytes per pixel -- the first `list_blocks` workgroups of the
+// launch do the list's part (PHASE 0, with the left camera's scatter: the key histogram; PHASE 1, with the right camera's: the
+// order), all others scatter a row segment of 256 pixels.  (On a second stream the two kernels overlapped poorly: scatter + list
+// 126 us for 85 + 45 alone.)
+template <int PHASE>
+__global__ __launch_bounds__(256) void ray_scatter_list_kernel(const uint32_t *__restrict__ cell_of, const uint32_t *__restrict__ rank_of, int W,
+                                                               const uint32_t *__restrict__ offs_cam, uint32_t *__restrict__ items,
+                                                               const uint32_t *__restrict__ offs, unsigned nb, uint32_t *__restrict__ hist,
+                                                               uint32_t *__restrict__ cursor, uint32_t *__restrict__ order,
+                                                               float *__restrict__ xyz_sum, uint8_t *__restrict__ count, unsigned list_blocks)
+{
+    if (blockIdx.x < list_blocks) {
+        if constexpr (PHASE == 0) ray_key_hist_block(blockIdx.x, offs, nb, hist, xyz_sum, count);
+        else ray_key_order_block(blockIdx.x, offs, nb, hist, cursor, order);
+        return;
+    }
+    const unsigned gx = ((unsigned)W + 255u) / 256u, sb = blockIdx.x - list_blocks;
+    const unsigned row = sb / gx, col = (sb - row * gx) * 256u + threadIdx.x;
+    if (col >= (unsigned)W) return;
+    const unsigned p = row * (unsigned)W + col;
+    const unsigned cell = cell_of[p];
+    if (cell != kNoBucket) items[offs_cam[cell] + rank_of[p]] = (col << 16) | row;
 }
 
 // One projector pixel's pairs, (c1 outer, c2 inner), accumulated like PointCloudImage::setPoint / addPoint do.
@@ -807,16 +833,21 @@ size_t ray_list_words(size_t cells) { return cells + 2 * (size_t)kBins + 2; }
 constexpr size_t kRayItemsPad = kNetLen;                     // the small kernel reads 16 items from every bucket start
 size_t ray_items_words(size_t cam_pixels) { return 2 * cam_pixels + kRayItemsPad; }
 
-// the work list of launch_ray_triangulate (and the zeros of the cells without pairs); needs `offs` only
-hipError_t launch_ray_list(const uint32_t *offs, int scan_w, int scan_h, uint32_t *list, float *xyz_sum, uint8_t *count, hipStream_t s)
+// pass 2 of both cameras (items[offs[cell] + rank]) with the work list of launch_ray_triangulate made beside it (and the zeros of
+// the cells without pairs written)
+hipError_t launch_ray_scatter_list(const uint32_t *cellL, const uint32_t *rankL, const uint32_t *cellR, const uint32_t *rankR, int W, int H,
+                                   const uint32_t *offs, uint32_t *items, int scan_w, int scan_h, uint32_t *list, float *xyz_sum,
+                                   uint8_t *count, hipStream_t s)
 {
     const size_t nb = (size_t)scan_w * scan_h;
     uint32_t *order = list, *hist = list + nb, *cursor = hist + kBins + 2;
     hipError_t e = hipMemsetAsync(hist, 0, (2 * (size_t)kBins + 2) * 4, s);   // hist, cursor
     if (e != hipSuccess) return e;
-    const unsigned lb = (unsigned)((nb + kKeyCells - 1) / kKeyCells);
-    SLR_LAUNCH(ray_key_hist_kernel, dim3(lb), dim3(256), 0, s, offs, (unsigned)nb, hist, xyz_sum, count);
-    SLR_LAUNCH(ray_key_order_kernel, dim3(lb), dim3(256), 0, s, offs, (unsigned)nb, (const uint32_t *)hist, cursor, order);
+    const unsigned lb = (unsigned)((nb + kKeyCells - 1) / kKeyCells), sb = (unsigned)(((size_t)W + 255) / 256 * (size_t)H);
+    SLR_LAUNCH(ray_scatter_list_kernel<0>, dim3(lb + sb), dim3(256), 0, s, cellL, rankL, W, offs, items, offs, (unsigned)nb, hist, cursor, order,
+               xyz_sum, count, lb);
+    SLR_LAUNCH(ray_scatter_list_kernel<1>, dim3(lb + sb), dim3(256), 0, s, cellR, rankR, W, offs + nb, items, offs, (unsigned)nb, hist, cursor, order,
+               xyz_sum, count, lb);
     return hipGetLastError();
 }
 

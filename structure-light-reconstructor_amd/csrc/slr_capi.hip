@@ -45,8 +45,6 @@ struct slr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t side = nullptr;                 // second stream of GRAY_ONLY: K6's work list is made beside the scatter kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool has_calib = false;
     DevCalib cal;
@@ -430,21 +428,9 @@ int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *
       SLR_HIP(c, launch_ray_count(cxR, cyR, vR, W, H, scan_w, scan_h, (uint32_t *)cnt + nb, cellR, rankR, c->stream)); }
     { ProfScope ps(c, K_RAY_SCAN);
       SLR_HIP(c, launch_ray_scan((const uint32_t *)cnt, (uint32_t *)offs, ncell, tmp, tb, c->stream)); }
-    // K6's work list (the cells ordered by bucket lengths) needs the offsets only: it is made on the side stream while the
-    // scatter kernels fill the buckets (two small latency-bound kernels, ~50 us, beside two bandwidth-bound ones, ~85 us)
-    if (!c->side) {
-        SLR_HIP(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        SLR_HIP(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        SLR_HIP(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
-    SLR_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-    SLR_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    SLR_HIP(c, launch_ray_list((const uint32_t *)offs, scan_w, scan_h, (uint32_t *)list, xyz_sum, count, c->side));
-    SLR_HIP(c, hipEventRecord(c->ev_join, c->side));
-    { ProfScope ps(c, K_RAY_SCATTER);
-      SLR_HIP(c, launch_ray_scatter(cellL, rankL, W, H, (const uint32_t *)offs, (uint32_t *)items, c->stream));
-      SLR_HIP(c, launch_ray_scatter(cellR, rankR, W, H, (const uint32_t *)offs + nb, (uint32_t *)items, c->stream)); }
-    SLR_HIP(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    { ProfScope ps(c, K_RAY_SCATTER);                    // (K6's work list is made inside the same two launches)
+      SLR_HIP(c, launch_ray_scatter_list(cellL, rankL, cellR, rankR, W, H, (const uint32_t *)offs, (uint32_t *)items, scan_w, scan_h,
+                                         (uint32_t *)list, xyz_sum, count, c->stream)); }
     { ProfScope ps(c, K_RAY_TRI);
       SLR_HIP(c, launch_ray_triangulate((const uint32_t *)offs, (uint32_t *)items, c->cal, scan_w, scan_h, W,
                                         (const float *)raysL, (const float *)raysR, (const uint32_t *)list, xyz_sum, count, c->stream)); }
@@ -551,9 +537,6 @@ int slr_destroy(slr_ctx *c)
     for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); if (c->d_dma_tiles[k]) (void)hipFree(c->d_dma_tiles[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_sched) (void)hipFree(c->d_sched);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return SLR_OK;

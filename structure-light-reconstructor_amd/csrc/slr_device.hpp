@@ -190,11 +190,13 @@ hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, 
                               uint32_t *items, hipStream_t s);
 // unit view rays of every camera pixel, [H][W][3] per camera (calibration constants, cached by the context)
 hipError_t launch_ray_tables(const DevCalib &cal, int W, int H, float *raysL, float *raysR, hipStream_t s);
-// `list`: ray_list_words(scan_w * scan_h) words of scratch (the cells ordered by bucket lengths), made by launch_ray_list from
-// the offsets alone (it also zeroes the cells without pairs) and read by launch_ray_triangulate
+// `list`: ray_list_words(scan_w * scan_h) words of scratch (the cells ordered by bucket lengths), made by
+// launch_ray_scatter_list beside the scatter (it also zeroes the cells without pairs) and read by launch_ray_triangulate
 size_t ray_list_words(size_t cells);
 size_t ray_items_words(size_t cam_pixels);             // both cameras' items + the padding K6 reads into
-hipError_t launch_ray_list(const uint32_t *offs, int scan_w, int scan_h, uint32_t *list, float *xyz_sum, uint8_t *count, hipStream_t s);
+hipError_t launch_ray_scatter_list(const uint32_t *cellL, const uint32_t *rankL, const uint32_t *cellR, const uint32_t *rankR, int W, int H,
+                                   const uint32_t *offs, uint32_t *items, int scan_w, int scan_h, uint32_t *list, float *xyz_sum,
+                                   uint8_t *count, hipStream_t s);
 hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const DevCalib &cal, int scan_w, int scan_h,
                                   int W, const float *raysL, const float *raysR, const uint32_t *list, float *xyz_sum, uint8_t *count,
                                   hipStream_t s);
