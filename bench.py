@@ -534,6 +534,27 @@ def main():
                 prof[name] = (a[0] + ms, a[1] + n)
             c_.profile_enable(False)
             c_.set_option(slr.capi.OPT_PROFILE_STRIDE, 1)
+    kernels_one_stream = None
+    if args.profile and args.mode == "gray" and not args.pmc_child:
+        # GRAY_ONLY batches pipeline their frames over two streams (SLR_OPT_BATCH_STREAMS = 2): the timed region's per-kernel
+        # durations are those of kernels that share the GPU with the other frame's other half.  An untimed pass of two steps on ONE
+        # stream gives each kernel's duration on its own.
+        prof1 = {}
+        for c_ in ctxs:
+            c_.set_option(slr.capi.OPT_BATCH_STREAMS, 1)
+            c_.set_option(slr.capi.OPT_PROFILE_STRIDE, 1)
+            c_.profile_enable(True)
+            c_.profile_reset()
+        for i in range(2):
+            step(i)
+        sync_all()
+        for c_ in ctxs:
+            for name, (ms, n) in c_.profile().items():
+                a = prof1.get(name, (0.0, 0))
+                prof1[name] = (a[0] + ms, a[1] + n)
+            c_.profile_enable(False)
+            c_.set_option(slr.capi.OPT_BATCH_STREAMS, 2)
+        kernels_one_stream = [{"name": k, "launches": n, "avg_us": round(ms / n * 1e3, 2)} for k, (ms, n) in sorted(prof1.items(), key=lambda kv: -kv[1][0])]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -706,7 +727,7 @@ def main():
                                        "alg_bytes_per_launch": e["alg_bytes_per_px"] * npix, "target_frac": 0.60}
                                       for e in extras if e["name"] == "slr_mf_decode"), None),
             "maps_of_the_timed_region": maps_info, "realistic_maps": realistic,
-            "kernels": kernels, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
+            "kernels": kernels, "kernels_one_stream_untimed_pass": kernels_one_stream, "other_kernels_untimed_region": extras, "cpu_baseline": cpu,
             "host_buffers_pcie_inclusive": hostio,
         }
         print(json.dumps(out))

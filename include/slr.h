@@ -142,6 +142,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * fused multi-frequency decode of both cameras on white, black and the fringes behind the Gray planes (measured faster: 349 vs
  * 385 us at 4096x3000); 1 = ONE kernel that walks all 2 n + 14 planes of a tile (one digest, one shadow mask). */
 #define SLR_OPT_HYBRID_ONE_PASS 11
+/* SLR_OPT_BATCH_STREAMS: 2 (default) = slr_reconstruct_batch in SLR_MODE_GRAY alternates its frames between two streams with a
+ * scratch set each, the second one half a frame behind: a frame's ray-ray triangulation (arithmetic) runs beside the next
+ * frame's decode, histogram and scatter (HBM streaming); 1 = one frame after the other on the context's stream.  Same results. */
+#define SLR_OPT_BATCH_STREAMS 12
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */

@@ -25,6 +25,7 @@ OPT_RECT_DMA_DEPTH = 7         # phases of LDS-DMA in flight ahead of the decode
 OPT_DEBUG_RECT_RESIDENT = 8    # tests: workgroups of the persistent fused decodes (0 = resident set)
 OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form, bit 2 no lean K5, bit 3 no fused decode+count
 OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
+OPT_BATCH_STREAMS = 12         # GRAY_ONLY batch: 2 (default) = frames pipelined over two streams, 1 = sequential
 OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()

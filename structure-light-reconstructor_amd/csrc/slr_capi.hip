@@ -65,12 +65,17 @@ struct slr_ctx {
     int opt_rect_algo = 0;         // SLR_OPT_RECT_DECODE_ALGO
     int opt_async_host = 0;        // SLR_OPT_ASYNC_HOST
     int opt_hybrid_one_pass = 0;   // SLR_OPT_HYBRID_ONE_PASS
+    int opt_batch_streams = 2;     // SLR_OPT_BATCH_STREAMS
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
     int rays_w = 0, rays_h = 0;
-    void *scratch[S_COUNT] = {};
-    size_t scratch_cap[S_COUNT] = {};
+    void *scratch[2 * S_COUNT] = {};            // two sets: slr_reconstruct_batch pipelines GRAY_ONLY frames over two streams
+    size_t scratch_cap[2 * S_COUNT] = {};
+    int scratch_set = 0;                        // the set get_scratch hands out (calibration tables live in set 0 only)
+    hipStream_t pipe = nullptr;                 // the second stream of that pipeline
+    hipEvent_t ev_pipe[2] = {nullptr, nullptr};
+    hipEvent_t mid_event = nullptr;             // recorded by core_ray between a GRAY_ONLY frame's two halves (the pipeline's skew)
     // profiler
     bool profiling = false;
     std::vector<ProfRec> pending;
@@ -151,6 +156,7 @@ int use_device(slr_ctx *c)
 int get_scratch(slr_ctx *c, int slot, size_t bytes, void **out)
 {
     if (bytes == 0) bytes = 16;
+    if (c->scratch_set && slot != S_RAYS_L && slot != S_RAYS_R && slot != S_UND_L && slot != S_UND_R) slot += S_COUNT;
     if (c->scratch_cap[slot] < bytes) {
         if (c->scratch[slot]) {
             SLR_HIP(c, hipStreamSynchronize(c->stream));
@@ -431,6 +437,7 @@ int core_ray(slr_ctx *c, const int32_t *cxL, const int32_t *cyL, const uint8_t *
     { ProfScope ps(c, K_RAY_SCATTER);                    // (K6's work list is made inside the same two launches)
       SLR_HIP(c, launch_ray_scatter_list(cellL, rankL, cellR, rankR, W, H, (const uint32_t *)offs, (uint32_t *)items, scan_w, scan_h,
                                          (uint32_t *)list, xyz_sum, count, c->stream)); }
+    if (c->mid_event) SLR_HIP(c, hipEventRecord(c->mid_event, c->stream));
     { ProfScope ps(c, K_RAY_TRI);
       SLR_HIP(c, launch_ray_triangulate((const uint32_t *)offs, (uint32_t *)items, c->cal, scan_w, scan_h, W,
                                         (const float *)raysL, (const float *)raysR, (const uint32_t *)list, xyz_sum, count, c->stream)); }
@@ -533,7 +540,9 @@ int slr_destroy(slr_ctx *c)
     for (auto e : c->free_events) (void)hipEventDestroy(e);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
-    for (int i = 0; i < S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    if (c->pipe) { (void)hipStreamSynchronize(c->pipe); (void)hipStreamDestroy(c->pipe); }
+    for (int k = 0; k < 2; k++) if (c->ev_pipe[k]) (void)hipEventDestroy(c->ev_pipe[k]);
+    for (int i = 0; i < 2 * S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); if (c->d_dma_tiles[k]) (void)hipFree(c->d_dma_tiles[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->d_sched) (void)hipFree(c->d_sched);
@@ -1586,9 +1595,32 @@ int slr_reconstruct_batch(slr_ctx *c, const slr_batch_desc *d, const uint8_t *st
             SLR_TRY(slr_reconstruct_ge(c, pl, pr, d->n_col_bits, d->pitch, d->W, d->H, d->black_thr, d->white_thr, d->scan_w, rect,
                                        d->have_color, xyz + (size_t)f * n * 3, has + (size_t)f * n,
                                        d->have_color ? color + (size_t)f * n : nullptr, SLR_MEM_DEVICE));
-        else
-            SLR_TRY(slr_reconstruct_gray(c, pl, pr, d->n_col_bits, d->n_row_bits, d->pitch, d->W, d->H, d->black_thr, d->white_thr,
-                                         d->scan_w, d->scan_h, xyz + (size_t)f * cells * 3, has + (size_t)f * cells, SLR_MEM_DEVICE));
+        else {
+            // GRAY_ONLY frames alternate between two streams, each with its own scratch set: a frame's first half (decode +
+            // bucket histogram, scan, scatter: ~430 us of HBM streaming) and its second half (K6: ~350 us of VALU work on data
+            // that is mostly in LDS and registers) use different units, so one frame's second half runs beside the next
+            // frame's first.  The second stream starts when frame 0 reaches its K6 (that is the skew which keeps the two
+            // streams in opposite halves; it is also behind the ray tables and whatever the caller queued before the batch),
+            // and the context's stream waits for it at the end.
+            const bool piped = d->n_frames > 1 && c->opt_batch_streams > 1;
+            const int odd = piped ? f & 1 : 0;
+            if (piped && !c->pipe) {
+                SLR_HIP(c, hipStreamCreateWithFlags(&c->pipe, hipStreamNonBlocking));
+                for (int k = 0; k < 2; k++) SLR_HIP(c, hipEventCreateWithFlags(&c->ev_pipe[k], hipEventDisableTiming));
+            }
+            if (f == 0 && piped) c->mid_event = c->ev_pipe[0];
+            if (f == 1 && piped) SLR_HIP(c, hipStreamWaitEvent(c->pipe, c->ev_pipe[0], 0));
+            hipStream_t own = c->stream;
+            if (odd) { c->stream = c->pipe; c->scratch_set = 1; }
+            const int st = slr_reconstruct_gray(c, pl, pr, d->n_col_bits, d->n_row_bits, d->pitch, d->W, d->H, d->black_thr, d->white_thr,
+                                                d->scan_w, d->scan_h, xyz + (size_t)f * cells * 3, has + (size_t)f * cells, SLR_MEM_DEVICE);
+            c->stream = own; c->scratch_set = 0; c->mid_event = nullptr;
+            if (st != SLR_OK) { if (c->pipe) (void)hipStreamSynchronize(c->pipe); return st; }
+        }
+    }
+    if (d->mode == SLR_MODE_GRAY && d->n_frames > 1 && c->opt_batch_streams > 1) {
+        SLR_HIP(c, hipEventRecord(c->ev_pipe[1], c->pipe));
+        SLR_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pipe[1], 0));
     }
     return SLR_OK;
 }
@@ -1649,6 +1681,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_RECT_DMA_DEPTH:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_DEPTH must be 1 or 2");
             c->opt_dma_depth = value;
+            return SLR_OK;
+        case SLR_OPT_BATCH_STREAMS:
+            if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_BATCH_STREAMS must be 1 or 2");
+            c->opt_batch_streams = value;
             return SLR_OK;
         case SLR_OPT_HYBRID_ONE_PASS:
             if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_HYBRID_ONE_PASS must be 0 or 1");

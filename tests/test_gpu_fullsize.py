@@ -360,6 +360,32 @@ def test_batch_entry_gray_only_two_frames_with_spare_planes(ctx, oracle, synth, 
     assert not torch.equal(xyz[0], xyz[1])                    # (the pair COUNTS are symmetric in the cameras, the points are not)
 
 
+def test_batch_entry_gray_only_frames_pipelined_over_two_streams(ctx, synth, slr):
+    """slr_reconstruct_batch in SLR_MODE_GRAY alternates its frames between two streams and two scratch sets: 7 different frames in
+    one call (each set reused by four / three frames, different sizes before and after so that the scratch is reallocated) ==
+    the same frames through slr_reconstruct_gray one at a time, twice in a row, and the context is usable right after"""
+    dev = torch.device("cuda", 0)
+    for (w, h, sw, sh, nf) in ((640, 96, 200, 60, 3), (1024, 768, 320, 256, 7), (512, 64, 128, 40, 2)):
+        calib, _ = synth.make_calibration(w, h, baseline=400.0, theta=0.6)
+        ctx.set_calibration(calib)
+        ncol, nrow = synth.gray_num_bits(sw), synth.gray_num_bits(sh)
+        stack = torch.stack([synth.render_gray_stack(w, h, sw, sh, seed=300 + f, noise=2 + f % 3, device=dev, rows=True) for f in range(nf)]).contiguous()
+        torch.cuda.synchronize()
+        one = [ctx.reconstruct_gray(stack[f, 0], stack[f, 1], ncol, nrow, BLACK, 0, sw, sh) for f in range(nf)]
+        ctx.synchronize()
+        for rep in range(3):
+            ctx.set_option(slr.capi.OPT_BATCH_STREAMS, 1 if rep == 2 else 2)
+            xyz, cnt, _ = ctx.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=sw, scan_h=sh,
+                                                rectify=False)
+            ctx.set_option(slr.capi.OPT_BATCH_STREAMS, 2)
+            again = ctx.reconstruct_gray(stack[0, 0], stack[0, 1], ncol, nrow, BLACK, 0, sw, sh)     # queued right behind the batch
+            ctx.synchronize()
+            for f in range(nf):
+                assert torch.equal(cnt[f], one[f][1]) and torch.equal(xyz[f], one[f][0]), (w, h, f, rep)
+            assert torch.equal(again[1], one[0][1]) and torch.equal(again[0], one[0][0])
+            assert (cnt[0] > 0).float().mean().item() > 0.2
+
+
 @pytest.mark.parametrize("theta,k1", [(0.2, -0.15), (0.3, -0.2)])
 def test_fullsize_verged_rig_maps_from_stereo_rectify(ctx, oracle, synth, scene, theta, k1):
     """Maps of a VERGED rig (keystone: rows tilt towards the image sides) built the way the reference builds them -- the host
