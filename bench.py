@@ -118,6 +118,8 @@ def parse_args():
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
+    ap.add_argument("--batch-streams", type=int, default=0,
+                    help="SLR_OPT_BATCH_STREAMS (0 = the library's default 2: GRAY_ONLY batches pipeline their frames over two streams; 1 = never)")
     ap.add_argument("--hybrid-one-pass", type=int, default=0,
                     help="--mode hybrid: 1 = SLR_OPT_HYBRID_ONE_PASS (one kernel over all 38 planes of a tile) instead of the default two "
                          "fused launches over the one stack")
@@ -418,6 +420,8 @@ def main():
             c_.set_option(slr.capi.OPT_RECT_DMA_SHAPE, args.dma_shape)
         if args.dma_depth >= 0:
             c_.set_option(slr.capi.OPT_RECT_DMA_DEPTH, args.dma_depth)
+        if args.batch_streams:
+            c_.set_option(slr.capi.OPT_BATCH_STREAMS, args.batch_streams)
         if args.hybrid_one_pass:
             c_.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 1)
         if rectify:
