@@ -117,3 +117,37 @@ def test_fuzz_match_kernels(ctx, oracle, synth, slr, seed):
     exyz, ehas, _, emk = oracle.ge_triangulate(cL, vL, cR, vR, Q, T)
     xyz, has, _, mk = ctx.ge_triangulate(cL, vL, cR, vR)
     assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz), (W, H, ncodes)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_ray_buckets(ctx, oracle, synth, slr, seed):
+    """K3' + K6 on random codes: bucket lengths from 0 to hundreds in one frame (the sorting-network form, its register rows 12..15,
+    the staged form and their mixtures inside one wave / workgroup), invalid pixels, codes beyond the projector (Q9), with and
+    without the transfer matrix"""
+    rng = np.random.default_rng(9000 + seed)
+    W, H = int(rng.integers(16, 260)), int(rng.integers(8, 120))
+    scan_w, scan_h = int(rng.integers(4, 80)), int(rng.integers(4, 60))
+    calib, _ = synth.make_calibration(W, H, with_T=bool(seed % 2), baseline=400.0, theta=0.6)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    def codes():
+        kind = rng.integers(0, 3)
+        if kind == 0:                                         # smooth (a camera looking at the projector): short buckets
+            cx = (np.arange(W)[None, :] * scan_w // W + rng.integers(-1, 2, (H, W))).astype(np.int32)
+            cy = (np.arange(H)[:, None] * scan_h // H + rng.integers(-1, 2, (H, W))).astype(np.int32)
+        elif kind == 1:                                       # uniform: lengths around W H / cells
+            cx = rng.integers(0, scan_w + 2, (H, W)).astype(np.int32); cy = rng.integers(0, scan_h + 2, (H, W)).astype(np.int32)
+        else:                                                 # a few cells take most pixels: long buckets beside empty ones
+            hot = rng.integers(0, scan_w, 5), rng.integers(0, scan_h, 5)
+            pick = rng.integers(0, 5, (H, W))
+            cx = np.where(rng.random((H, W)) < 0.7, hot[0][pick], rng.integers(0, scan_w, (H, W))).astype(np.int32)
+            cy = np.where(rng.random((H, W)) < 0.7, hot[1][pick], rng.integers(0, scan_h, (H, W))).astype(np.int32)
+        v = (rng.random((H, W)) < rng.choice([0.3, 0.8, 1.0])).astype(np.uint8)
+        return np.clip(cx, 0, None), np.clip(cy, 0, None), v
+    cxL, cyL, vL = codes()
+    cxR, cyR, vR = codes()
+    offL, itL = oracle.gray_bucket(cxL, cyL, vL, scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(cxR, cyR, vR, scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = ctx.ray_triangulate(cxL, cyL, vL, cxR, cyR, vR, scan_w, scan_h)
+    assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz), (W, H, scan_w, scan_h)
