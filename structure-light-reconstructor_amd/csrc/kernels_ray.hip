@@ -15,8 +15,11 @@
 // buckets are built as a counting sort -- histogram with returning atomics (rank inside the bucket, arbitrary
 // order), one exclusive scan over both cameras' histograms, scatter to offs[bucket]+rank -- and the push order is
 // restored inside each bucket by sorting its (few) pixels on (col,row), which IS the column-major walk order.
-// Buckets are numbered by their PointCloudImage cell  j*scan_w + i  (bucket ac = i*scan_h + j  <->  cell (j,i)),
-// so the triangulation kernel reads its ranges and writes its sums fully coalesced.
+// Buckets are numbered by their PointCloudImage cell  j*scan_w + i  (bucket ac = i*scan_h + j  <->  cell (j,i)).
+// Round 3: the whole-path entries decode inside the histogram kernel (gray_decode_count_kernel); K6 takes its cells from a work
+// list ordered by bucket lengths, made inside the scatter's launches (ray_scatter_list_kernel), and runs one wave per 64 cells
+// with the buckets in registers and per-lane LDS columns (ray_triangulate_small_kernel), longer buckets through LDS 256 cells
+// at a time (ray_triangulate_staged_kernel); DESIGN section 4 has the measurements.
 #include "slr_device.hpp"
 #include "decode_common.hpp"
 
