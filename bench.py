@@ -89,7 +89,7 @@ def parse_args():
                     help="mf: the metric's 3-freq x 4-step path (default); ge: GRAY_EPI (Gray columns + rectification); gray: GRAY_ONLY "
                          "(Gray columns + rows, ray-ray triangulation, 1280x1024 projector); hybrid: BASELINE config 3 -- Gray columns + "
                          "3-freq x 4-step fringes in one stack (38 planes per camera), decoded in ONE pass, then phase match + triangulation")
-    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident stereo frames per GPU per step (0 = 8; gray: 4)")
+    ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident stereo frames per GPU per step (0 = 8; hybrid: 4)")
     ap.add_argument("--traffic", choices=["auto", "live", "file", "off"], default="auto",
                     help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a 3-step child run, "
                          "file = profiles/pmc_traffic.json, auto = live when rocprofv3 is on PATH and N == 1")
@@ -394,7 +394,7 @@ def main():
     synth = importlib.import_module("structure-light-reconstructor_amd.synth")
     W, H = args.width, args.height
     mode = args.mode
-    F = args.frames if args.frames > 0 else (4 if mode in ("gray", "hybrid") else 8)
+    F = args.frames if args.frames > 0 else (4 if mode == "hybrid" else 8)
     if args.pmc_child:                                   # the rocprofv3 child of live_traffic(): one frame, three steps
         F, args.steps, args.warmup, args.profile, args.cpu_baseline, args.host_io, args.traffic = 1, 3, 1, 0, 0, 0, "off"
     scan_w, scan_h = (W, 0) if mode in ("ge", "hybrid") else ((1280, 1024) if mode == "gray" else (0, 0))
