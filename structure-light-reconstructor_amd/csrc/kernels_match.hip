@@ -1339,18 +1339,38 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
     for (int i = 0; i < IPT; i++)
         if (cr[i] >= 0) S[start[cr[i]] + rank[i]] = (unsigned short)(k0 + i);
     __syncthreads();
-    {   // ascending columns inside every list (the arrival order of the atomics is arbitrary)
-        unsigned lo = excl;
-#pragma unroll 1
+    {   // ascending columns inside every list (the arrival order of the atomics is arbitrary).  A camera sees a projector column in
+        // 1-4 pixels of a row: the thread reads the first four entries of each of its 8 lists at once (independent LDS reads,
+        // one latency instead of a chain of dependent ones per list: the insertion sort was 22 of the kernel's 87 us), sorts
+        // them in registers with 0xFFFF behind the list's end, and writes back what it changed; longer lists take the loop.
+        unsigned lo[kPer], e[kPer][4];
+        {
+            unsigned at = excl;
+#pragma unroll
+            for (int q = 0; q < kPer; q++) { lo[q] = at; at += c[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; q++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) e[q][i] = (unsigned)i < c[q] ? (unsigned)S[lo[q] + i < (unsigned)N ? lo[q] + i : (unsigned)N - 1u] : 0xFFFFu;
+#pragma unroll
         for (int q = 0; q < kPer; q++) {
-            const unsigned n = c[q];
-            for (unsigned i = lo + 1; i < lo + n; i++) {
-                const unsigned short v = S[i];
-                unsigned j = i;
-                while (j > lo && S[j - 1] > v) { S[j] = S[j - 1]; j--; }
-                S[j] = v;
+            if (c[q] < 2u) continue;
+            if (c[q] <= 4u) {
+                unsigned a0 = e[q][0], a1 = e[q][1], a2 = e[q][2], a3 = e[q][3];
+                const auto cx = [](unsigned &x, unsigned &y) { const unsigned lo_ = x < y ? x : y, hi_ = x < y ? y : x; x = lo_; y = hi_; };
+                cx(a0, a1); cx(a2, a3); cx(a0, a2); cx(a1, a3); cx(a1, a2);
+                S[lo[q]] = (unsigned short)a0; S[lo[q] + 1] = (unsigned short)a1;
+                if (c[q] > 2u) S[lo[q] + 2] = (unsigned short)a2;
+                if (c[q] > 3u) S[lo[q] + 3] = (unsigned short)a3;
+            } else {
+                for (unsigned i = lo[q] + 1; i < lo[q] + c[q]; i++) {
+                    const unsigned short v = S[i];
+                    unsigned j = i;
+                    while (j > lo[q] && S[j - 1] > v) { S[j] = S[j - 1]; j--; }
+                    S[j] = v;
+                }
             }
-            lo += n;
         }
     }
     __syncthreads();
