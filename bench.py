@@ -401,6 +401,8 @@ def main():
     ncol = synth.gray_num_bits(scan_w) if mode != "mf" else 0
     nrow = synth.gray_num_bits(scan_h) if mode == "gray" else 0
     ppc = 14 if mode == "mf" else 2 + 2 * ncol + 2 * nrow + (12 if mode == "hybrid" else 0)
+    if mode == "gray":                                   # the GRAY_ONLY decode with the bucket histogram inside, per camera launch:
+        ALG_BYTES["slr_gray_decode"] = float(ppc + 8)    # its planes read, cell + rank written
     rectify = (bool(args.rectify) or mode == "hybrid") and mode != "gray"      # GRAY_ONLY never rectifies (reconstruct.cpp:230-265)
 
     S = max(1, args.streams)
