@@ -1271,7 +1271,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
 // launch (deferred_only).  The triangulation is K4-lean's: one refined reciprocal for the three quotients, fma form of T.
 // Reference: Reconstruct::triangulation_ge Duke/reconstruct.cpp:555-611.
 // ------------------------------------------------------------------------------------------------------
-template <bool HAS_T>
+template <bool HAS_T, int TC>                          // TC: the list-head table's codes (8192, or 4096 when the caller's codes are known to fit)
 __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *__restrict__ codeL, const uint8_t *__restrict__ validL,
                                                                 const int32_t *__restrict__ codeR, const uint8_t *__restrict__ validR,
                                                                 int W, int H, K4Lean kc,
@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
                                                                 float *__restrict__ xyz, uint8_t *__restrict__ has,
                                                                 uint8_t *__restrict__ color, int32_t *__restrict__ match_k)
 {
-    constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, TC = 8192, kPer = TC / BLOCK, kMaxList = 32;
+    constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, kPer = TC / BLOCK, kMaxList = 32;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned start[TC + BLOCK + 1];             // counters, then list starts (start[TC] = total); [TC + 1 + tid]: atomics' sinks
@@ -1474,7 +1474,7 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
 
 hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR, const uint8_t *validR,
                            int W, int H, const DevCalib &cal, const uint8_t *whiteL, const uint8_t *whiteR,
-                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s)
+                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, int code_bound, hipStream_t s)
 {
     const int TC = 8192;                           // codes below this use the direct list-head table (16 KB LDS)
     int deferred_only = 0;
@@ -1484,10 +1484,13 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
         K4Lean kc;
         kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
         for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
-        if (cal.has_T) SLR_LAUNCH(ge_match_lean_kernel<true>, dim3(H), dim3(1024), 0, s, codeL, validL, codeR, validR, W, H, kc, whiteL,
-                                  whiteR, xyz, has, color, match_k);
-        else SLR_LAUNCH(ge_match_lean_kernel<false>, dim3(H), dim3(1024), 0, s, codeL, validL, codeR, validR, W, H, kc, whiteL, whiteR,
-                        xyz, has, color, match_k);
+        // code_bound: every valid code is below it (0 = unknown): a 12-bit Gray stack needs half the table, half the counters per
+        // thread to clear, scan and own (a code at or above the table's size only defers its row to the general kernel)
+#define SLR_GE_LEAN(T_, TC_) SLR_LAUNCH((ge_match_lean_kernel<T_, TC_>), dim3(H), dim3(1024), 0, s, codeL, validL, codeR, validR, W, H, kc, whiteL, whiteR, xyz, has, color, match_k)
+        const bool small_table = code_bound > 0 && code_bound <= 4096;
+        if (cal.has_T) { if (small_table) SLR_GE_LEAN(true, 4096); else SLR_GE_LEAN(true, 8192); }
+        else           { if (small_table) SLR_GE_LEAN(false, 4096); else SLR_GE_LEAN(false, 8192); }
+#undef SLR_GE_LEAN
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         deferred_only = 1;                          // the rows it marked (codes >= 8192, long lists) follow in the general kernel

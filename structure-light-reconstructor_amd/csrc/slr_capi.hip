@@ -910,7 +910,7 @@ int slr_ge_triangulate(slr_ctx *c, const int32_t *codeL, const uint8_t *validL, 
     { ProfScope ps(c, K_GE_MATCH, true);
       SLR_HIP(c, launch_ge_match((const int32_t *)cl, (const uint8_t *)vl, (const int32_t *)cr, (const uint8_t *)vr, W, H,
                                  c->cal, (const uint8_t *)wl, (const uint8_t *)wr, (float *)dx, (uint8_t *)dh,
-                                 (uint8_t *)dc, (int32_t *)dk, c->stream)); }
+                                 (uint8_t *)dc, (int32_t *)dk, 0, c->stream)); }
     return st.finish();
 }
 
@@ -1304,7 +1304,8 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
     }
     { ProfScope ps(c, K_GE_MATCH, true);
       SLR_HIP(c, launch_ge_match((const int32_t *)cxl, (const uint8_t *)vl, (const int32_t *)cxr, (const uint8_t *)vr, W, H,
-                                 c->cal, wl, wr, (float *)dx, (uint8_t *)dh, (uint8_t *)dc, nullptr, c->stream)); }
+                                 c->cal, wl, wr, (float *)dx, (uint8_t *)dh, (uint8_t *)dc, nullptr,
+                                 ncol < 31 ? 1 << ncol : 0, c->stream)); }   // (the decode's codes have ncol bits)
     return st.finish();
 }
 

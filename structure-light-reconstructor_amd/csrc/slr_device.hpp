@@ -167,7 +167,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const int32_t *codeR,
                            const uint8_t *validR, int W, int H, const DevCalib &cal,
                            const uint8_t *whiteL, const uint8_t *whiteR,
-                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, hipStream_t s);
+                           float *xyz, uint8_t *has, uint8_t *color, int32_t *match_k, int code_bound, hipStream_t s);
 
 // build extension: generalised n_freq x n_step fp16 multi-frequency decode (kernels_mfn.hip)
 hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
