@@ -1393,10 +1393,28 @@ struct GrayDma {
         else fo[q] = mx != kDmaSentinel ? dma_finish_q24(fo[q], dma_pair_q24((int)gxs[q], Pw)) : kInvalidPhase;
     }
     // the difference of pair j (>= 1) of a pixel goes where it belongs
+    template <bool WT>
     __device__ __forceinline__ void pair_step(int q, int j, int sd)
     {
-        if (!HYB || j <= ncol) bit_step(q, sd, j == ncol);
+        if (!HYB || j <= ncol) bit_step<WT>(q, sd);
         else fringe_step(q, j - 1 - ncol, sd);
+    }
+    // the differences of pair j of the thread's pixels.  Wave-uniform facts stay out of the per-pixel work: whether the contrast test
+    // can fire at all (whiteThreshold's default is 0, SURVEY Q10: it never does), and whether the column word is complete behind
+    // this pair -- together 7 of the 10 instructions a code bit used to cost per pixel.
+    __device__ __forceinline__ void pair_steps(int j, const int sd[PX])
+    {
+        if (white_thr > 0) {
+#pragma unroll
+            for (int q = 0; q < PX; q++) pair_step<true>(q, j, sd[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < PX; q++) pair_step<false>(q, j, sd[q]);
+        }
+        if ((!HYB || j <= ncol) && j == ncol) {              // the column word is complete: the row bits (if any) start from zero
+#pragma unroll
+            for (int q = 0; q < PX; q++) { gxs[q] = acc[q]; acc[q] = 0u; }
+        }
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
@@ -1406,13 +1424,13 @@ struct GrayDma {
             dma16(voff, rs_dig, lds0 + (unsigned)(DIG_OFF + r * NT * 16) + wave_off, 0u);
         }
     }
-    // code bit from a pair's difference (reconstruct.cpp:387-400 / 349-360); move: the column word is complete behind this bit
-    __device__ __forceinline__ void bit_step(int q, int df, bool move)
+    // code bit from a pair's difference (reconstruct.cpp:387-400 / 349-360); WT: the contrast test can fire (white_thr > 0)
+    template <bool WT>
+    __device__ __forceinline__ void bit_step(int q, int df)
     {
-        flags |= ((df < 0 ? -df : df) < white_thr ? 0x100u : 0u) << q;
-        acc[q] = (acc[q] << 1) | (df > 0 ? 1u : 0u);
-        gxs[q] = move ? acc[q] : gxs[q];
-        acc[q] = move ? 0u : acc[q];
+        if constexpr (WT) flags |= ((df < 0 ? -df : df) < white_thr ? 0x100u : 0u) << q;
+        // acc = 2 acc + (df > 0): a compare into VCC and an add-with-carry of acc to itself
+        asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc[q]) : "v"(df) : "vcc");
     }
     __device__ __forceinline__ void finish(int ty, int tx)
     {
@@ -1470,19 +1488,16 @@ struct GrayDma {
         {
             int sd[PX];
             dma_differences<PX, i00, i01, (unsigned)RS>(mode, tap, qbase, second, sd);
+            if constexpr (FIRST) {
 #pragma unroll
-            for (int q = 0; q < PX; q++) {
-                if constexpr (FIRST) {
-                    flags |= (sd[q] > black_thr ? 1u : 0u) << q;                       // computeShadows, reconstruct.cpp:218-224
-                } else pair_step(q, NPP * k, sd[q]);
-            }
+                for (int q = 0; q < PX; q++) flags |= (sd[q] > black_thr ? 1u : 0u) << q;   // computeShadows, reconstruct.cpp:218-224
+            } else pair_steps(NPP * k, sd);
         }
         if constexpr (NPP == 2) {
             if (2 * k + 1 < npairs) {                        // (a stack's last phase may hold one pair only)
                 int sd[PX];
                 dma_differences<PX, i10, i11, (unsigned)RS>(mode, tap, qbase, second, sd);
-#pragma unroll
-                for (int q = 0; q < PX; q++) pair_step(q, 2 * k + 1, sd[q]);
+                pair_steps(2 * k + 1, sd);
             }
         }
         __builtin_amdgcn_s_setprio(0);
