@@ -21,6 +21,7 @@
 //   K3' Reconstruct::decodePaterns/getProjPixel (col + row bits)                   Duke/reconstruct.cpp:56-74,325-370
 //       GrayCodes::grayToDec                                                       Duke/graycodes.cpp:116-128
 #include "decode_common.hpp"
+#include <type_traits>
 
 #include <stdlib.h>
 
@@ -1347,25 +1348,25 @@ __global__ __launch_bounds__(256) void gray_decode_kernel(GrayPlanes pl, int n_c
         int gx[V], gy[V], err[V];
 #pragma unroll
         for (int i = 0; i < V; i++) { gx[i] = 0; gy[i] = 0; err[i] = 0; }
-        for (int c = 0; c < n_col_bits; c++) {                       // reconstruct.cpp:387-400
-            const unsigned a = fetch(2 * c + 2), b = fetch(2 * c + 3);
+        // (the contrast test can only fire with a positive white threshold -- the reference's default is 0, SURVEY Q10 --: a
+        // wave-uniform fact, kept out of the per-pixel work; a code bit is then a byte compare and an add of the word to itself)
+        const auto bits = [&](int first, int n, int g[V], auto wt) {
+            for (int c = 0; c < n; c++) {
+                const unsigned a = fetch(first + 2 * c), b = fetch(first + 2 * c + 1);
 #pragma unroll
-            for (int i = 0; i < V; i++) {
-                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
-                const int df = v1 - v2;
-                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
-                gx[i] = (gx[i] << 1) | (v1 > v2 ? 1 : 0);
+                for (int i = 0; i < V; i++) {
+                    const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
+                    if constexpr (decltype(wt)::value) { const int df = v1 - v2; err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0; }
+                    g[i] = g[i] + g[i] + (v1 > v2 ? 1 : 0);
+                }
             }
-        }
-        for (int c = 0; c < n_row_bits; c++) {                       // reconstruct.cpp:349-360
-            const unsigned a = fetch(2 * c + 2 + 2 * n_col_bits), b = fetch(2 * c + 3 + 2 * n_col_bits);
-#pragma unroll
-            for (int i = 0; i < V; i++) {
-                const int v1 = (a >> (8 * i)) & 0xFF, v2 = (b >> (8 * i)) & 0xFF;
-                const int df = v1 - v2;
-                err[i] |= ((df < 0 ? -df : df) < white_thr) ? 1 : 0;
-                gy[i] = (gy[i] << 1) | (v1 > v2 ? 1 : 0);
-            }
+        };
+        if (white_thr > 0) {
+            bits(2, n_col_bits, gx, std::true_type{});                       // reconstruct.cpp:387-400
+            bits(2 + 2 * n_col_bits, n_row_bits, gy, std::true_type{});      // reconstruct.cpp:349-360
+        } else {
+            bits(2, n_col_bits, gx, std::false_type{});
+            bits(2 + 2 * n_col_bits, n_row_bits, gy, std::false_type{});
         }
         int cx[V], cy[V];
         unsigned vw = 0;
