@@ -1392,28 +1392,25 @@ struct GrayDma {
         else if (m == 3) { fo[q] = dma_pair_q24((int)gxs[q], Pw); gxs[q] = (unsigned)Pw; }
         else fo[q] = mx != kDmaSentinel ? dma_finish_q24(fo[q], dma_pair_q24((int)gxs[q], Pw)) : kInvalidPhase;
     }
-    // the difference of pair j (>= 1) of a pixel goes where it belongs
-    template <bool WT>
-    __device__ __forceinline__ void pair_step(int q, int j, int sd)
-    {
-        if (!HYB || j <= ncol) bit_step<WT>(q, sd);
-        else fringe_step(q, j - 1 - ncol, sd);
-    }
-    // the differences of pair j of the thread's pixels.  Wave-uniform facts stay out of the per-pixel work: whether the contrast test
-    // can fire at all (whiteThreshold's default is 0, SURVEY Q10: it never does), and whether the column word is complete behind
-    // this pair -- together 7 of the 10 instructions a code bit used to cost per pixel.
+    // the differences of pair j (>= 1) of the thread's pixels go where they belong.  Wave-uniform facts stay out of the per-pixel
+    // work: whether the contrast test can fire at all (whiteThreshold's default is 0, SURVEY Q10: it never does), and whether the
+    // column word is complete behind this pair -- together 7 of the 10 instructions a code bit used to cost per pixel.
     __device__ __forceinline__ void pair_steps(int j, const int sd[PX])
     {
-        if (white_thr > 0) {
+        if (!HYB || j <= ncol) {
 #pragma unroll
-            for (int q = 0; q < PX; q++) pair_step<true>(q, j, sd[q]);
+            for (int q = 0; q < PX; q++) bit_step(q, sd[q]);
+            if (white_thr > 0) {
+#pragma unroll
+                for (int q = 0; q < PX; q++) flags |= ((sd[q] < 0 ? -sd[q] : sd[q]) < white_thr ? 0x100u : 0u) << q;
+            }
+            if (j == ncol) {                                 // the column word is complete: the row bits (if any) start from zero
+#pragma unroll
+                for (int q = 0; q < PX; q++) { gxs[q] = acc[q]; acc[q] = 0u; }
+            }
         } else {
 #pragma unroll
-            for (int q = 0; q < PX; q++) pair_step<false>(q, j, sd[q]);
-        }
-        if ((!HYB || j <= ncol) && j == ncol) {              // the column word is complete: the row bits (if any) start from zero
-#pragma unroll
-            for (int q = 0; q < PX; q++) { gxs[q] = acc[q]; acc[q] = 0u; }
+            for (int q = 0; q < PX; q++) fringe_step(q, j - 1 - ncol, sd[q]);
         }
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
@@ -1424,12 +1421,10 @@ struct GrayDma {
             dma16(voff, rs_dig, lds0 + (unsigned)(DIG_OFF + r * NT * 16) + wave_off, 0u);
         }
     }
-    // code bit from a pair's difference (reconstruct.cpp:387-400 / 349-360); WT: the contrast test can fire (white_thr > 0)
-    template <bool WT>
+    // code bit from a pair's difference (reconstruct.cpp:387-400 / 349-360): acc = 2 acc + (df > 0), a compare into VCC and an
+    // add-with-carry of acc to itself
     __device__ __forceinline__ void bit_step(int q, int df)
     {
-        if constexpr (WT) flags |= ((df < 0 ? -df : df) < white_thr ? 0x100u : 0u) << q;
-        // acc = 2 acc + (df > 0): a compare into VCC and an add-with-carry of acc to itself
         asm("v_cmp_lt_i32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc[q]) : "v"(df) : "vcc");
     }
     __device__ __forceinline__ void finish(int ty, int tx)
