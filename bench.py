@@ -118,6 +118,8 @@ def parse_args():
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
+    ap.add_argument("--debug-flags", type=int, default=0,
+                    help="SLR_OPT_DEBUG_FLAGS (A/B runs of forms with identical results, e.g. 32 = map digests without the quad sort)")
     ap.add_argument("--batch-streams", type=int, default=0,
                     help="SLR_OPT_BATCH_STREAMS (0 = the library's default 2: GRAY_ONLY batches pipeline their frames over two streams; 1 = never)")
     ap.add_argument("--hybrid-one-pass", type=int, default=0,
@@ -257,7 +259,7 @@ def live_traffic(args, kernel_name):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "1", "--mode", args.mode, "--width", str(args.width), "--height", str(args.height),
                "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--dma-shape", str(args.dma_shape),
-               "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad)]
+               "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
             got = []
@@ -424,6 +426,8 @@ def main():
             c_.set_option(slr.capi.OPT_RECT_DMA_DEPTH, args.dma_depth)
         if args.batch_streams:
             c_.set_option(slr.capi.OPT_BATCH_STREAMS, args.batch_streams)
+        if args.debug_flags:
+            c_.set_option(slr.capi.OPT_DEBUG_FLAGS, args.debug_flags)
         if args.hybrid_one_pass:
             c_.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 1)
         if rectify:
@@ -712,6 +716,7 @@ def main():
                        "maps": ("synthetic near-identity rectification maps (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / -0.06); "
                                 "verged rigs: see realistic_maps") if rectify else None,
                        "mode": mode, "frames_per_gpu_per_step": F, "rectify": rectify, "streams_per_gpu": S,
+                       "debug_flags": args.debug_flags,
                        "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
                            world, ", RCCL all-gather of XYZ+mask after every step (overlapped)" if do_gather else

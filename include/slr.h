@@ -132,7 +132,9 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * entries instead of the digest, bit 1 = per-plane pointers instead of one buffer descriptor, bit 2 = the general Gray-code match
  * kernel for every row (instead of only the rows its lean form defers), bit 3 = slr_reconstruct_gray decodes into code
  * arrays and counts the buckets in a second kernel (instead of one fused kernel per camera), bit 4 = the LDS-tiled fused Gray
- * decode takes its 64 x 4 tiles (the form of stacks of 42 planes and more) whatever the plane count.  SLR_OPT_DEBUG_K4_STOP exists only
+ * decode takes its 64 x 4 tiles (the form of stacks of 42 planes and more) whatever the plane count, bit 5 = the map digests of the
+ * LDS-DMA fused decodes leave every wave the quads of its own block of a tile (instead of handing a tile's straddling quads to as
+ * few waves as hold them; installed maps are digested again when the bit changes).  SLR_OPT_DEBUG_K4_STOP exists only
  * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9

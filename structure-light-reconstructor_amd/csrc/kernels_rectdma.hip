@@ -86,15 +86,17 @@ static int dma_shape_th(int shape) { return shape == 0 || shape == 3 || shape ==
 // map digest, one dword per destination pixel, [tile][thread][pass][pixel of the quad] (a thread's PX entries are contiguous):
 //   [12:2]  dword index of the tap's upper left byte in a plane's LDS image: (sy - y0) * (CMAX * 4) + ((sx - x0) >> 2)
 //   [14:13] (sx - x0) & 3
-//   [31:16] 4 * (fy << 5 | fx)  (cv::remap's 5-bit fractions: the byte offset of the pixel's entry in the weight tables), or
+//   [28:16] 4 * (fy << 5 | fx)  (cv::remap's 5-bit fractions: the byte offset of the pixel's entry in the weight tables), or
 //           4 * 1024: the sample is 0 (pixel beyond the ragged image edge, or footprint completely outside the source)
+//   [31:29] of a quad's entries 0 .. 3: bits 2:0, 5:3, 8:6, 11:9 of the quad's SLOT in the tile, tile row << 6 | quad column --
+//           where the decode stores the quad's results (see "quads sorted by class" in dma_tiles_kernel)
 // and the QUAD's class, from which the kernel picks a wave-uniform way of reading the taps:
 //   class 0: all four pixels' taps lie in source rows r0, r0+1 and in the two dwords c0, c0+1 of those rows -> 4 dword reads per
 //            plane serve the whole quad (instead of 4 per pixel); class 1: the same with rows r0 .. r0+2 (the quad straddles a
 //            step of sy); class 2: anything else (the per-pixel reads).  With a scale near 1 a quad spans source bytes
 //            x .. x+4 -- always inside two dwords -- so class 2 is borders and strongly distorting maps.
 //   bit 0   the pixel's dword column minus c0 (0 / 1), bit 1: its sy minus r0 (0 / 1); classes 0 and 1 only
-//   bit 15  entry 0: class & 1, entry 1: class >> 1
+//   bit 15  entry 0: class & 1, entry 1: class >> 1, entry 2: the quad is not the one the thread's position names (it was moved)
 //   A zero-sample pixel inside a class 0 / 1 quad carries the quad's base address (r0, c0) in [12:2]: entry 0 always yields it.
 // box table: int4 per tile = x0 (multiple of 16, may be negative), y0, chunks per row, rows; z == 0: nothing to fetch
 constexpr unsigned kDmaZeroEntry = 1024u << 18;
@@ -114,7 +116,7 @@ template <int TW, int TH, int NT>
 __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
                                                        int W, int H, int tiles_x, int4 *__restrict__ boxes,
                                                        unsigned *__restrict__ digest, unsigned *__restrict__ nofit,
-                                                       unsigned *__restrict__ nofit_list, unsigned promote)
+                                                       unsigned *__restrict__ nofit_list, unsigned promote, int sort_quads)
 {
     typedef DmaGeom<TW, TH, NT> Gm;
     constexpr int NW = Gm::NWAVES;
@@ -126,22 +128,31 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int sxs[Gm::PX], sys[Gm::PX];
     unsigned frs[Gm::PX];
-    int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+    int gq[Gm::NQ];                                          // the quads this thread's slots decode (DmaGeom numbering)
+    auto load_quad = [&](int p) {                            // map entries of quad gq[p]
 #pragma unroll
-    for (int q = 0; q < Gm::PX; q++) {
-        const int g = (q >> 2) * NT + (int)threadIdx.x;
-        const int row = ty * TH + Gm::quad_row(g), col = tx * TW + Gm::quad_col(g) + (q & 3);
-        sxs[q] = 0x7FFFFFFF; sys[q] = 0; frs[q] = 0;
-        if (row < H && col < W) {
-            const size_t m = (size_t)row * W + col;
-            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
-            if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {       // footprints completely outside read 0
-                sxs[q] = sx; sys[q] = sy; frs[q] = map_frac[m] & 1023u;
-                mnx = sx < mnx ? sx : mnx; mxx = sx > mxx ? sx : mxx;
-                mny = sy < mny ? sy : mny; mxy = sy > mxy ? sy : mxy;
+        for (int i = 0; i < 4; i++) {
+            const int q = 4 * p + i;
+            const int row = ty * TH + Gm::quad_row(gq[p]), col = tx * TW + Gm::quad_col(gq[p]) + i;
+            sxs[q] = 0x7FFFFFFF; sys[q] = 0; frs[q] = 0;
+            if (row < H && col < W) {
+                const size_t m = (size_t)row * W + col;
+                const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+                if (!(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {   // footprints completely outside read 0
+                    sxs[q] = sx; sys[q] = sy; frs[q] = map_frac[m] & 1023u;
+                }
             }
         }
-    }
+    };
+    int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+#pragma unroll
+    for (int p = 0; p < Gm::NQ; p++) { gq[p] = p * NT + (int)threadIdx.x; load_quad(p); }
+#pragma unroll
+    for (int q = 0; q < Gm::PX; q++)
+        if (sxs[q] != 0x7FFFFFFF) {
+            mnx = sxs[q] < mnx ? sxs[q] : mnx; mxx = sxs[q] > mxx ? sxs[q] : mxx;
+            mny = sys[q] < mny ? sys[q] : mny; mxy = sys[q] > mxy ? sys[q] : mxy;
+        }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         int t;
@@ -204,11 +215,10 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
     const int level = slevel, part = level > 1 ? wv / (NW / level) : 0;
     const int x0 = spart[part][0], y0 = spart[part][1], fits = spart[part][2];
     const size_t ent = (size_t)(unsigned)spart[part][3];
-    unsigned tcls = 0;                                      // the thread's read class over its quads (what dma_tap_setup sees)
-#pragma unroll
-    for (int p = 0; p < Gm::NQ; p++) {
-        // the quad's class and base (r0, c0) over its pixels that sample anything
-        int r0 = 0x7FFFFFFF, r1 = -0x7FFFFFFF, c0 = 0x7FFFFFFF, c1 = -0x7FFFFFFF;
+    // the class and base (r0, c0) of the quad in slot p, over its pixels that sample anything
+    auto quad_class = [&](int p, int &r0, int &c0) -> unsigned {
+        int r1 = -0x7FFFFFFF, c1 = -0x7FFFFFFF;
+        r0 = 0x7FFFFFFF; c0 = 0x7FFFFFFF;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int q = 4 * p + i;
@@ -225,7 +235,83 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             const int q = 4 * p + i;
             if (fits && sxs[q] != 0x7FFFFFFF && (sxs[q] - x0) - 4 * c0 > 6) wide = true;
         }
-        unsigned cls = wide ? 2u : (r1 > r0 ? 1u : 0u);
+        return wide ? 2u : (r1 > r0 ? 1u : 0u);
+    };
+    // Quads sorted by class.  The decode reads a wave's taps in ONE mode, so a single straddling quad makes its whole wave pay the
+    // three-row (or per-pixel) reads -- and the steps of sy run down the image in strips every 1 / slope pixels: on the keystone
+    // maps of verged rigs 5-8 % of the quads put 60 % of the waves into the dear modes.  A tile that is decoded whole therefore
+    // hands its class 1 / 2 quads to as few waves as hold them (the waves that have the most already), in exchange for plain
+    // quads of those waves; every quad carries its slot in the tile (digest bits 31:29), which is where the decode stores it.
+    if (sort_quads) {                                        // (kernel argument: block-uniform)
+        __shared__ unsigned short lst_a[Gm::NQ * NT], lst_c[Gm::NQ * NT];
+        __shared__ int cnt_a[NW * Gm::NQ], cnt_c[NW * Gm::NQ], wbad[NW];
+        __shared__ unsigned ssink;
+        bool bad[Gm::NQ];
+        int nbad = 0;
+#pragma unroll
+        for (int p = 0; p < Gm::NQ; p++) {
+            int r0, c0;
+            bad[p] = level == 1 && fits && quad_class(p, r0, c0) != 0u;
+            nbad += __popcll(__ballot(bad[p]));
+        }
+        if (lane == 0) wbad[wv] = nbad;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int total = 0, holders = 0;
+            for (int w = 0; w < NW; w++) { total += wbad[w]; holders += wbad[w] > 0 ? 1 : 0; }
+            const int need = (total + 64 * Gm::NQ - 1) / (64 * Gm::NQ);
+            unsigned sink = 0;
+            if (need < holders)                              // (otherwise no exchange lowers the number of waves that pay)
+                for (int k = 0; k < need; k++) {
+                    int best = -1;
+                    for (int w = 0; w < NW; w++)
+                        if (!((sink >> w) & 1u) && (best < 0 || wbad[w] >= wbad[best])) best = w;
+                    sink |= 1u << best;
+                }
+            ssink = sink;
+        }
+        __syncthreads();
+        const unsigned sink = ssink;
+        if (sink != 0u) {                                    // (block-uniform)
+            const bool mine = ((sink >> wv) & 1u) != 0;
+            unsigned long long ba[Gm::NQ], bc[Gm::NQ];
+#pragma unroll
+            for (int p = 0; p < Gm::NQ; p++) {
+                ba[p] = __ballot(bad[p] && !mine);           // class 1 / 2 quads outside the sink waves ...
+                bc[p] = __ballot(!bad[p] && mine);           // ... change places with plain quads inside them, in slot order
+                if (lane == 0) { cnt_a[wv * Gm::NQ + p] = __popcll(ba[p]); cnt_c[wv * Gm::NQ + p] = __popcll(bc[p]); }
+            }
+            __syncthreads();
+            int base_a = 0, base_c = 0, total_a = 0;
+            for (int j = 0; j < NW * Gm::NQ; j++) {
+                if (j < wv * Gm::NQ) { base_a += cnt_a[j]; base_c += cnt_c[j]; }
+                total_a += cnt_a[j];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int rank[Gm::NQ];
+#pragma unroll
+            for (int p = 0; p < Gm::NQ; p++) {
+                const int ra = base_a + __popcll(ba[p] & below), rc = base_c + __popcll(bc[p] & below);
+                rank[p] = -1;
+                if (bad[p] && !mine) { lst_a[ra] = (unsigned short)gq[p]; rank[p] = ra; }
+                if (!bad[p] && mine) { lst_c[rc] = (unsigned short)gq[p]; rank[p] = rc; }
+                base_a += __popcll(ba[p]); base_c += __popcll(bc[p]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < Gm::NQ; p++) {
+                const int own = gq[p];
+                if (bad[p] && !mine) gq[p] = lst_c[rank[p]];
+                else if (!bad[p] && mine && rank[p] < total_a) gq[p] = lst_a[rank[p]];
+                if (gq[p] != own) load_quad(p);
+            }
+        }
+    }
+    unsigned tcls = 0;                                      // the thread's read class over its quads (what dma_tap_setup sees)
+#pragma unroll
+    for (int p = 0; p < Gm::NQ; p++) {
+        int r0, c0;
+        unsigned cls = quad_class(p, r0, c0);
         // The decode reads a wave's taps in ONE mode.  The three-row mode blends a third row for every pixel POSITION (0 .. 3 of a
         // quad) at which some lane's pixel lies in its quad's lower row pair: +4 VALU instructions per position, plane pair and
         // pixel, in a kernel that is bound by VALU issue.  The per-pixel mode costs LDS reads instead (32 instead of 12 dwords per
@@ -267,6 +353,8 @@ __global__ __launch_bounds__(NT) void dma_tiles_kernel(const int16_t *__restrict
             }
             if (i == 0) e |= (cls & 1u) << 15;
             if (i == 1) e |= (cls >> 1) << 15;
+            if (i == 2) e |= gq[p] != p * NT + (int)threadIdx.x ? 1u << 15 : 0u;
+            e |= (((unsigned)(Gm::quad_row(gq[p]) << 6 | Gm::quad_col(gq[p]) >> 2) >> (3 * i)) & 7u) << 29;
             digest[ent * (TW * TH) + threadIdx.x * Gm::PX + q] = e;      // (a part's digest holds its own waves' slots only)
         }
     }
@@ -294,7 +382,7 @@ size_t dma_tile_count_of(int W, int H, int shape) { return dma_tile_count(W, H, 
 unsigned dma_extra_entries_capacity(int W, int H, int shape) { return dma_extra_capacity((unsigned)dma_tile_count(W, H, shape)); }
 
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape, bool promote,
-                            unsigned *nofit_host, hipStream_t s)
+                            bool sort_quads, unsigned *nofit_host, hipStream_t s)
 {
     char *b = reinterpret_cast<char *>(buf);
     int4 *boxes = reinterpret_cast<int4 *>(b);
@@ -307,7 +395,7 @@ hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int
     if (e != hipSuccess) return e;
     const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
     const dim3 grid((unsigned)dma_tile_count(W, H, shape));
-#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit, nofit_list, promote ? kDmaPromote : kDmaNoPromote)
+#define SLR_DMA_X(TW, TH, NT) SLR_LAUNCH((dma_tiles_kernel<TW, TH, NT>), grid, dim3(NT), 0, s, map_xy, map_frac, W, H, tiles_x, boxes, digest, nofit, nofit_list, promote ? kDmaPromote : kDmaNoPromote, sort_quads ? 1 : 0)
     SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
     e = hipGetLastError();
@@ -452,7 +540,7 @@ __device__ __forceinline__ unsigned dma_blend3(const DmaRd3 &r, int g, const Dma
 // 8 bytes x 2 rows, 1 = 8 bytes x 3 rows, 2 = per pixel.  Sets the per-pixel tap state and the quads' base addresses.
 template <int PX, int RS, int WT_OFF, int WT1_OFF>
 __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0, const unsigned *dg, DmaTap tap[PX], unsigned qbase[PX / 4],
-                                             unsigned &second)
+                                             unsigned &second, unsigned oslot[PX / 4])
 {
     unsigned e[PX];
     unsigned cls = 0;
@@ -463,6 +551,11 @@ __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0,
         const unsigned c = ((e[4 * p] >> 15) & 1u) | ((e[4 * p + 1] >> 14) & 2u);
         cls = c > cls ? c : cls;
         qbase[p] = ((e[4 * p] & 0x1FFCu) - ((e[4 * p] >> 1) & 1u) * (unsigned)RS - (e[4 * p] & 1u) * 4u) | lds0;
+        // the quad's slot in the tile (row << 6 | quad column): three bits from the top of each entry, one funnel shift each
+        unsigned sl = e[4 * p + 3] >> 29;
+        sl = __builtin_amdgcn_alignbit(sl, e[4 * p + 2], 29);
+        sl = __builtin_amdgcn_alignbit(sl, e[4 * p + 1], 29);
+        oslot[p] = __builtin_amdgcn_alignbit(sl, e[4 * p], 29);
     }
 #if defined(SLR_DMA_FORCE_MODE) && SLR_DMA_FORCE_MODE == 10      // timing probe: every wave takes mode 0, all three paths compiled
     const int mode = __builtin_amdgcn_readfirstlane(__ballot(cls == 7u) != 0ull ? 2 : (__ballot(cls == 6u) != 0ull ? 1 : 0));
@@ -474,12 +567,12 @@ __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0,
     second = 0;
 #pragma unroll
     for (int q = 0; q < PX; q++) {
-        const unsigned *wt = reinterpret_cast<const unsigned *>(smem + (e[q] >> 16));
+        const unsigned *wt = reinterpret_cast<const unsigned *>(smem + ((e[q] >> 16) & 0x1FFFu));
         const unsigned sh = (e[q] >> 13) & 3u;
         const unsigned o = mode == 2 ? sh : sh + ((e[q] & 1u) << 2);           // byte offset of the left tap in the 8 bytes read
         tap[q].sel = __umul24(o, 0x10001u) + 0x0C010C00u;
         unsigned w0, w1;
-        if constexpr (WT_OFF < 0) { dma_weights(e[q] >> 18, w0, w1); (void)wt; }   // no weight tables in this kernel's LDS
+        if constexpr (WT_OFF < 0) { dma_weights((e[q] >> 18) & 0x7FFu, w0, w1); (void)wt; }   // no weight tables in this kernel's LDS
         else { w0 = wt[WT_OFF / 4]; w1 = wt[WT1_OFF / 4]; }
         if (mode == 1) {                                     // weights of rows 0, 1, 2 of the quad (the pixel's own rows: st, st + 1)
             const bool st = ((e[q] >> 1) & 1u) != 0;
@@ -738,6 +831,7 @@ struct DmaDecode {
     // per-tile state
     DmaTap tap[PX];
     unsigned qbase[PX / 4];              // LDS address of the 8-byte window of each quad (read modes 0 and 1)
+    unsigned oslot[PX / 4];              // where the quad's results go: tile row << 6 | quad column (the digest's slot field); kept until the flush
     unsigned second;                     // bit q (wave-uniform): some lane's pixel q blends rows 1, 2 of its quad's three (read mode 1)
     int mode;                            // the wave's read mode for this tile (dma_tap_setup)
     // validity.  HASVALID: bit q of ok = pixel q passed the shadow mask and every (n | d) != 0 so far, bit 16 + q = the mask
@@ -758,8 +852,7 @@ struct DmaDecode {
     {
 #pragma unroll
         for (int p = 0; p < PX / 4; p++) {
-            const int g = p * NT + (int)threadIdx.x;
-            const int row = out_ty * TH + Gm::quad_row(g), col = out_tx * TW + Gm::quad_col(g);
+            const int row = out_ty * TH + (int)(oslot[p] >> 6), col = out_tx * TW + (int)(oslot[p] & 63u) * 4;
             const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             if constexpr (HASVALID) {
@@ -820,7 +913,7 @@ struct DmaDecode {
             if (out_pending) flush();
             // tap state of the tile's pixels from the digest, and the wave's read mode for the tile
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second, oslot);
             ok = 0;
         }
         constexpr unsigned img0 = (unsigned)(((K0 + P) % D) * 2 * PS), img1 = img0 + PS;
@@ -1323,6 +1416,7 @@ struct GrayDma {
     float fo[PX];
     DmaTap tap[PX];
     unsigned qbase[PX / 4], second;      // (the quad read modes of the MF kernel: dma_tap_setup)
+    unsigned oslot[PX / 4];              // the quads' slots in the tile (see the MF kernel)
     int mode;
     unsigned acc[PX], gxs[PX];           // Gray bits of the axis in flight (MSB first); the finished column word
     unsigned flags;                      // bit q: shadow mask of pixel q, bit 8 + q: error
@@ -1336,8 +1430,7 @@ struct GrayDma {
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int p = 0; p < PX / 4; p++) {
-            const int g = p * NT + (int)threadIdx.x;
-            const int row = out_ty * TH + Gm::quad_row(g), col = out_tx * TW + Gm::quad_col(g);
+            const int row = out_ty * TH + (int)(oslot[p] >> 6), col = out_tx * TW + (int)(oslot[p] & 63u) * 4;
             const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
             const u32x4_t vx = {(unsigned)out_x[4 * p], (unsigned)out_x[4 * p + 1], (unsigned)out_x[4 * p + 2], (unsigned)out_x[4 * p + 3]};
@@ -1473,7 +1566,7 @@ struct GrayDma {
         }
         if constexpr (FIRST) {
             const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
-            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second);
+            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second, oslot);
 #pragma unroll
             for (int q = 0; q < PX; q++) { acc[q] = 0; gxs[q] = 0; }
             flags = 0;

@@ -646,12 +646,12 @@ static int build_dma_tiles(slr_ctx *c, int cam)
     // first with the three-row read mode for every wave whose quads straddle source rows; when few waves do (at most 35 %: mild
     // maps), again with the heavily straddling ones promoted to per-pixel reads (launch_dma_tiles; the decision needs the count)
     SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape, false,
-                                c->dma_stats[cam], c->stream));
+                                !c->debug.no_quad_sort, c->dma_stats[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     const unsigned long long waves = (unsigned long long)c->dma_stats[cam][4] + c->dma_stats[cam][5] + c->dma_stats[cam][6];
     if (c->dma_stats[cam][5] > 0 && 100ull * c->dma_stats[cam][5] <= 35ull * waves) {
         SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape, true,
-                                    c->dma_stats[cam], c->stream));
+                                    !c->debug.no_quad_sort, c->dma_stats[cam], c->stream));
         SLR_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->dma_shape_built[cam] = c->opt_dma_shape;
@@ -1667,12 +1667,18 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 31) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..31");
+            if (value < 0 || value > 63) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..63");
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
             c->debug.no_ge_lean = (value & 4) != 0;
             c->debug.no_decode_count = (value & 8) != 0;
             c->debug.gray_small_tiles = (value & 16) != 0;
+            if (c->debug.no_quad_sort != ((value & 32) != 0)) {      // the map digests of the LDS-DMA forms are built either way
+                c->debug.no_quad_sort = (value & 32) != 0;
+                for (int cam = 0; cam < 2; cam++)
+                    if (c->d_map_xy[cam] && c->d_dma_tiles[cam]) SLR_TRY(build_dma_tiles(c, cam));
+                SLR_HIP(c, hipStreamSynchronize(c->stream));
+            }
             return SLR_OK;
 #ifdef SLR_DEBUG_HOOKS
         case SLR_OPT_DEBUG_K4_STOP:

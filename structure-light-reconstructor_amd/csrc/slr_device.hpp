@@ -66,6 +66,7 @@ struct DebugKnobs {
     bool no_buffer_form = false; // fused decode: per-plane pointers instead of one buffer descriptor
     bool no_ge_lean = false;     // K5: the general kernel for every row
     bool no_decode_count = false;// GRAY_ONLY: separate decode and bucket-histogram kernels
+    bool no_quad_sort = false;   // LDS-DMA fused decodes: every wave keeps the quads of its own block of the tile (read when maps are installed)
     bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
     int k4_stop = 0;
 };
@@ -125,6 +126,7 @@ size_t     dma_tile_count_of(int W, int H, int shape);
 unsigned   dma_extra_entries_capacity(int W, int H, int shape);
 hipError_t launch_dma_tiles(const int16_t *map_xy, const uint16_t *map_frac, int W, int H, void *buf, int shape,
                             bool promote /* waves whose quads straddle source rows at several pixel positions read per pixel */,
+                            bool sort_quads /* a tile's straddling quads handed to as few of its waves as hold them */,
                             unsigned *nofit_host, hipStream_t s);
 // the tiles whose source box does not fit the form (launch_dma_tiles counted and listed them) are rewritten by a gather pass
 // behind the main kernel: it needs the camera's original maps and the count

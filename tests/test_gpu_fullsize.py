@@ -426,3 +426,40 @@ def test_fullsize_verged_rig_maps_from_stereo_rectify(ctx, oracle, synth, scene,
         cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
         ctx.synchronize()
         assert bits_equal(np_of(cx), ex) and bits_equal(np_of(v), ev), cam
+
+
+@pytest.mark.parametrize("theta,k1", [(0.1, -0.10), (0.3, -0.2)])
+def test_verged_rig_quads_sorted_by_class(ctx, synth, scene, slr, theta, k1):
+    """A tile's straddling quads are handed to as few of its waves as hold them when the maps are installed (dma_tiles_kernel,
+    "quads sorted by class"; every quad carries its slot in the tile): the fused multi-frequency pair decode and the fused Gray
+    decode give bit for bit what they give with every wave on the quads of its own block (SLR_OPT_DEBUG_FLAGS bit 5), and far
+    fewer waves take the three-row / per-pixel read modes."""
+    st = scene[0]
+    rig = synth.make_verged_rig(W, H, theta, k1)
+    g = synth.render_gray_stack(W, H, 1024, seed=11, noise=2, device=st.device)
+    ncol = synth.gray_num_bits(1024)
+    got = {}
+    try:
+        for flags in (32, 0):
+            ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
+            synth.install_verged_maps(ctx, rig, W, H)
+            info = [ctx.rectify_info(cam) for cam in range(2)]
+            ph, vd = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=True)
+            ctx.synchronize()
+            outs = [ph[0].clone(), ph[1].clone(), vd[0].clone(), vd[1].clone()]
+            for cam in range(2):
+                cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
+                ctx.synchronize()
+                outs += [cx.clone(), v.clone()]
+            got[flags] = (info, outs)
+    finally:
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+    print("verged rig theta %.1f: own blocks %s, sorted %s" % (theta, [i["waves_by_mode"] for i in got[32][0]],
+                                                               [i["waves_by_mode"] for i in got[0][0]]))
+    for a, b in zip(got[32][1], got[0][1]):
+        assert torch.equal(a.view(torch.uint8) if a.dtype != torch.uint8 else a, b.view(torch.uint8) if b.dtype != torch.uint8 else b)
+    for cam in range(2):
+        own, srt = got[32][0][cam], got[0][0][cam]
+        assert own["mf_form"] == 7 and srt["mf_form"] == 7
+        assert own["quads_by_class"][0] + own["quads_by_class"][1] + own["quads_by_class"][2] == sum(srt["quads_by_class"])
+        assert 2 * (srt["waves_by_mode"][1] + srt["waves_by_mode"][2]) < own["waves_by_mode"][1] + own["waves_by_mode"][2], (own, srt)
