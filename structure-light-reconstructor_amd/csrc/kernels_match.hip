@@ -14,7 +14,7 @@
 // no FMA contraction changes a rounding.
 #include "slr_device.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/block/block_radix_sort.hpp>
 
 // stage ablation of the match kernels (profiles/k4_stages.sh): "leave after stage N, outputs are not written".  Only builds with
 // -DSLR_DEBUG_HOOKS contain the exits; the production kernels carry none of them.
@@ -341,12 +341,11 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
     constexpr int TS = 2 * N;                            // hash slots (power of two, load factor <= 0.5)
     constexpr int kPer = kBins / BLOCK;                  // bins per thread (kBins is a multiple of BLOCK)
     constexpr unsigned kEmpty = 0xFFFFFFFFu;             // a NaN pattern: never a candidate's phase bits
-    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
     __shared__ union {
         struct { unsigned key[TS]; unsigned mink[TS]; } t;               // phase bits -> smallest column
         struct { float2 pk[N]; unsigned binstart[kBins + 1]; } b;        // (phi, column as bits) grouped by bin; bin index
     } sh;
-    __shared__ typename ScanU::TempStorage scan_tmp;
+    __shared__ unsigned scan_tmp[BLOCK / 64];
 
     const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
     const size_t base = (size_t)blockIdx.x * W;
@@ -411,8 +410,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
         unsigned c[kPer], sum = 0;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { c[q] = sh.b.binstart[tid * kPer + q]; sum += c[q]; }
-        unsigned excl, total;
-        ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+        unsigned total;
+        unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);
 #pragma unroll
         for (int q = 0; q < kPer; q++) { sh.b.binstart[tid * kPer + q] = excl; excl += c[q]; }   // own bins only: no hazard
         if (tid == 0) sh.b.binstart[kBins] = total;
@@ -734,12 +733,11 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
     constexpr int kPer = kBins / BLOCK;
     constexpr unsigned kEmpty = 0xFFFFFFFFu;
     constexpr unsigned kOpen = 0xFFFFu, kNever = 0xFFFEu;
-    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
     __shared__ union {
         struct { unsigned key[TS]; unsigned mink[TS]; } t;
         struct { float2 pk[N]; unsigned binstart[kBins + 1]; } b;
     } sh;
-    __shared__ typename ScanU::TempStorage scan_tmp;
+    __shared__ unsigned scan_tmp[BLOCK / 64];
 
     const int row = blockIdx.x + row0, tid = threadIdx.x;
     const size_t base = (size_t)blockIdx.x * W;
@@ -801,8 +799,8 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
                 unsigned c[kPer], sum = 0;
 #pragma unroll
                 for (int q = 0; q < kPer; q++) { c[q] = sh.b.binstart[tid * kPer + q]; sum += c[q]; }
-                unsigned excl, total;
-                ScanU(scan_tmp).ExclusiveSum(sum, excl, total);
+                unsigned total;
+                unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);
 #pragma unroll
                 for (int q = 0; q < kPer; q++) { sh.b.binstart[tid * kPer + q] = excl; excl += c[q]; }
                 if (tid == 0) sh.b.binstart[kBins] = total;
@@ -884,20 +882,18 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
                                                               uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
 {
     constexpr int N = BLOCK * IPT;
-    typedef hipcub::BlockRadixSort<unsigned, BLOCK, IPT> Sort;     // keys only: (group << 16) | k
-    typedef hipcub::BlockScan<int, BLOCK> Scan;
-    typedef hipcub::BlockScan<unsigned, BLOCK> ScanU;
+    typedef rocprim::block_radix_sort<unsigned, BLOCK, IPT> Sort;  // keys only: (group << 16) | k
     __shared__ union {
-        typename Sort::TempStorage sort;
+        typename Sort::storage_type sort;
         struct { float2 pk[N]; } d;                      // distinct values: (phi, min column as bits)
     } sh;
     __shared__ float phR[N];                             // right-row phases, gathered by column after the sort
-    __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ int scan_tmp[BLOCK / 64];
     __shared__ unsigned last_key[BLOCK];
     __shared__ int n_distinct;
     __shared__ unsigned short binfirst[kBins + 1];
     __shared__ unsigned chunk_min[BLOCK];
-    __shared__ typename ScanU::TempStorage scanu_tmp;
+    __shared__ unsigned scanu_tmp[BLOCK / 64];
 
     const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
     const size_t base = (size_t)blockIdx.x * W;
@@ -927,7 +923,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         phR[k0 + i] = pr[i];
     }
     SLR_K4_STOP_AT(1);
-    Sort(sh.sort).Sort(keys, 16, 32);
+    Sort().sort(keys, sh.sort, 16, 32);
     __syncthreads();                                     // phR visible; everybody is done with sh.sort
     SLR_K4_STOP_AT(2);
     unsigned phb[IPT];                                   // phase bits of the sorted items (0xFFFFFFFF = none)
@@ -945,8 +941,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         headmask |= h ? (1u << i) : 0u;
         heads += h ? 1 : 0;
     }
-    int pos, total;
-    Scan(scan_tmp).ExclusiveSum(heads, pos, total);
+    int total;
+    int pos = wg_exclusive_scan<BLOCK>(heads, 0, [](int a, int b) { return a + b; }, scan_tmp, &total);
 #pragma unroll
     for (int i = 0; i < IPT; i++)
         if (headmask & (1u << i)) { sh.d.pk[pos] = make_float2(__uint_as_float(phb[i]), __uint_as_float(keys[i] & 0xFFFFu)); pos++; }
@@ -972,8 +968,9 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
         chunk_min[tid] = m;                              // min over this thread's bins
         __syncthreads();
         // exclusive suffix-min over threads = exclusive prefix-min in reversed thread order
-        unsigned carry;
-        ScanU(scanu_tmp).ExclusiveScan(chunk_min[BLOCK - 1 - tid], carry, 0xFFFFu, hipcub::Min());
+        // (0xFFFF is the identity here: the bins' first indices are 16-bit)
+        unsigned carry = wg_exclusive_scan<BLOCK>(chunk_min[BLOCK - 1 - tid], 0xFFFFu, [](unsigned a, unsigned b) { return a < b ? a : b; },
+                                                  scanu_tmp, (unsigned *)nullptr);
         __syncthreads();
         chunk_min[BLOCK - 1 - tid] = carry;
         __syncthreads();
@@ -1153,11 +1150,10 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
     // deferred_only: run behind ge_match_lean_kernel, for the rows it marked (has[first pixel of the row] == kGeDeferred)
     if (deferred_only && has[(size_t)blockIdx.x * W] != kGeDeferred) return;
     constexpr int N = 256 * IPT;
-    typedef hipcub::BlockRadixSort<unsigned, 256, IPT> Sort;
-    typedef hipcub::BlockScan<int, 256> ScanI;
-    __shared__ union { typename Sort::TempStorage sort; unsigned S[N]; } sh;
+    typedef rocprim::block_radix_sort<unsigned, 256, IPT> Sort;
+    __shared__ union { typename Sort::storage_type sort; unsigned S[N]; } sh;
     __shared__ short mk[N];                        // match column per left pixel (-1 = none), written by the walk
-    __shared__ typename ScanI::TempStorage scan_tmp;
+    __shared__ int scan_tmp[256 / 64];
     extern __shared__ unsigned short first[];      // TC list heads: first[code] = index in S of the code's smallest
     unsigned *S = sh.S;                            // column (0xFFFF = none)
     const int row = blockIdx.x;
@@ -1175,7 +1171,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
         keys[i] = (k < W && (validR ? validR[base + k] != 0 : true) && (unsigned)cr <= 0xFFFFu) ? (((unsigned)cr << 16) | (unsigned)k) : 0xFFFFFFFFu;
     }
     for (int t = threadIdx.x; t < TC; t += 256) first[t] = 0xFFFFu;
-    Sort(sh.sort).Sort(keys, 16, 32);
+    Sort().sort(keys, sh.sort, 16, 32);
     __syncthreads();                               // everybody is done with sh.sort before S aliases it
 #pragma unroll
     for (int i = 0; i < IPT; i++) S[threadIdx.x * IPT + i] = keys[i];
@@ -1235,8 +1231,7 @@ __global__ __launch_bounds__(256) void ge_match_kernel(const int32_t *__restrict
                 if (j0 + i < W) mk[j0 + i] = (short)m;     // W <= 32768: columns fit 15 bits, -1 = no match
             }
         }
-        int exc;
-        ScanI(scan_tmp).ExclusiveScan(lm, exc, -1, hipcub::Max());
+        const int exc = wg_exclusive_scan<256>(lm, -1, [](int a, int b) { return a > b ? a : b; }, scan_tmp, (int *)nullptr);
         const int new_in = exc > 0 ? exc : 0;
         dirty = new_in > fm;                       // kstart passed this thread's first match: its walk must be redone
         ks_in = new_in > ks_in ? new_in : ks_in;

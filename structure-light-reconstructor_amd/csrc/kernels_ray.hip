@@ -23,7 +23,7 @@
 #include "slr_device.hpp"
 #include "decode_common.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <math.h>
 #include <type_traits>
 #include <utility>
@@ -222,13 +222,13 @@ hipError_t launch_ray_scatter(const uint32_t *cell_of, const uint32_t *rank_of, 
 size_t ray_scan_temp_bytes(size_t n)
 {
     size_t bytes = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n);
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u, n, rocprim::plus<uint32_t>());
     return bytes;
 }
 
 hipError_t launch_ray_scan(const uint32_t *cnt, uint32_t *offs, size_t n, void *temp, size_t temp_bytes, hipStream_t s)
 {
-    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, cnt, offs, (int)n, s);
+    return rocprim::exclusive_scan(temp, temp_bytes, cnt, offs, 0u, n, rocprim::plus<uint32_t>(), s);
 }
 
 // ---- per camera-pixel unit ray (reconstruct.cpp:440-445) ----------------------------------------------

@@ -234,7 +234,7 @@ int prof_event(slr_ctx *c, hipEvent_t *e)
 }
 
 // exact == true (scopes around ONE kernel launch): the events are armed for SLR_LAUNCH, which stamps them at the kernel's
-// own start and end; otherwise (several launches, or a library call such as the hipcub scan) they bracket the scope
+// own start and end; otherwise (several launches, or a library call such as the rocprim scan) they bracket the scope
 struct ProfScope {
     slr_ctx *c; int id; ProfRec r{}; bool on, exact;
     ProfScope(slr_ctx *ctx, int kid, bool exact_ = false) : c(ctx), id(kid), on(ctx->profiling), exact(exact_)
