@@ -696,22 +696,36 @@ constexpr int kSchedDone = 2 * 8 * kSchedStride;             // sched[kSchedDone
 constexpr size_t kSchedBytes = (size_t)(kSchedDone + kSchedStride) * sizeof(unsigned);
 size_t dma_sched_bytes() { return kSchedBytes; }
 
-// old value of *p, which is incremented by 1: scalar atomic, issued here and NOT waited for (dma_ticket_wait)
-__device__ __forceinline__ unsigned dma_ticket_issue(unsigned *p)
+// The next tile's ticket: *p is incremented by a scalar atomic that is issued a phase before its result is needed and NOT waited
+// for in between.  Such a result must not live in a register the compiler knows about: to the compiler the asm statement's output
+// is complete, so it may copy or spill it at once -- and in the fused Gray decode of 256 x 8 tiles it did copy it, in front of the
+// wait, on the path of a wave 0 that decodes nothing of an entry (a part of a split tile): a copy taken before the atomic has
+// returned holds the operand (1) instead of the ticket, the workgroup decodes entry first + 1 a second time and the entry the
+// ticket named is never decoded (found by poisoning the outputs: whole parts of corner tiles of a verged rig's maps unwritten,
+// a different set every run).  So the result goes to a fixed SGPR that the two decode kernels keep out of register allocation
+// (amdgpu_num_sgpr(96): s0 .. s89 + VCC / XNACK / flat-scratch accounting), written by dma_ticket_issue and read by dma_ticket_take
+// and by nothing else (checked on the disassembly: tests/test_capi_symbols.py).
+#define SLR_TICKET_SGPR "s94"
+#define SLR_TICKET_KERNEL __attribute__((amdgpu_num_sgpr(96)))
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"            // ("clobber list contains reserved registers": that is the point -- and the
+                                                           //  clobber makes the kernel's SGPR count include the register)
+__device__ __forceinline__ void dma_ticket_issue(unsigned *p)
 {
-    unsigned v = 1u;
-    asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(v) : "s"(p) : "memory");
+    asm volatile("s_mov_b32 " SLR_TICKET_SGPR ", 1\n\ts_atomic_add " SLR_TICKET_SGPR ", %0, 0x0 glc" :: "s"(p) : "memory", SLR_TICKET_SGPR);
+}
+__device__ __forceinline__ unsigned dma_ticket_take()
+{
+    unsigned v;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, " SLR_TICKET_SGPR : "=s"(v) :: "memory", SLR_TICKET_SGPR);
     return v;
 }
-__device__ __forceinline__ void dma_ticket_wait(unsigned &v)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) :: "memory");
-}
+#pragma clang diagnostic pop
 // a workgroup leaves the kernel (one thread calls this): the last one zeroes the counters for the next launch
 __device__ __forceinline__ void dma_sched_leave(unsigned *sched)
 {
-    unsigned v = dma_ticket_issue(sched + kSchedDone);
-    dma_ticket_wait(v);
+    unsigned v;                                             // (issued and waited for in one statement: an ordinary value)
+    asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(sched + kSchedDone) : "memory");
     if (v + 1u == gridDim.x) {
         for (int i = 0; i < 16; i++) __hip_atomic_store(sched + i * kSchedStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sched + kSchedDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -769,11 +783,11 @@ struct DmaSched {
         return in ? (unsigned)gy * (unsigned)pitch + (unsigned)gx : kDmaInvalid;
     }
     // wave 0, one phase before pick_up(): draw (before the phase's tap loop) and publish (behind it) the next tile's ticket
-    __device__ __forceinline__ unsigned draw() const { return wave0 ? dma_ticket_issue(ctr) : 0u; }
-    __device__ __forceinline__ void publish(unsigned ticket) const
+    __device__ __forceinline__ void draw() const { if (wave0) dma_ticket_issue(ctr); }
+    __device__ __forceinline__ void publish() const
     {
         if (!wave0) return;
-        dma_ticket_wait(ticket);
+        const unsigned ticket = dma_ticket_take();
         // every lane writes the same word; the barriers of these kernels are bare s_barrier, so the write must have landed before
         // the next one (explicit DS operations: a generic-pointer access would be a FLAT instruction and drain the vector-memory queue)
         asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" :: "v"(tkt_lds), "v"(ticket) : "memory");
@@ -904,8 +918,7 @@ struct DmaDecode {
 #if !defined(SLR_DMA_ABL) || SLR_DMA_ABL != 3
         asm volatile("s_barrier" ::: "memory");
 #endif
-        unsigned ticket = 0;
-        if (P == 1) ticket = sc.draw();                               // (scalar memory: invisible to the counted vmcnt waits)
+        if (P == 1) sc.draw();                                        // (scalar memory: invisible to the counted vmcnt waits)
         if constexpr (P == 2) sc.pick_up();                           // the ticket wave 0 drew in phase 1 -> the next tile
         if (P == kDmaDigestPhase) issue_digest((unsigned)sc.nxt, sc.has_next);
         issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? sc.voff_next : voff_cur);
@@ -949,7 +962,7 @@ struct DmaDecode {
         else dma_differences<PX, img0, img1, (unsigned)RS>(mode, tap, qbase, second, sd);
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if (P == 1) sc.publish(ticket);                               // (the ticket has had the tap loop to arrive)
+        if (P == 1) sc.publish();                                     // (the ticket has had the tap loop to arrive)
         if constexpr (P == 0) {
 #pragma unroll
             for (int q = 0; q < PX; q++) {                         // computeShadows :198-204
@@ -990,13 +1003,12 @@ struct DmaDecode {
         if (plane_wave) wait_vm<dma_wait_count<PX, A, PLANE_DMAS>(P)>();
         else if (P == 0) wait_vm<0>();
         asm volatile("s_barrier" ::: "memory");
-        unsigned ticket = 0;
-        if (P == 1) ticket = sc.draw();
+        if (P == 1) sc.draw();
         if constexpr (P == 2) sc.pick_up();
         if (P == kDmaDigestPhase) issue_digest((unsigned)sc.nxt, sc.has_next);
         issue_planes((P + A) % 7, (K0 + P + A) % D, P + A >= 7 ? sc.voff_next : voff_cur);
         if constexpr (P == 0) { if (out_pending) flush(); out_pending = false; }
-        if (P == 1) sc.publish(ticket);
+        if (P == 1) sc.publish();
     }
 
     template <int K0>
@@ -1037,7 +1049,7 @@ template <int LDS_BYTES, int NT>
 constexpr int mf_dma_waves() { return dma_waves_per_simd<LDS_BYTES, NT>() > 6 ? 6 : dma_waves_per_simd<LDS_BYTES, NT>(); }
 
 template <int TW, int TH, int NT, int A, bool HASVALID>
-__global__ __launch_bounds__(NT, (HASVALID ? 4 : mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>()))
+__global__ __launch_bounds__(NT, (HASVALID ? 4 : mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>())) SLR_TICKET_KERNEL
 void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
                                int tiles_x, int tiles_y, unsigned *__restrict__ sched)
 {
@@ -1538,18 +1550,25 @@ struct GrayDma {
             out_ok |= (ok ? 1u : 0u) << q;
         }
         if constexpr (!HYB) { out_ty = ty; out_tx = tx; out_pending = true; }
+#if defined(SLR_GRAY_DMA_FLUSH_NOW)
+        if constexpr (!HYB) { flush(); out_pending = false; }
+#endif
     }
     // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
     // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
     template <int B, bool FIRST>
     __device__ __forceinline__ void phase(int k, int ty, int tx, bool act, unsigned voff_cur)
     {
+#if defined(SLR_GRAY_DMA_SAFE)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+#else
         if (plane_wave || FIRST) wait_vm<0>();              // (a wave without chunks only waits for its share of the digest)
         asm volatile("s_barrier" ::: "memory");
+#endif
         // the schedule: wave 0 draws the next tile's ticket around the tap loop of phase 0, every wave picks it up here in phase 1
         // (nq >= 2); the next tile's digest and its first planes are fetched in the tile's last phase
-        unsigned ticket = 0;
-        if constexpr (FIRST) ticket = sc.draw();
+        if constexpr (FIRST) sc.draw();
         else if (k == 1) sc.pick_up();
         const bool last = k + 1 == nq;
         if (last) issue_digest((unsigned)sc.nxt, sc.has_next);   // (every wave is past its digest reads of phase 0)
@@ -1561,7 +1580,7 @@ struct GrayDma {
         // act (wave-uniform): this wave belongs to the part of the tile that the entry decodes (see dma_tiles_kernel); the other waves
         // keep the barriers, fetch their chunks and (wave 0) draw the next ticket
         if (!act) {
-            if constexpr (FIRST) sc.publish(ticket);
+            if constexpr (FIRST) sc.publish();
             return;
         }
         if constexpr (FIRST) {
@@ -1589,7 +1608,7 @@ struct GrayDma {
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (FIRST) sc.publish(ticket);             // (the ticket has had the tap loop to arrive)
+        if constexpr (FIRST) sc.publish();                   // (the ticket has had the tap loop to arrive)
         // the code words are complete behind the last code-bit pair (HYB: the fringe pairs follow; acc / gxs are free from here)
         const int jlast = NPP * k + (NPP == 2 && 2 * k + 1 < npairs ? 1 : 0);
         if (HYB ? (NPP * k <= ncol && jlast >= ncol && !FIRST) : last) finish(ty, tx);
@@ -1616,7 +1635,7 @@ constexpr int gray_dma_waves()
 }
 
 template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false>
-__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB>::LDS_BYTES, NT, NPP>()))
+__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB>::LDS_BYTES, NT, NPP>())) SLR_TICKET_KERNEL
 void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
                                  int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched,
                                  const float *__restrict__ lut_g)

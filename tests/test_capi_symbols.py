@@ -84,3 +84,53 @@ def test_header_is_plain_c_and_links(tmp_path):
     assert int(out[0]) == len(names) and int(out[1]) == 100
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", "-I",
                     os.path.join(ROOT, "include"), str(src)], check=True, capture_output=True)
+
+
+def test_ticket_register_of_the_fused_decodes_is_untouched(tmp_path):
+    """The LDS-DMA fused decodes draw the next tile's ticket with a scalar atomic whose result arrives a phase later in a FIXED
+    SGPR (kernels_rectdma.hip, SLR_TICKET_SGPR) that the kernels keep out of register allocation -- a compiler-visible register
+    was copied before the result had arrived (entries of split tiles never decoded).  The invariant is checked on the device code
+    of the library as built: inside every *_rect_decode_dma_kernel that register is written by the issue (s_mov 1, s_atomic_add),
+    read by the take (s_mov to another SGPR) and named by nothing else."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = tmp_path / "lib.so"
+    shutil.copy(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)   # unbundles next to the copy
+    reg = re.search(r'#define\s+SLR_TICKET_SGPR\s+"s(\d+)"',
+                    open(os.path.join(ROOT, "structure-light-reconstructor_amd", "csrc", "kernels_rectdma.hip")).read())
+    assert reg, "SLR_TICKET_SGPR"
+    n = int(reg.group(1))
+    # the register by itself, or inside a range s[a:b]
+    def names_it(ins):
+        if re.search(r"\bs%d\b" % n, ins):
+            return True
+        return any(int(a) <= n <= int(b) for a, b in re.findall(r"s\[(\d+):(\d+)\]", ins))
+    allowed = [re.compile(r"^s_mov_b32 s%d, 1$" % n), re.compile(r"^s_atomic_add s%d, s\[\d+:\d+\], 0x0 glc$" % n),
+               re.compile(r"^s_mov_b32 s\d+, s%d$" % n)]
+    kernels, issues, takes = 0, 0, 0
+    for f in sorted(os.listdir(tmp_path)):
+        if not f.endswith("gfx950"):
+            continue
+        text = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        if "rect_decode_dma_kernel" not in text:
+            continue
+        cur = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+            if m:
+                cur = m.group(1)
+                kernels += 1 if "rect_decode_dma_kernel" in cur and not cur.endswith(".kd") else 0
+                continue
+            if not cur or "rect_decode_dma_kernel" not in cur or "\t" not in line:
+                continue
+            ins = " ".join(line.split("//")[0].split())
+            if not names_it(ins):
+                continue
+            assert any(p.match(ins) for p in allowed), (cur, ins)
+            issues += 1 if ins.startswith("s_atomic_add") else 0
+            takes += 1 if allowed[2].match(ins) else 0
+    assert kernels >= 6 and issues >= kernels and takes >= kernels, (kernels, issues, takes)

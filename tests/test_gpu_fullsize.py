@@ -463,3 +463,58 @@ def test_verged_rig_quads_sorted_by_class(ctx, synth, scene, slr, theta, k1):
         assert own["mf_form"] == 7 and srt["mf_form"] == 7
         assert own["quads_by_class"][0] + own["quads_by_class"][1] + own["quads_by_class"][2] == sum(srt["quads_by_class"])
         assert 2 * (srt["waves_by_mode"][1] + srt["waves_by_mode"][2]) < own["waves_by_mode"][1] + own["waves_by_mode"][2], (own, srt)
+
+
+def test_split_tiles_every_part_is_decoded(ctx, synth, scene, slr):
+    """Entries of split tiles (a verged rig's corner tiles are decoded in wave-aligned parts, dma_tiles_kernel) sit at the end of
+    every pool of the tile schedule, one after the other, with wave 0 idle in most of them -- the path on which the next tile's
+    ticket was once read before the scalar atomic had returned it (fused Gray decode, 256 x 8 tiles: the workgroup decoded entry
+    first + 1 again and the entry the ticket named never; ~12 % of the parts, another set every run, invisible wherever the output
+    buffer still held an earlier run's values).  Outputs are therefore allocated over poisoned blocks: a pixel nobody writes
+    cannot equal the gather form's result.  Both fused decodes, both tile shapes that serve them, few and many workgroups."""
+    st = scene[0]
+    rig = synth.make_verged_rig(W, H, 0.15, -0.12)
+    g = synth.render_gray_stack(W, H, 1024, seed=9, noise=2, device=st.device)
+    ncol = synth.gray_num_bits(1024)
+
+    def poison():
+        t = [torch.full((H, W), 0x7B7B7B7B, dtype=torch.int32, device=st.device) for _ in range(6)]
+        u = [torch.full((H, W), 0x7B, dtype=torch.uint8, device=st.device) for _ in range(6)]
+        torch.cuda.synchronize()
+        del t, u
+
+    def decode():
+        poison()
+        ph, vd = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=True)
+        ctx.synchronize()
+        outs = [ph[0].clone(), ph[1].clone(), vd[0].clone(), vd[1].clone()]
+        del ph, vd
+        for cam in range(2):
+            poison()
+            cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
+            ctx.synchronize()
+            outs += [cx.clone(), v.clone()]
+            del cx, v
+        return outs
+
+    try:
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 1)                    # the per-pixel gather form: no tiles, no schedule
+        synth.install_verged_maps(ctx, rig, W, H)
+        ref = decode()
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+        for shape in (1, 3):
+            ctx.set_option(slr.capi.OPT_RECT_DMA_SHAPE, shape)
+            synth.install_verged_maps(ctx, rig, W, H)
+            info = [ctx.rectify_info(cam) for cam in range(2)]
+            assert all(i["mf_form"] == 7 for i in info) and sum(i["dma_extra_entries"] for i in info) > (100 if shape == 1 else 0), info
+            for resident in (0, 8):
+                ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, resident)
+                for rep in range(2):
+                    got = decode()
+                    for k, (a, b) in enumerate(zip(got, ref)):
+                        same = a.view(torch.uint8) == b.view(torch.uint8)
+                        assert bool(same.all()), (shape, resident, rep, k, int((~same).sum()))
+    finally:
+        ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, 0)
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+        ctx.set_option(slr.capi.OPT_RECT_DMA_SHAPE, 3)
