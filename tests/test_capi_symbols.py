@@ -134,3 +134,83 @@ def test_ticket_register_of_the_fused_decodes_is_untouched(tmp_path):
             issues += 1 if ins.startswith("s_atomic_add") else 0
             takes += 1 if allowed[2].match(ins) else 0
     assert kernels >= 6 and issues >= kernels and takes >= kernels, (kernels, issues, takes)
+
+
+def _lds_inflight_violations(listing, kernel_substr="rect_decode_dma_kernel"):
+    """Linear scan of an llvm-objdump listing: the destination of a ds_read is 'in flight' until an s_waitcnt lgkmcnt(n) that
+    retires it (LDS operations return in order; with a scalar-memory operation outstanding only lgkmcnt(0) retires anything).
+    Returns (number of ds_reads seen, [(kernel, instruction, registers)] of instructions that name an in-flight register)."""
+    def regs(tok):
+        out = set()
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+            out.update(range(int(a), int(b) + 1))
+        out.update(int(a) for a in re.findall(r"\bv(\d+)\b", tok))
+        return out
+    cur, pend, viol, reads = None, [], [], 0
+    for line in listing.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            cur, pend = m.group(1), []
+            continue
+        if not cur or kernel_substr not in cur or "\t" not in line:
+            continue
+        ins = " ".join(line.split("//")[0].split())
+        if not ins:
+            continue
+        mn, _, ops = ins.partition(" ")
+        if mn == "s_waitcnt":
+            mm = re.search(r"lgkmcnt\((\d+)\)", ops)
+            n = 0 if ops.strip() == "0" else int(mm.group(1)) if mm else None
+            if n == 0:
+                pend = []
+            elif n is not None and not any(k == "smem" for k, _ in pend):
+                del pend[:max(0, len(pend) - n)]
+            continue
+        inflight = set().union(*[d for k, d in pend if k == "ds"]) if pend else set()
+        if mn.startswith("ds_read"):
+            first, _, rest = ops.partition(",")
+            if regs(rest) & inflight:
+                viol.append((cur, ins, sorted(regs(rest) & inflight)))
+            pend.append(("ds", regs(first)))
+            reads += 1
+            continue
+        if regs(ops) & inflight:
+            viol.append((cur, ins, sorted(regs(ops) & inflight)))
+        if mn.startswith("ds_"):
+            pend.append(("dsw", set()))
+        elif mn.startswith(("s_load", "s_atomic", "s_buffer_load", "s_store", "s_dcache")):
+            pend.append(("smem", set()))
+    return reads, viol
+
+
+def test_lds_reads_in_flight_are_not_touched(tmp_path):
+    """The tap reads of the LDS-DMA fused decodes are inline-asm ds_read_b32 issued a pixel ahead of their use and retired by
+    COUNTED s_waitcnt lgkmcnt (kernels_rectdma.hip, dma_rd / dma_rd_wait).  Between the two statements the compiler believes the
+    destination registers hold their values -- the same hazard class as the in-flight ticket (a copy, a spill or a reordered use
+    would read the register before the LDS has written it; gfx950 has no interlock for that).  Checked on the device code of the
+    library as built: no instruction of any *_rect_decode_dma_kernel names a register with an LDS read outstanding."""
+    import shutil
+    import subprocess
+    # the checker itself, on a planted violation and on its repaired twin
+    bad = "0000 <k_rect_decode_dma_kernel>:\n\tds_read_b32 v1, v9 offset:16\n\tds_read_b32 v2, v9 offset:20\n\ts_waitcnt lgkmcnt(1)\n" \
+          "\tv_add_u32_e32 v3, v1, v2\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v4, v2\n"
+    n, v = _lds_inflight_violations(bad)
+    assert n == 2 and len(v) == 1 and v[0][2] == [2], v
+    assert _lds_inflight_violations(bad.replace("lgkmcnt(1)", "lgkmcnt(0)"))[1] == []
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = tmp_path / "lib.so"
+    shutil.copy(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
+    reads = 0
+    for f in sorted(os.listdir(tmp_path)):
+        if not f.endswith("gfx950"):
+            continue
+        text = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        if "rect_decode_dma_kernel" not in text:
+            continue
+        n, viol = _lds_inflight_violations(text)
+        assert not viol, viol[:5]
+        reads += n
+    assert reads > 5000, reads          # (the default build: ~19 000 tap reads over 18 kernel instances)
