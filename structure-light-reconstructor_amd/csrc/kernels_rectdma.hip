@@ -1163,7 +1163,10 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
 #undef SLR_DMA_TILE
     }
 #undef SLR_DMA_COUNT
-    d.flush();
+    // (only what a tile left behind: a wave that was idle in every entry its workgroup decoded -- parts of split tiles as a workgroup's
+    //  first and only entries, i.e. small images on the full resident set -- has no results, and its out_ty / oslot / values are
+    //  whatever the registers held: stores of junk to junk addresses inside the image, found with poisoned outputs at 1040 x 524)
+    if (d.out_pending) d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
     if (threadIdx.x == 0) dma_sched_leave(sched);
 #if defined(SLR_DMA_CLOCKPROBE)
@@ -1727,7 +1730,10 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
         if constexpr (ODD) SLR_GDMA_TILE(1)
 #undef SLR_GDMA_TILE
     }
-    d.flush();
+    // (only what a tile left behind: a wave that was idle in every entry its workgroup decoded -- parts of split tiles as a workgroup's
+    //  first and only entries, i.e. small images on the full resident set -- has no results, and its out_ty / oslot / values are
+    //  whatever the registers held: stores of junk to junk addresses inside the image, found with poisoned outputs at 1040 x 524)
+    if (d.out_pending) d.flush();
     wait_vm<0>();                                           // the dummy DMAs behind the last tile must land before the LDS is released
     if (threadIdx.x == 0) dma_sched_leave(sched);
 }

@@ -175,3 +175,52 @@ def test_dma_form_fullsize_every_shape(dma_ctx, slr, oracle, synth):
         except slr.capi.SlrError as e:       # the 256-thread shapes hold few source rows: these maps' corner tiles may not fit
             assert e.status == slr.capi.ERR_UNSUPPORTED and shape not in (0, 1, 3), (shape, str(e))
     assert (0, 1) in ran and (1, 1) in ran and (3, 2) in ran and len(ran) >= 6, ran
+
+
+@pytest.mark.parametrize("W,H", [(1040, 524), (528, 260)])
+def test_split_tiles_as_a_workgroups_only_entries(dma_ctx, slr, synth, W, H):
+    """A small image on the FULL resident set: there are more workgroups than tile-table entries, so every entry -- the parts of
+    split corner tiles of a verged rig among them -- is some workgroup's first and only one, and the waves outside such a part
+    never decode anything.  Their end-of-kernel flush once stored whatever their registers held to whatever address those
+    registers made (wrong values scattered over the image, another set every run; with few resident workgroups, or at 4096 x
+    3000, every wave has decoded a tile before and the flush merely repeated it).  Both fused decodes, every compiled tile shape
+    that serves them, sorted and own-order digests, three runs each, against the per-pixel gather form."""
+    ctx = dma_ctx
+    st = synth.render_mf_stack(W, H, seed=7, noise=3, device="cuda")
+    g = synth.render_gray_stack(W, H, 1024, seed=9, noise=2, device="cuda")
+    ncol = synth.gray_num_bits(1024)
+    ctx.set_calibration(synth.make_calibration(W, H)[0])
+
+    def decode():
+        ph, vd = ctx.mf_rectify_decode_pair(st[0], st[1], BLACK, want_valid=True)
+        ctx.synchronize()
+        outs = [ph[0].clone(), ph[1].clone(), vd[0].clone(), vd[1].clone()]
+        for cam in range(2):
+            cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
+            ctx.synchronize()
+            outs += [cx.clone(), v.clone()]
+        return outs
+
+    try:
+        split = 0
+        for theta, k1 in ((0.15, -0.12), (0.25, 0.1), (0.35, -0.25)):
+            rig = synth.make_verged_rig(W, H, theta, k1)
+            ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 1)
+            synth.install_verged_maps(ctx, rig, W, H)
+            ref = decode()
+            ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+            for shape in (0, 1, 3):
+                ctx.set_option(slr.capi.OPT_RECT_DMA_SHAPE, shape)
+                for flags in (0, 32):
+                    ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
+                    synth.install_verged_maps(ctx, rig, W, H)
+                    split += sum(ctx.rectify_info(cam)["dma_extra_entries"] for cam in range(2))
+                    for rep in range(3):
+                        for k, (a, b) in enumerate(zip(decode(), ref)):
+                            same = a.view(torch.uint8) == b.view(torch.uint8)
+                            assert bool(same.all()), (theta, shape, flags, rep, k, int((~same).sum()))
+        assert split > 50, split
+    finally:
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+        ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
