@@ -189,6 +189,7 @@ def test_split_tiles_as_a_workgroups_only_entries(dma_ctx, slr, synth, W, H):
     st = synth.render_mf_stack(W, H, seed=7, noise=3, device="cuda")
     g = synth.render_gray_stack(W, H, 1024, seed=9, noise=2, device="cuda")
     ncol = synth.gray_num_bits(1024)
+    hy = synth.render_hybrid_stack(W, H, 1024, seed=5, noise=2, device="cuda")
     ctx.set_calibration(synth.make_calibration(W, H)[0])
 
     def decode():
@@ -199,6 +200,12 @@ def test_split_tiles_as_a_workgroups_only_entries(dma_ctx, slr, synth, W, H):
             cx, _, v = ctx.gray_decode(g[cam], ncol, 0, BLACK, 3, 1024, 0, rectify_cam=cam)
             ctx.synchronize()
             outs += [cx.clone(), v.clone()]
+        for one_pass in (0, 1):                                     # the hybrid stack: two fused launches, or the one-pass kernel
+            ctx.set_option(slr.capi.OPT_HYBRID_ONE_PASS, one_pass)
+            hx, hp = ctx.hybrid_rectify_decode_pair(hy[0], hy[1], ncol, BLACK, 3, 1024)
+            ctx.synchronize()
+            outs += [hx[0].clone(), hx[1].clone(), hp[0].clone(), hp[1].clone()]
+        ctx.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 0)
         return outs
 
     try:
@@ -224,3 +231,4 @@ def test_split_tiles_as_a_workgroups_only_entries(dma_ctx, slr, synth, W, H):
     finally:
         ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
+        ctx.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 0)
