@@ -148,6 +148,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * scratch set each, the second one half a frame behind: a frame's ray-ray triangulation (arithmetic) runs beside the next
  * frame's decode, histogram and scatter (HBM streaming); 1 = one frame after the other on the context's stream.  Same results. */
 #define SLR_OPT_BATCH_STREAMS 12
+/* SLR_OPT_DEBUG_POISON_SCRATCH (tests): 1 = every scratch buffer the context hands to a call (phases, codes, buckets, staging --
+ * not the cached calibration tables) is filled with 0x7B bytes first, behind a device synchronisation: an intermediate a kernel
+ * fails to write cannot pass for the previous call's.  Slow; 0 (default) = off. */
+#define SLR_OPT_DEBUG_POISON_SCRATCH 13
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */

@@ -26,6 +26,7 @@ OPT_DEBUG_RECT_RESIDENT = 8    # tests: workgroups of the persistent fused decod
 OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-descriptor form, bit 2 no lean K5, bit 3 no fused decode+count
 OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
 OPT_BATCH_STREAMS = 12         # GRAY_ONLY batch: 2 (default) = frames pipelined over two streams, 1 = sequential
+OPT_DEBUG_POISON_SCRATCH = 13  # tests: scratch buffers are filled with 0x7B bytes before a call gets them
 OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()
@@ -134,6 +135,8 @@ def load_library():
 # because the caching allocator handed out the block of an earlier, correct run (that is how the unwritten parts of split
 # tiles stayed hidden in round 3: DESIGN.md section 4).
 POISON_OUTPUTS = os.environ.get("SLR_POISON_OUTPUTS", "0") == "1"
+# ... and SLR_POISON_SCRATCH=1 makes every Context poison the library's own scratch buffers the same way (SLR_OPT_DEBUG_POISON_SCRATCH)
+POISON_SCRATCH = os.environ.get("SLR_POISON_SCRATCH", "0") == "1"
 
 
 def _empty(shape, dtype, device):
@@ -224,6 +227,8 @@ class Context:
                 stream = None
         if stream is not None:
             self.set_stream(stream)
+        if POISON_SCRATCH:
+            self.set_option(OPT_DEBUG_POISON_SCRATCH, 1)
 
     def _mem(self, arrs):
         """host/device mode of a call; device mode: order the ctx stream after torch's current stream"""

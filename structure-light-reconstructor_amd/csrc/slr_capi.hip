@@ -169,6 +169,17 @@ int get_scratch(slr_ctx *c, int slot, size_t bytes, void **out)
         c->scratch_cap[slot] = cap;
     }
     *out = c->scratch[slot];
+    // tests (SLR_OPT_DEBUG_POISON_SCRATCH): what a call gets is never what the previous call left there.  The calibration tables
+    // are cached across calls (und_valid / rays_valid) and keep their contents; the second scratch set is used on a second
+    // stream, hence the device-wide synchronisation instead of stream order.
+    if (c->debug.poison_scratch) {
+        const int base = slot >= S_COUNT ? slot - S_COUNT : slot;
+        if (base != S_RAYS_L && base != S_RAYS_R && base != S_UND_L && base != S_UND_R) {
+            SLR_HIP(c, hipDeviceSynchronize());
+            SLR_HIP(c, hipMemset(c->scratch[slot], 0x7B, c->scratch_cap[slot]));
+            SLR_HIP(c, hipDeviceSynchronize());
+        }
+    }
     return SLR_OK;
 }
 
@@ -1692,6 +1703,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_BATCH_STREAMS:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_BATCH_STREAMS must be 1 or 2");
             c->opt_batch_streams = value;
+            return SLR_OK;
+        case SLR_OPT_DEBUG_POISON_SCRATCH:
+            if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_POISON_SCRATCH must be 0 or 1");
+            c->debug.poison_scratch = value != 0;
             return SLR_OK;
         case SLR_OPT_HYBRID_ONE_PASS:
             if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_HYBRID_ONE_PASS must be 0 or 1");

@@ -69,6 +69,7 @@ struct DebugKnobs {
     bool no_quad_sort = false;   // LDS-DMA fused decodes: every wave keeps the quads of its own block of the tile (read when maps are installed)
     bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
     int k4_stop = 0;
+    bool poison_scratch = false; // SLR_OPT_DEBUG_POISON_SCRATCH
 };
 extern thread_local DebugKnobs tl_debug;
 #define SLR_LAUNCH(kernel, grid, block, lds, stream, ...)                                                            \

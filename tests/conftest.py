@@ -7,6 +7,8 @@ import pytest
 # every device output the Python wrapper allocates starts as 0x7B bytes (capi.POISON_OUTPUTS, read at import): a pixel no kernel
 # writes cannot pass for a correct one because the caching allocator handed out the block of an earlier, correct run
 os.environ.setdefault("SLR_POISON_OUTPUTS", "1")
+# ... and the library's own scratch buffers (phases, codes, buckets, staging) before every call that gets them (capi.POISON_SCRATCH)
+os.environ.setdefault("SLR_POISON_SCRATCH", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -39,9 +39,9 @@ def test_header_constants_match_the_binding(slr):
     enums = {k: int(v) for k, v in re.findall(r"\b(SLR_[A-Z_]+)\s*=\s*(-?\d+)", text)}
     cap = slr.capi
     for name in ("MF_MATCH_ALGO", "MF_DECODE_VEC", "RECT_DECODE_ALGO", "ASYNC_HOST", "PROFILE_STRIDE", "RECT_DMA_SHAPE",
-                 "RECT_DMA_DEPTH", "DEBUG_RECT_RESIDENT", "DEBUG_FLAGS", "DEBUG_K4_STOP", "HYBRID_ONE_PASS", "BATCH_STREAMS"):
+                 "RECT_DMA_DEPTH", "DEBUG_RECT_RESIDENT", "DEBUG_FLAGS", "DEBUG_K4_STOP", "HYBRID_ONE_PASS", "BATCH_STREAMS", "DEBUG_POISON_SCRATCH"):
         assert defines["SLR_OPT_" + name] == getattr(cap, "OPT_" + name), name
-    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 13))   # no duplicate ids
+    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 14))   # no duplicate ids
     for name in ("OK", "ERR_INVALID_ARG", "ERR_NO_DEVICE", "ERR_HIP", "ERR_NOT_CONFIGURED", "ERR_UNSUPPORTED", "ERR_OOM"):
         assert enums["SLR_" + name] == getattr(cap, name), name
     assert (enums["SLR_MEM_HOST"], enums["SLR_MEM_DEVICE"]) == (cap.MEM_HOST, cap.MEM_DEVICE)
@@ -214,3 +214,12 @@ def test_lds_reads_in_flight_are_not_touched(tmp_path):
         assert not viol, viol[:5]
         reads += n
     assert reads > 5000, reads          # (the default build: ~19 000 tap reads over 18 kernel instances)
+
+
+def test_the_suite_runs_with_poisoned_buffers(slr):
+    """tests/conftest.py turns both poison hooks on before the binding is imported: device outputs the wrapper allocates and the
+    library's scratch buffers start every call as 0x7B bytes (capi.POISON_OUTPUTS / POISON_SCRATCH -> SLR_OPT_DEBUG_POISON_SCRATCH);
+    bench.py removes both from its environment."""
+    assert slr.capi.POISON_OUTPUTS and slr.capi.POISON_SCRATCH
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'os.environ.pop("SLR_POISON_OUTPUTS", None)' in src and 'os.environ.pop("SLR_POISON_SCRATCH", None)' in src
