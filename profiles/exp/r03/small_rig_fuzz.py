@@ -56,6 +56,7 @@ while time.time() < T_END:
         for rep in range(2):
             for k, (a, b) in enumerate(zip(decode(), ref)):
                 same = a.view(torch.uint8) == b.view(torch.uint8)
+                assert not bool((a.view(torch.uint8) == 0x7B).all()), ("nothing written", k)
                 assert bool(same.all()), (W, H, theta, k1, shape, res, rep, k, int((~same).sum()), [i["mf_form"] for i in info])
         n += 1
     ctx.set_option(capi.OPT_RECT_DMA_SHAPE, 3)
