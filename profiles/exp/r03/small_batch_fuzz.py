@@ -1,5 +1,5 @@
 """Whole-path companion of small_rig_fuzz.py: the BATCH entries (slr_reconstruct_mf_batch, slr_reconstruct_batch in GE and GRAY
-modes, slr_reconstruct_hybrid_batch) on 2-3 distinct small frames, verged rigs, random tile shape / resident set, outputs AND
+modes -- GRAY with and without rectification --, slr_reconstruct_hybrid_batch) on 2-3 distinct small frames, verged rigs, random tile shape / resident set, outputs AND
 scratch poisoned -- against the same entry on the per-pixel gather forms (SLR_OPT_RECT_DECODE_ALGO = 1), frame by frame.
   python profiles/exp/r03/small_batch_fuzz.py <seed> <seconds>"""
 import sys, os, importlib, time
@@ -21,6 +21,9 @@ while time.time() < T_END:
     mf = torch.stack([synth.render_mf_stack(W, H, seed=int(rng.integers(1, 9999)), noise=3, device="cuda") for _ in range(nf)]).contiguous()
     gr = torch.stack([synth.render_gray_stack(W, H, 1024, seed=int(rng.integers(1, 9999)), noise=2, device="cuda") for _ in range(nf)]).contiguous()
     hy = torch.stack([synth.render_hybrid_stack(W, H, 1024, seed=int(rng.integers(1, 9999)), noise=2, device="cuda") for _ in range(nf)]).contiguous()
+    sw, sh = 256, 128
+    gc, gw = synth.gray_num_bits(sw), synth.gray_num_bits(sh)
+    go = torch.stack([synth.render_gray_stack(W, H, sw, sh, seed=int(rng.integers(1, 9999)), noise=2, device="cuda", rows=True) for _ in range(nf)]).contiguous()
     ctx.set_calibration(synth.make_calibration(W, H, with_T=bool(rng.integers(0, 2)))[0])
     rig = synth.make_verged_rig(W, H, theta, k1)
     def run():
@@ -30,6 +33,9 @@ while time.time() < T_END:
         outs += [x.clone(), h.clone(), c.clone()]
         x, h, cx = ctx.reconstruct_hybrid_batch(hy, ncol, BLACK, 3, 1024, want_codes=True); ctx.synchronize()
         outs += [x.clone(), h.clone(), cx.clone()]
+        for rect in (True, False):
+            x, h, _ = ctx.reconstruct_batch(capi.MODE_GRAY, go, BLACK, 0, n_col_bits=gc, n_row_bits=gw, scan_w=sw, scan_h=sh, rectify=rect); ctx.synchronize()
+            outs += [x.clone(), h.clone()]
         return outs
     ctx.set_option(capi.OPT_DEBUG_RECT_RESIDENT, 0)
     ctx.set_option(capi.OPT_RECT_DECODE_ALGO, 1)
