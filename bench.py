@@ -128,6 +128,11 @@ def parse_args():
     ap.add_argument("--hybrid-one-pass", type=int, default=0,
                     help="--mode hybrid: 1 = SLR_OPT_HYBRID_ONE_PASS (one kernel over all 38 planes of a tile) instead of the default two "
                          "fused launches over the one stack")
+    ap.add_argument("--maps", default="verged",
+                    help="rectification maps of the timed region: 'verged' (default) = a stereo head verged by 0.2 rad in total with "
+                         "k1 = -0.15, rectified by the repo's stereoRectify + initUndistortRectifyMap restatements (keystone maps: "
+                         "tilted rows, taller tile boxes); 'verged:THETA:K1' = another such rig; 'near-identity' = "
+                         "synth.make_rectify_maps (0.2 deg of roll, k1 -0.08: the maps of rounds 1-3)")
     ap.add_argument("--map-sweep", type=int, default=1,
                     help="also time the fused decode on the maps of three verged rigs (stereoRectify + initUndistortRectifyMap), outside "
                          "the timed region: form selected, tiles that do not fit, read-mode histogram (realistic_maps)")
@@ -262,7 +267,8 @@ def live_traffic(args, kernel_name):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "1", "--mode", args.mode, "--width", str(args.width), "--height", str(args.height),
                "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--dma-shape", str(args.dma_shape),
-               "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags)]
+               "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags),
+               "--maps", args.maps]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
             got = []
@@ -356,11 +362,21 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
     return out
 
 
+_T0 = time.perf_counter()
+
+
+def _trace(what):
+    """SLR_BENCH_TRACE=1: wall-clock stage marks on stderr (where a run's minutes go outside the timed region)"""
+    if os.environ.get("SLR_BENCH_TRACE"):
+        print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
     import numpy as np
     import torch
     import torch.distributed as dist
+    _trace("imports done")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -415,10 +431,27 @@ def main():
     ctxs = [slr.Context(local, stream=st_) for st_ in streams]
     compute, ctx = streams[0], ctxs[0]
     calib, _ = synth.make_calibration(W, H) if mode != "gray" else synth.make_calibration(W, H, baseline=400.0, theta=0.6)
-    maps = None
-    if rectify:
+    maps, rig, rig_desc = None, None, None
+    if rectify and args.maps.startswith("verged"):
+        parts = args.maps.split(":")
+        rig_theta = float(parts[1]) if len(parts) > 1 else 0.2
+        rig_k1 = float(parts[2]) if len(parts) > 2 else -0.15
+        rig = synth.make_verged_rig(W, H, rig_theta, rig_k1)
+        calib = rig["calib"]                              # Q is stereoRectify's for this rig
+        rig_desc = ("verged stereo head: %.2f rad of toe-in in total, k1 %.2f, rectified by the host mirror's stereoRectify + "
+                    "slr_init_rectify_maps (keystone maps); near-identity maps and two more rigs: see realistic_maps" % (rig_theta, rig_k1))
+    elif rectify:
+        if args.maps != "near-identity":
+            raise SystemExit("--maps: verged[:theta:k1] or near-identity")
         maps = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
         torch.cuda.synchronize()
+
+    def install_maps(c_):
+        if rig is not None:
+            synth.install_verged_maps(c_, rig, W, H)
+        else:
+            for cam in range(2):
+                c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
     for c_ in ctxs:
         c_.set_calibration(calib)
         if args.rect_algo:
@@ -434,8 +467,8 @@ def main():
         if args.hybrid_one_pass:
             c_.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 1)
         if rectify:
-            for cam in range(2):
-                c_.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+            install_maps(c_)
+    _trace("contexts, calibration and maps installed")
     # F distinct synthetic stereo frames per rank (seeds 1234 + F rank + f), resident in HBM
     pitch = W + max(0, args.pitch_pad)
     stack = torch.zeros((F, 2, ppc, H, pitch), dtype=torch.uint8, device=dev)      # rows padded: see --pitch-pad
@@ -455,29 +488,27 @@ def main():
 
     nbuf = 2 if S == 1 else S
     oh, ow = (scan_h, scan_w) if mode == "gray" else (H, W)
-    xyz = [torch.empty((F, oh, ow, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    has = [torch.empty((F, oh, ow), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     do_gather = world > 1 and args.gather == "step"
     final_gather = world > 1 and args.gather == "final"
     after_gather = world > 1 and args.gather == "after"
+    sdist = importlib.import_module("structure-light-reconstructor_amd.dist")
     if do_gather or final_gather or after_gather:
+        # The assembled cloud of every rank: [world * F] frames, rank r owning frames [r F, (r + 1) F) ("blocked": its shard is one
+        # contiguous piece, which the batch entry point fills in ONE call -- no copy between the kernels and the collective -- and
+        # one in-place RCCL all-gather per array assembles the whole).  The library path: dist.gather_point_clouds.
         comm = torch.cuda.Stream(device=dev)
-        # output = concatenation of the per-rank clouds along dim 0 (the form every backend accepts)
-        g_xyz = torch.empty((world * F * oh, ow, 3), dtype=torch.float32, device=dev)
-        g_has = torch.empty((world * F * oh, ow), dtype=torch.uint8, device=dev)
+        g_xyz = [torch.empty((world * F, oh, ow, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        g_has = [torch.empty((world * F, oh, ow), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        xyz = [sdist.local_slots(g, rank, world, "blocked") for g in g_xyz]
+        has = [sdist.local_slots(g, rank, world, "blocked") for g in g_has]
         done_compute = [torch.cuda.Event() for _ in range(nbuf)]
         done_gather = [torch.cuda.Event() for _ in range(nbuf)]
+    else:
+        xyz = [torch.empty((F, oh, ow, 3), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        has = [torch.empty((F, oh, ow), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
 
     def gather(b):
-        if dist.get_backend() == "nccl":                 # RCCL over xGMI
-            dist.all_gather_into_tensor(g_xyz, xyz[b].view(F * oh, ow, 3))
-            dist.all_gather_into_tensor(g_has, has[b].view(F * oh, ow))
-        else:                                            # dry run of the N > 1 path on a box without several GPUs: via the host
-            torch.cuda.current_stream().synchronize()
-            cx, ch = torch.empty(g_xyz.shape, dtype=g_xyz.dtype), torch.empty(g_has.shape, dtype=g_has.dtype)
-            dist.all_gather_into_tensor(cx, xyz[b].view(F * oh, ow, 3).cpu())
-            dist.all_gather_into_tensor(ch, has[b].view(F * oh, ow).cpu())
-            g_xyz.copy_(cx); g_has.copy_(ch)
+        sdist.gather_point_clouds(xyz[b], has[b], world * F, out=(g_xyz[b], g_has[b]), assignment="blocked")
 
     def step(i):
         b = i % nbuf
@@ -507,9 +538,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    _trace("frames rendered")
     for i in range(args.warmup):
         step(i)
     sync_all()
+    _trace("warm-up done")
     if args.profile:
         for c_ in ctxs:
             c_.set_option(slr.capi.OPT_PROFILE_STRIDE, max(1, args.profile_stride))
@@ -529,9 +562,16 @@ def main():
             gather(b)
     sync_all()
     elapsed = time.perf_counter() - t0
-    gather_ms = None
-    if after_gather:                                    # the job's one exchange step, timed on its own (max over ranks)
+    _trace("timed region done")
+    gather_ms, gather_proof = None, None
+    if after_gather or final_gather or do_gather:
         b = (args.steps - 1) % nbuf
+        # the proof of the exchange: every rank's checksums of its LOCAL frames (taken before the gather where the gather is still
+        # to come) travel by a second, tiny all-gather; every frame of every rank's assembled cloud must reproduce its owner's word
+        mine = sdist.frame_checksums(xyz[b], has[b])
+        torch.cuda.synchronize()
+    if after_gather:                                    # the job's one exchange step, timed on its own (max over ranks)
+        sync_all()
         tg = time.perf_counter()
         with torch.cuda.stream(comm):
             gather(b)
@@ -539,6 +579,19 @@ def main():
         tt = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         gather_ms = float(tt.item()) * 1e3
+    if after_gather or final_gather or do_gather:
+        try:
+            nchk = sdist.verify_gathered(g_xyz[b], g_has[b], mine, world * F, assignment="blocked")
+            okv = torch.tensor([1], dtype=torch.int64, device=dev)
+            err = None
+        except RuntimeError as e:
+            nchk, okv, err = 0, torch.tensor([0], dtype=torch.int64, device=dev), str(e)
+        dist.all_reduce(okv, op=dist.ReduceOp.MIN)      # every rank holds the whole cloud: every rank must agree
+        gather_proof = {"frames_verified_on_every_rank": nchk, "all_ranks_ok": bool(int(okv.item()) == 1), "error": err,
+                        "how": "per-frame 64-bit position-weighted checksums of each rank's local XYZ + mask, all-gathered and compared "
+                               "with the assembled cloud on every rank (dist.verify_gathered)"}
+        if not gather_proof["all_ranks_ok"]:
+            raise SystemExit("bench.py: the assembled point cloud does not match its owners' checksums: %s" % (err,))
     prof = {}
     if args.profile:
         for c_ in ctxs:                                   # merge the per-context HIP-event profiles
@@ -642,9 +695,10 @@ def main():
                            "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
         ctx.profile_enable(False)
 
-    # the timed region runs on friendly maps (near-identity: ~0.2 deg of roll, k1 = -0.08); what the fused decode does on the maps
-    # of VERGED rigs -- built by the repo's own stereoRectify + slr_init_rectify_maps -- is measured here, outside the timed region:
-    # which form `auto` picks for them, how many tiles do not fit it, the quad / wave read-mode histogram, and the kernel's time
+    # The timed region runs on the maps --maps names (default: the rig verged by 0.2 rad).  What the fused decode does on OTHER maps
+    # -- the near-identity maps of rounds 1-3 and verged rigs of 0.1 / 0.2 / 0.3 rad, built by the repo's own stereoRectify +
+    # slr_init_rectify_maps -- is measured here, outside the timed region: which form `auto` picks for them, how many tiles do not
+    # fit it, the quad / wave read-mode histogram, and the kernel's time
     maps_info, realistic = None, []
     if rank == 0 and rectify and mode == "mf":
         try:
@@ -652,11 +706,21 @@ def main():
         except Exception as e:
             maps_info = {"error": repr(e)}
     if rank == 0 and args.profile and rectify and mode == "mf" and args.map_sweep and not args.pmc_child:
-        for theta, k1 in ((0.1, -0.10), (0.2, -0.15), (0.3, -0.20)):
-            ent = {"rig": "verged, theta %.1f rad, k1 %.2f" % (theta, k1)}
+        sweep = [("near-identity", None, None), ("verged", 0.1, -0.10), ("verged", 0.2, -0.15), ("verged", 0.3, -0.20)]
+        for kind, theta, k1 in sweep:
+            if kind == "verged" and rig is not None and abs(theta - rig_theta) < 1e-9 and abs(k1 - rig_k1) < 1e-9:
+                continue                                     # the maps of the timed region themselves
+            if kind == "near-identity" and rig is None:
+                continue
+            ent = {"rig": "verged, theta %.1f rad, k1 %.2f" % (theta, k1) if kind == "verged" else
+                          "near-identity (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / -0.06)"}
             try:
-                rig = synth.make_verged_rig(W, H, theta, k1)
-                synth.install_verged_maps(ctx, rig, W, H)
+                if kind == "verged":
+                    synth.install_verged_maps(ctx, synth.make_verged_rig(W, H, theta, k1), W, H)
+                else:
+                    for cam in range(2):
+                        mxy, mfr = synth.make_rectify_maps(W, H, cam, device=dev)
+                        ctx.set_rectify_maps(cam, mxy, mfr)
                 info = [ctx.rectify_info(cam) for cam in range(2)]
                 # stream-event time of F back-to-back calls (the LDS-DMA form's fix-up launches for tiles that do not fit it are
                 # part of a call; the per-kernel profiler would only see the main kernel)
@@ -668,7 +732,6 @@ def main():
                 for f in range(F):
                     ctx.mf_rectify_decode_pair(stack[f, 0], stack[f, 1], BLACK_THR, W=W, want_valid=False, phase=ph_sw)
                 per_frame_us = ctx.timer_end() / F * 1e3
-                name = "_pair"
                 gbs = ALG_BYTES["slr_mf_rectify_decode_pair"] * npix / (per_frame_us * 1e-6) / 1e9
                 ent.update({"form_selected": [i["mf_form"] for i in info], "nofit_tiles": [i["dma_nofit_tiles"] for i in info],
                             "dma_tiles": info[0]["dma_tiles"], "quads_by_class": [i["quads_by_class"] for i in info],
@@ -679,9 +742,9 @@ def main():
             except Exception as e:                          # never break the bench line
                 ent["error"] = repr(e)
             realistic.append(ent)
-        for cam in range(2):                                 # back to the maps of the timed region
-            ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
+        install_maps(ctx)                                    # back to the maps of the timed region
 
+    _trace("traffic, extras and map sweep done")
     if roofline and isinstance(maps_info, list):
         roofline["form_selected"] = [i["mf_form"] for i in maps_info]
         roofline["nofit_tiles"] = [i["dma_nofit_tiles"] for i in maps_info]
@@ -698,9 +761,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline and mode == "mf":
         rows = args.cpu_rows or H          # whole frame: ~8 s of single-thread CPU work at 4096x3000
-        maps_cpu = None if maps is None else [(m[0].cpu().numpy(), m[1].cpu().numpy()) for m in maps]
+        maps_cpu = None if not rectify else [ctx.get_rectify_maps(cam, W, H) for cam in range(2)]
         cpu = cpu_baseline(synth, W, H, np.ascontiguousarray(stack[0, :, :, :, :W].cpu().numpy()), maps_cpu, calib, rows)
 
+    _trace("host-io and cpu baseline done")
     if rank == 0:
         out = {
             "metric": "Mpixels/s decode+unwrap+triangulate, 4096x3000 stereo, 1/2/4/8 GPU",
@@ -716,8 +780,8 @@ def main():
                                     "hybrid": "%dx%d stereo, Gray-code columns + 3-freq x 4-step fringes in one stack (38 planes/camera, "
                                               "BASELINE config 3): one-pass rectify+Gray decode+phase decode, phase match+triangulate"}[mode] % (W, H)
                                    + "; a step = %d distinct HBM-resident frames per GPU" % F,
-                       "maps": ("synthetic near-identity rectification maps (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / -0.06); "
-                                "verged rigs: see realistic_maps") if rectify else None,
+                       "maps": (rig_desc or "synthetic near-identity rectification maps (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / "
+                                "-0.06); verged rigs: see realistic_maps") if rectify else None,
                        "mode": mode, "frames_per_gpu_per_step": F, "rectify": rectify, "streams_per_gpu": S,
                        "debug_flags": args.debug_flags,
                        "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
@@ -731,6 +795,10 @@ def main():
             "collective_ranks": None if collective is None else collective["ranks"],
             "collective": collective,
             "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+            # the same job with its one exchange step counted: all units / (timed steps + the all-gather that follows them)
+            "gather_inclusive_value": (round(world * npix * F * args.steps / (elapsed + gather_ms * 1e-3) / 1e6, 2) if gather_ms is not None
+                                       else (round(value, 2) if final_gather else None)),
+            "gather_proof": gather_proof,
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
             "roofline": roofline,

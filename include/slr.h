@@ -152,6 +152,18 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * not the cached calibration tables) is filled with 0x7B bytes first, behind a device synchronisation: an intermediate a kernel
  * fails to write cannot pass for the previous call's.  Slow; 0 (default) = off. */
 #define SLR_OPT_DEBUG_POISON_SCRATCH 13
+/* SLR_OPT_EVAL_MODEL: which evaluation of the reference's floating-point source text the multi-frequency path reproduces.
+ *   0 (default) = strict IEEE: every f32 operation rounds to f32 (what oracle/slr_oracle.c restates; SSE2-style code).
+ *   1 = x87: the reference's own binary is an MSVC2010 32-bit x87 build (Duke.pro, /fp:precise, 53-bit precision control) in which
+ *       a compound float expression keeps 53 bits until it is stored -- P[count] = atan(...) + PI lands in a double unrounded,
+ *       P123 and phase = P123/(2*PI)*255 round once, fabs(phiL - phiR) < 0.1 sees the exact difference, the disparity
+ *       ulx - urx is stored to a double unrounded (mfreconstruct.cpp:246-268, :295, :299).  On BASELINE's scene the two models
+ *       differ in the last place of 37 % of the phases and pick another first-match column for 2.2-2.4 % of the matched pixels
+ *       (tests/x87_sensitivity.py); neither can be pinned without the MSVC2010 toolchain, so a host that must
+ *       match the shipped Windows binary chooses here.  Mode 1 runs the plain kernel forms (per-pixel gather for the rectifying
+ *       decode, the general match kernel) and real f64 divisions: about 1.5x the time per frame.  Gray-code modes are integer
+ *       work up to the Q reprojection and are the same under both. */
+#define SLR_OPT_EVAL_MODEL 14
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
 /* ---- configuration ---------------------------------------------------------------------------------- */
@@ -171,7 +183,8 @@ int slr_init_rectify_maps(slr_ctx *ctx, int cam, const double M[9], const double
                           const double P[12], int W, int H);
 /* What the installed maps of `cam` mean for the fused rectify + decode kernels (they pick their form per call from this):
  *   mf_form          the SLR_OPT_RECT_DECODE_ALGO value the multi-frequency decode resolves to for these maps under the current
- *                    options (7 = LDS-DMA form; 5 / 6 = round-1 LDS tiles, which fall back per tile to a gather)
+ *                    options (7 = LDS-DMA form; 5 / 6 = round-1 LDS tiles, which fall back per tile to a gather); -1: the option
+ *                    asks for form 7 explicitly and these maps do not allow it (a decode call returns SLR_ERR_UNSUPPORTED)
  *   dma_tiles / dma_nofit_tiles   tiles of the LDS-DMA form's shape, and how many of them the form cannot hold even in parts:
  *                    a tile whose source box is larger than the LDS image (keystone corners) is decoded in wave-aligned halves,
  *                    quarters, ... (dma_extra_entries counts the extra parts); what no split makes fit is rewritten by a gather
@@ -222,6 +235,23 @@ int slr_mf_rectify_decode_pair(slr_ctx *ctx, const uint8_t *const planesL[SLR_MF
  * every frequency has a modulation amplitude above half a grey level.  2 <= n_freq <= SLR_MFN_MAX_FREQ, 3 <= n_step <= SLR_MFN_MAX_STEPS. */
 int slr_mfn_decode(slr_ctx *ctx, const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
                    float black_thr, float *phase, uint8_t *valid, slr_mem mem);
+/* ... and THROUGH THE RECTIFICATION (BASELINE config 5 on the north_star path; build extension, parity unpinned): raw fp16
+ * camera planes, camera `cam`'s maps applied with cv::remap's geometry as stereoRect::doStereoRectify uses it (stereorect.cpp:26-34:
+ * CV_16SC2 + CV_16UC1 maps, 5-bit fractions, the four taps (sx, sy) .. (sx + 1, sy + 1), BORDER_CONSTANT 0) and f32 arithmetic --
+ *     sample = ((t00 w00 + t01 w01) + (t10 w10 + t11 w11)) * (1 / 1024),  w00 = (32 - fx)(32 - fy), w01 = fx (32 - fy), ...
+ * every operation rounded to f32 (OpenCV 2.4's remap has no fp16 mode, so there is nothing to be bit-equal to) -- fused with the
+ * decode above: the rectified samples go into the DFT sums as f32.
+ * ROW BANDS (one huge frame over several GPUs): the call decodes destination rows [row0, row0 + rows) of the H-row
+ * image into phase / valid of [rows][W] elements.  The planes hold SOURCE rows [src_row0, src_row0 + src_rows) only: planes[i]
+ * points at source row src_row0, pitch in elements; a tap outside that window reads 0.  slr_rectify_source_rows returns the window
+ * a band needs (the rows its maps point into, clipped to the image); with a window at least that large a band's result equals
+ * the same rows of the whole-frame call (row0 = 0, rows = H, src_row0 = 0, src_rows = H) bit for bit. */
+int slr_mfn_rectify_decode(slr_ctx *ctx, int cam, const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                           float black_thr, int row0, int rows, int src_row0, int src_rows, float *phase, uint8_t *valid,
+                           slr_mem mem);
+/* source rows [*src_row0, *src_row0 + *src_rows) that destination rows [row0, row0 + rows) of camera `cam` sample through the
+ * installed maps (both bilinear rows, clipped to the image; 0 rows when the band samples nothing).  Synchronous. */
+int slr_rectify_source_rows(slr_ctx *ctx, int cam, int row0, int rows, int *src_row0, int *src_rows);
 
 /* ---- K3 / K3': Reconstruct::computeShadows + decodePatterns_GE/getProjPixel_GE (reconstruct.cpp:79-97,
  * 210-227,381-407) or decodePaterns/getProjPixel (:56-74,:325-370) + GrayCodes::grayToDec
@@ -307,9 +337,11 @@ int slr_reconstruct_gray(slr_ctx *ctx, const uint8_t *const *planesL, const uint
  * steps, multifrequency.cpp:14-33): 2 + 2 n_col_bits + 12 planes.  Raw camera images; the ctx maps are applied (fused).
  * Each output is exactly what its own mode computes: code_x = Reconstruct::decodePatterns_GE / getProjPixel_GE
  * (reconstruct.cpp:79-97, 381-407; -1 where masked or erroneous), phase = MFReconstruct::decodePatterns / getPhase
- * (mfreconstruct.cpp:210-269; a quiet NaN where the pixel is invalid, see slr_mf_rectify_decode_pair).  One pass over the stack
- * -- both cameras in one launch, the shadow mask, the map digest and the source-box geometry shared by the two decodes -- when
- * the LDS-DMA form applies (equally spaced planes, W % 16 == 0, the default tile shape); otherwise two fused decodes per camera. */
+ * (mfreconstruct.cpp:210-269; a quiet NaN where the pixel is invalid, see slr_mf_rectify_decode_pair).  When the LDS-DMA form
+ * applies (equally spaced planes, W % 16 == 0, the default tile shape) the default is TWO launches over the one stack, each for both
+ * cameras: the fused Gray decode on planes 0 .. 2 n + 1, then the fused multi-frequency decode on white, black and the fringes
+ * behind the Gray planes; SLR_OPT_HYBRID_ONE_PASS = 1 selects ONE kernel over all planes of a tile instead (shadow mask, map digest
+ * and source-box geometry shared; measured slower: DESIGN.md).  Otherwise two fused decodes per camera.  Same results every way. */
 int slr_hybrid_rectify_decode_pair(slr_ctx *ctx, const uint8_t *const *planesL, const uint8_t *const *planesR, int n_col_bits,
                                    int pitch, int W, int H, int black_thr, int white_thr, int scan_w,
                                    int32_t *code_xL, float *phaseL, int32_t *code_xR, float *phaseR, slr_mem mem);

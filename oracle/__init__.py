@@ -44,7 +44,7 @@ class Camera(C.Structure):
 
 def build(force=False):
     """Compile the oracle with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("slr_oracle.c", "slr_oracle.h", "slr_literal.cpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("slr_oracle.c", "slr_oracle_x87.c", "slr_oracle.h", "slr_literal.cpp")]
     newest = max(os.path.getmtime(f) for f in srcs if os.path.exists(f))
     if (not force and os.path.exists(_LIB_PATH) and os.path.exists(_LIT_PATH)
             and min(os.path.getmtime(_LIB_PATH), os.path.getmtime(_LIT_PATH)) >= newest):
@@ -65,6 +65,9 @@ def lib():
         _lib.slro_wrapped_phase.restype = C.c_int
         _lib.slro_heterodyne.restype = C.c_float
         _lib.slro_line_line_intersection.restype = C.c_int
+        _lib.slro_wrapped_phase_ev.restype = C.c_int
+        _lib.slro_heterodyne_ev.restype = C.c_float
+        _lib.slro_line_line_intersection_x87.restype = C.c_int
     return _lib
 
 
@@ -155,6 +158,24 @@ def mfn_decode_f64(planes, n_freq, n_step, black_thr, W=None):
     valid = np.empty((H, W), np.uint8)
     lib().slro_mfn_decode_f64(ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch), C.c_int(W), C.c_int(H),
                               C.c_double(black_thr), _p(phase), _p(valid))
+    return phase, valid
+
+
+def mfn_rect_decode_f64(planes, n_freq, n_step, black_thr, map_xy, map_frac, W=None, rows=None):
+    """BUILD EXTENSION model of slr_mfn_rectify_decode: planes [2+F*N][H][pitch] float16 (raw camera images) through cv::remap's
+    geometry with an exact (f64) bilinear sample -> (phase f64 [H][W], valid u8), rows = (r0, r1) only (default: all)."""
+    planes = np.ascontiguousarray(planes).view(np.uint16)
+    n, H, pitch = planes.shape
+    assert n == 2 + n_freq * n_step
+    W = pitch if W is None else W
+    r0, r1 = (0, H) if rows is None else rows
+    ptrs = (C.c_void_p * n)(*[planes[i].ctypes.data for i in range(n)])
+    phase = np.zeros((H, W), np.float64)
+    valid = np.zeros((H, W), np.uint8)
+    mx, mf = np.ascontiguousarray(map_xy, np.int16), np.ascontiguousarray(map_frac, np.uint16)
+    assert mx.shape == (H, W, 2) and mf.shape == (H, W)
+    lib().slro_mfn_rect_decode_f64(ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                   C.c_double(black_thr), _p(mx), _p(mf), C.c_int(r0), C.c_int(r1), _p(phase), _p(valid))
     return phase, valid
 
 
@@ -309,3 +330,66 @@ def pointcloud_get(pc_sum, pc_count):
     lib().slro_pointcloud_get(_p(np.ascontiguousarray(pc_sum, np.float32)), _p(np.ascontiguousarray(pc_count)),
                               C.c_int(n), _p(out))
     return out.reshape(pc_count.shape + (3,))
+
+
+# ---- second evaluation model: the reference's MSVC2010 x87 build (slr_oracle_x87.c; sensitivity analysis) -----------------------
+def atan_table(mode):
+    """511 floats: atan of the integer quotients -255 .. 255.  mode 0 glibc atanf, 1 MSVC x86's (float)atan((double)q), 2 / 3
+    every |entry| one ulp up / down, >= 4 seeded random -1 / 0 / +1 ulp."""
+    tab = np.empty(511, np.float32)
+    lib().slro_atan_table(C.c_int(mode), _p(tab))
+    return tab
+
+
+def wrapped_phase_ev(G1, G2, G3, G4, atab, x87):
+    P = C.c_double(0)
+    ok = lib().slro_wrapped_phase_ev(C.c_int(G1), C.c_int(G2), C.c_int(G3), C.c_int(G4), _p(atab), C.c_int(x87), C.byref(P))
+    return bool(ok), float(P.value)
+
+
+def heterodyne_ev(P, x87):
+    a = (C.c_double * 3)(*[float(v) for v in P])
+    return np.float32(lib().slro_heterodyne_ev(a, C.c_int(x87)))
+
+
+def mf_decode_ev(planes, black_thr, atab, x87, W=None):
+    ptrs, pitch = _planes_ptrs(planes)
+    H = planes.shape[1]
+    W = pitch if W is None else W
+    phase = np.empty((H, W), np.float32)
+    valid = np.empty((H, W), np.uint8)
+    lib().slro_mf_decode_ev(ptrs, C.c_int(pitch), C.c_int(W), C.c_int(H), C.c_int(black_thr), _p(atab), C.c_int(x87),
+                            _p(phase), _p(valid))
+    return phase, valid
+
+
+def mf_triangulate_ev(phaseL, validL, phaseR, validR, camL, camR, Q, x87, T=None, rows=None):
+    H, W = phaseL.shape
+    xyz = np.zeros((H, W, 3), np.float32)
+    has = np.zeros((H, W), np.uint8)
+    mk = np.full((H, W), -1, np.int32)
+    Qa, Ta = _q(Q), _t(T)
+    r0, r1 = (0, H) if rows is None else rows
+    lib().slro_mf_triangulate_rows_ev(_p(np.ascontiguousarray(phaseL, np.float32)), _p(np.ascontiguousarray(validL)),
+                                      _p(np.ascontiguousarray(phaseR, np.float32)), _p(np.ascontiguousarray(validR)),
+                                      C.c_int(W), C.c_int(H), C.c_int(r0), C.c_int(r1), C.byref(camL), C.byref(camR),
+                                      _p(Qa), _p(Ta), C.c_int(x87), _p(xyz), _p(has), _p(mk))
+    return xyz, has, mk
+
+
+def line_line_intersection_x87(p1, v1, p2, v2):
+    a = [np.ascontiguousarray(v, np.float32) for v in (p1, v1, p2, v2)]
+    out = np.zeros(3, np.float32)
+    ok = lib().slro_line_line_intersection_x87(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out))
+    return bool(ok), out
+
+
+def ray_triangulate_x87(offL, itemsL, offR, itemsR, camL, camR, scan_w, scan_h, T=None):
+    xyz = np.zeros((scan_h, scan_w, 3), np.float32)
+    cnt = np.zeros((scan_h, scan_w), np.uint8)
+    Ta = _t(T)
+    iL = np.ascontiguousarray(itemsL, np.uint32) if itemsL.size else np.zeros(1, np.uint32)
+    iR = np.ascontiguousarray(itemsR, np.uint32) if itemsR.size else np.zeros(1, np.uint32)
+    lib().slro_ray_triangulate_x87(_p(offL), _p(iL), _p(offR), _p(iR), C.byref(camL), C.byref(camR), _p(Ta),
+                                   C.c_int(scan_w), C.c_int(scan_h), _p(xyz), _p(cnt))
+    return xyz, cnt

@@ -640,3 +640,51 @@ void slro_mfn_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, 
             valid[o] = (uint8_t)ok;
         }
 }
+
+/* the same model THROUGH the rectification (slr_mfn_rectify_decode; build extension, no reference counterpart): cv::remap's
+ * geometry as stereorect.cpp:26-34 uses it (CV_16SC2 + CV_16UC1 maps, 5-bit fractions, taps (sx, sy) .. (sx+1, sy+1),
+ * BORDER_CONSTANT 0) with the bilinear sample evaluated in f64 -- exact: taps are binary16, weights integers below 2^11 --
+ * and the decode of slro_mfn_decode_f64 on those samples.  rows [row0, row1) only (phase / valid are full [H][W] arrays). */
+void slro_mfn_rect_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                              double black_thr, const int16_t *map_xy, const uint16_t *map_frac, int row0, int row1,
+                              double *phase, uint8_t *valid)
+{
+    const double PI = 3.14159265358979323846, TWO_PI = 2 * PI;
+    double D[16];
+    for (int row = row0; row < row1; row++)
+        for (int col = 0; col < W; col++) {
+            const size_t o = (size_t)row * W + col;
+            const int sx = map_xy[2 * o], sy = map_xy[2 * o + 1];
+            const int f = map_frac[o] & 1023, fx = f & 31, fy = f >> 5;
+            const double w[4] = {(double)((32 - fx) * (32 - fy)), (double)(fx * (32 - fy)), (double)((32 - fx) * fy), (double)(fx * fy)};
+            size_t t[4];
+            int in[4];
+            for (int k = 0; k < 4; k++) {
+                const int x = sx + (k & 1), y = sy + (k >> 1);
+                in[k] = x >= 0 && x < W && y >= 0 && y < H;
+                t[k] = in[k] ? (size_t)y * pitch + x : 0;
+            }
+#define SLRO_SAMPLE(P) ((((in[0] ? slro_half_to_double((P)[t[0]]) : 0.0) * w[0] + (in[1] ? slro_half_to_double((P)[t[1]]) : 0.0) * w[1]) \
+                       + ((in[2] ? slro_half_to_double((P)[t[2]]) : 0.0) * w[2] + (in[3] ? slro_half_to_double((P)[t[3]]) : 0.0) * w[3])) / 1024.0)
+            const int mask = SLRO_SAMPLE(planes[0]) - SLRO_SAMPLE(planes[1]) > black_thr;
+            int ok = mask;
+            for (int fq = 0; fq < n_freq; fq++) {
+                double S = 0, C = 0;
+                for (int k = 0; k < n_step; k++) {
+                    const double I = SLRO_SAMPLE(planes[2 + fq * n_step + k]);
+                    S += I * sin(TWO_PI * k / n_step);
+                    C += I * cos(TWO_PI * k / n_step);
+                }
+                double p = atan2(-S, C);
+                if (p < 0) p += TWO_PI;
+                if (!(S * S + C * C > (0.25 * n_step) * (0.25 * n_step))) ok = 0;
+                D[fq] = p;
+            }
+#undef SLRO_SAMPLE
+            for (int lvl = 1; lvl < n_freq; lvl++)
+                for (int i = 0; i + lvl < n_freq; i++)
+                    D[i] = (D[i] > D[i + 1]) ? (D[i] - D[i + 1]) : (D[i] - D[i + 1] + TWO_PI);
+            phase[o] = mask ? D[0] / TWO_PI * 255 : 0.0;
+            valid[o] = (uint8_t)ok;
+        }
+}

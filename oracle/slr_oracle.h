@@ -148,6 +148,28 @@ void slro_pointcloud_get(const float *pc_sum, const uint8_t *pc_count, int n, fl
 void slro_mfn_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
                          double black_thr, double *phase, uint8_t *valid);
 
+/* ... through the rectification (slr_mfn_rectify_decode): cv::remap's geometry, the bilinear sample exact in f64; rows [row0, row1)
+ * of full [H][W] outputs */
+void slro_mfn_rect_decode_f64(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                              double black_thr, const int16_t *map_xy, const uint16_t *map_frac, int row0, int row1,
+                              double *phase, uint8_t *valid);
+
+/* ---- second evaluation model: the reference's MSVC2010 x87 build (slr_oracle_x87.c; sensitivity analysis only) --------------
+ *      x87 = 0: strict IEEE, what every function above computes; x87 = 1: 53-bit x87 stack under /fp:precise (see that file).
+ *      atab: 511 floats from slro_atan_table (mode 0 glibc atanf, 1 MSVC x86's (float)atan((double)q), 2 / 3 +-1 ulp, >= 4 random). */
+void  slro_atan_table(int mode, float tab[511]);
+int   slro_wrapped_phase_ev(int G1, int G2, int G3, int G4, const float *atab, int x87, double *P);
+float slro_heterodyne_ev(const double P[3], int x87);
+void  slro_mf_decode_ev(const uint8_t *const planes[SLRO_MF_PLANES], int pitch, int W, int H, int black_thr,
+                        const float *atab, int x87, float *phase, uint8_t *valid);
+void  slro_mf_triangulate_rows_ev(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
+                                  int W, int H, int row0, int row1, const slro_camera *camL, const slro_camera *camR,
+                                  const double Q[16], const float *T, int x87, float *xyz, uint8_t *has, int32_t *match_k);
+int   slro_line_line_intersection_x87(const float p1[3], const float v1[3], const float p2[3], const float v2[3], float out[3]);
+void  slro_ray_triangulate_x87(const int32_t *offL, const uint32_t *itemsL, const int32_t *offR, const uint32_t *itemsR,
+                               const slro_camera *camL, const slro_camera *camR, const float *T, int scan_w, int scan_h,
+                               float *xyz_sum, uint8_t *count);
+
 #ifdef __cplusplus
 }
 #endif

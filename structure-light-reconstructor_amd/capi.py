@@ -27,6 +27,7 @@ OPT_DEBUG_FLAGS = 9            # tests: bit 0 no map digest, bit 1 no buffer-des
 OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
 OPT_BATCH_STREAMS = 12         # GRAY_ONLY batch: 2 (default) = frames pipelined over two streams, 1 = sequential
 OPT_DEBUG_POISON_SCRATCH = 13  # tests: scratch buffers are filled with 0x7B bytes before a call gets them
+OPT_EVAL_MODEL = 14            # 0 = strict IEEE (default), 1 = the reference's MSVC2010 x87 / fp:precise evaluation (slr.h)
 OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel
 OPT_ASYNC_HOST = 4             # host-buffer calls return after enqueuing; outputs valid after ctx.synchronize()
@@ -38,7 +39,8 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_CONFIGURED, ERR_UNSUPPORTED
 SYMBOLS = [
     "slr_version", "slr_status_string", "slr_current_device", "slr_create", "slr_destroy", "slr_set_stream", "slr_synchronize",
     "slr_last_error", "slr_set_option", "slr_set_calibration", "slr_set_rectify_maps", "slr_init_rectify_maps",
-    "slr_get_rectify_maps", "slr_get_rectify_info", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode",
+    "slr_get_rectify_maps", "slr_get_rectify_info", "slr_remap_u8", "slr_mf_decode", "slr_mfn_decode", "slr_mfn_rectify_decode",
+    "slr_rectify_source_rows",
     "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_line_line_intersections", "slr_pointcloud_from_grid", "slr_pointcloud_get",
@@ -380,6 +382,30 @@ class Context:
         return phase, valid
 
     # -- K3 / K3'
+    def rectify_source_rows(self, cam, row0, rows):
+        """(src_row0, src_rows): the source rows destination rows [row0, row0 + rows) of `cam` sample through the installed maps"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.slr_rectify_source_rows(self.h, C.c_int(cam), C.c_int(row0), C.c_int(rows), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def mfn_rectify_decode(self, cam, planes, n_freq, n_step, black_thr, W=None, H=None, row0=0, rows=None, src_row0=0, phase=None,
+                           valid=None):
+        """planes [2 + F*N][src_rows][pitch] float16: source rows [src_row0, src_row0 + src_rows) of an H-row image (H defaults to
+        src_rows: the whole frame); decodes destination rows [row0, row0 + rows) through camera `cam`'s maps."""
+        ptrs, n, src_rows, pitch = _plane_ptrs(planes)
+        assert n == 2 + n_freq * n_step
+        W = pitch if W is None else W
+        H = src_rows if H is None else H
+        rows = H - row0 if rows is None else rows
+        mem = self._mem(_flat(planes) + [phase, valid])
+        like = _flat(planes)[0]
+        phase = self._new(mem, (rows, W), np.float32, like) if phase is None else phase
+        valid = self._new(mem, (rows, W), np.uint8, like) if valid is None else valid
+        self._chk(self.lib.slr_mfn_rectify_decode(self.h, C.c_int(cam), ptrs, C.c_int(n_freq), C.c_int(n_step), C.c_int(pitch),
+                                                  C.c_int(W), C.c_int(H), C.c_float(black_thr), C.c_int(row0), C.c_int(rows),
+                                                  C.c_int(src_row0), C.c_int(src_rows), _ptr(phase), _ptr(valid), C.c_int(mem)))
+        return phase, valid
+
     def gray_decode(self, planes, n_col_bits, n_row_bits, black_thr, white_thr, scan_w, scan_h, W=None,
                     rectify_cam=None):
         ptrs, n, H, pitch = _plane_ptrs(planes)

@@ -78,11 +78,32 @@ __device__ __forceinline__ float heterodyne_q24(int P0, int P1, int P2)
 {
     return het_finish_q24(het_pair_q24(P0, P1), het_pair_q24(P1, P2));
 }
+// SLR_OPT_EVAL_MODEL = 1: mfreconstruct.cpp:267-268 as the reference's own MSVC2010 x87 / fp:precise binary evaluates it (the
+// 53-bit x87 stack, one rounding at each store).  The wrapped phases come from the
+// x87 variant of lutP (float + float at 53 bits, stored to a double: the UNROUNDED sums, still integers at the 2^24 scale), P12
+// and P23 are formed exactly as in the strict model (het_pair_q24: an exact difference, one rounding).  Then
+//   P123 = P12 - P23 (+ 2*PI): the operands are f32 images of integers below 2^28, so the sum is exact in int32 and
+//          v_cvt_f32_i32 is the ONE rounding of the x87 store (the strict model rounds twice in the + branch);
+//   phase = P123 / (2*PI) * 255: quotient and product rounded to 53 bits, one narrowing to f32 -- real f64 arithmetic here (an
+//          opt-in parity mode: the cost, ~40 % more VALU time in the decode, is the price of the division).
+__device__ __forceinline__ float het_finish_x87(float F12, float F23)
+{
+    const int d = ((int)F12 - (int)F23) + ((F12 > F23) ? 0 : kQ24TwoPI);
+    const float F123 = (float)d;
+    const double q = (double)F123 / (double)(kTwoPI * 16777216.0f);     // == P123 / (2*PI): the 2^24 scales cancel exactly
+    return (float)(q * 255.0);
+}
+template <bool X87>
+__device__ __forceinline__ float heterodyne_ev(int P0, int P1, int P2)
+{
+    if constexpr (X87) return het_finish_x87(het_pair_q24(P0, P1), het_pair_q24(P1, P2));
+    else return heterodyne_q24(P0, P1, P2);
+}
 
 // one pixel of K2: g[0]=white g[1]=black g[2..13] fringes.  SH: the samples sit in bits [SH, SH+8) of g[] with zeros
 // above (the fused LDS kernel hands over its dot-product accumulators, SH = 16, so that the extraction folds into the
 // subtractions as an SDWA operand select instead of 14 shifts).
-template <int SH>
+template <int SH, bool X87 = false>
 __device__ __forceinline__ float mf_pixel_sh(const int *gs, int black_thr, const float *lut, int &valid)
 {
     int g[SLR_MF_PLANES];
@@ -94,13 +115,14 @@ __device__ __forceinline__ float mf_pixel_sh(const int *gs, int black_thr, const
     const int P0 = wrapped_phase_q24(g[2], g[3], g[4], g[5], lut, nz0);
     const int P1 = wrapped_phase_q24(g[6], g[7], g[8], g[9], lut, nz1);
     const int P2 = wrapped_phase_q24(g[10], g[11], g[12], g[13], lut, nz2);
-    const float ph = heterodyne_q24(P0, P1, P2);
+    const float ph = heterodyne_ev<X87>(P0, P1, P2);
     valid = (mask && nz0 != 0 && nz1 != 0 && nz2 != 0) ? 1 : 0;   // Q5 rule: an undefined P makes the pixel invalid
     return mask ? ph : 0.0f;
 }
+template <bool X87 = false>
 __device__ __forceinline__ float mf_pixel(const int *g, int black_thr, const float *lut, int &valid)
 {
-    return mf_pixel_sh<0>(g, black_thr, lut, valid);
+    return mf_pixel_sh<0, X87>(g, black_thr, lut, valid);
 }
 
 // ------------------------------------------------------------------------------------------------------

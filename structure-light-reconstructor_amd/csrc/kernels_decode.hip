@@ -84,7 +84,7 @@ __device__ __forceinline__ unsigned word_of(unsigned v, int) { return v; }
 __device__ __forceinline__ unsigned word_of(const u32x2 &v, int k) { return v[k]; }
 __device__ __forceinline__ unsigned word_of(const u32x4 &v, int k) { return v[k]; }
 
-template <int NW>
+template <int NW, bool X87 = false>
 __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                         const float *__restrict__ lut_g,
                                                         float *__restrict__ phase, uint8_t *__restrict__ valid)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
 #pragma unroll
                 for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (word_of(w[p], k) >> (8 * b)) & 0xFFu;
                 int v;
-                ph[b] = mf_pixel(gpx, black_thr, lut, v);
+                ph[b] = mf_pixel<X87>(gpx, black_thr, lut, v);
                 if (!valid) ph[b] = v ? ph[b] : kInvalidPhase;
                 vw |= (unsigned)v << (8 * b);
             }
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void mf_decode_kernel(MfPlanes pl, int pitch, 
 }
 
 // generic (any W / pitch / alignment): one pixel per thread
+template <bool X87 = false>
 __global__ __launch_bounds__(256) void mf_decode_scalar_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                                const float *__restrict__ lut_g,
                                                                float *__restrict__ phase, uint8_t *__restrict__ valid)
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(256) void mf_decode_scalar_kernel(MfPlanes pl, int 
 #pragma unroll
         for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = pl.p[p][so];
         int v;
-        const float ph = mf_pixel(gpx, black_thr, lut, v);
+        const float ph = mf_pixel<X87>(gpx, black_thr, lut, v);
         phase[g] = valid || v ? ph : kInvalidPhase;
         if (valid) valid[g] = (uint8_t)v;
     }
 }
 
 // fused K1+K2: V destination pixels per thread (V = 4 when W % 4 == 0, else 1); taps gathered through L1/L2
-template <int V>
+template <int V, bool X87 = false>
 __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                              const float *__restrict__ lut_g,
                                                              const int16_t *__restrict__ map_xy,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void mf_rect_decode_kernel(MfPlanes pl, int pi
 #pragma unroll
             for (int p = 0; p < SLR_MF_PLANES; p++) gpx[p] = (packed[p] >> (8 * i)) & 0xFFu;
             int v;
-            ph[i] = mf_pixel(gpx, black_thr, lut, v);
+            ph[i] = mf_pixel<X87>(gpx, black_thr, lut, v);
             if (!valid) ph[i] = v ? ph[i] : kInvalidPhase;
             vw |= (unsigned)v << (8 * i);
         }
@@ -1241,6 +1242,7 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
                                       bool *done, hipStream_t s)
 {
     *done = false;
+    if (tl_debug.eval_x87) return hipSuccess;               // SLR_OPT_EVAL_MODEL = 1: per camera, through launch_mf_decode_x87
     for (int c = 0; c < 2; c++)
         if (!rect_lds_ok(pl[c], pitch, W, H, phase[c], valid[c], map_xy[c], tile_boxes[c], rect_algo)) return hipSuccess;
     RectJob jobs[2];
@@ -1249,10 +1251,35 @@ hipError_t launch_mf_rect_decode_pair(const MfPlanes pl[2], int pitch, int W, in
     return launch_rect_lds(jobs, 2, pitch, W, H, black_thr, atan_lut, rect_algo, s);
 }
 
+// SLR_OPT_EVAL_MODEL = 1 (the x87 evaluation of the heterodyne tail, decode_common.hpp): the plain forms only -- the per-pixel
+// gather for a rectifying decode, one pixel group per thread otherwise; atan_lut is then the x87 variant of the tables
+static hipError_t launch_mf_decode_x87(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
+                                       float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac, hipStream_t s)
+{
+    if (map_xy) {
+        const bool vec = (W % 4 == 0) && ((uintptr_t)phase % 16 == 0) && (!valid || (uintptr_t)valid % 4 == 0) &&
+                         ((uintptr_t)map_xy % 16 == 0) && ((uintptr_t)map_frac % 8 == 0);
+        if (vec) SLR_LAUNCH((mf_rect_decode_kernel<4, true>), dim3(pick_blocks((size_t)(W / 4) * H)), dim3(256), 0, s,
+                            pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
+        else     SLR_LAUNCH((mf_rect_decode_kernel<1, true>), dim3(pick_blocks((size_t)W * H)), dim3(256), 0, s,
+                            pl, pitch, W, H, black_thr, atan_lut, map_xy, map_frac, phase, valid);
+        return hipGetLastError();
+    }
+    bool a4 = (W % 4 == 0) && (pitch % 4 == 0) && pitch == W;
+    for (int p = 0; p < SLR_MF_PLANES; p++) a4 = a4 && ((uintptr_t)pl.p[p] % 4 == 0);
+    a4 = a4 && ((uintptr_t)phase % 16 == 0) && ((uintptr_t)valid % 4 == 0);
+    if (a4) SLR_LAUNCH((mf_decode_kernel<1, true>), dim3(pick_blocks_k2((size_t)(W / 4) * H)), dim3(256), 0, s,
+                       pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    else    SLR_LAUNCH((mf_decode_scalar_kernel<true>), dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
+                       pl, pitch, W, H, black_thr, atan_lut, phase, valid);
+    return hipGetLastError();
+}
+
 hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int black_thr, const float *atan_lut,
                             float *phase, uint8_t *valid, const int16_t *map_xy, const uint16_t *map_frac,
                             const void *tile_boxes, int vec_hint, int rect_algo, hipStream_t s)
 {
+    if (tl_debug.eval_x87) return launch_mf_decode_x87(pl, pitch, W, H, black_thr, atan_lut, phase, valid, map_xy, map_frac, s);
     if (rect_lds_ok(pl, pitch, W, H, phase, valid, map_xy, tile_boxes, rect_algo)) {
         const RectJob job{pl, 0u, map_xy, map_frac, (const int4 *)tile_boxes, phase, valid, nullptr};
         return launch_rect_lds(&job, 1, pitch, W, H, black_thr, atan_lut, rect_algo, s);
@@ -1296,7 +1323,7 @@ hipError_t launch_mf_decode(const MfPlanes &pl, int pitch, int W, int H, int bla
     }
     else if (a4)  SLR_LAUNCH(mf_decode_kernel<1>, dim3(pick_blocks_k2((size_t)(W / 4) * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
-    else          SLR_LAUNCH(mf_decode_scalar_kernel, dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
+    else          SLR_LAUNCH((mf_decode_scalar_kernel<false>), dim3(pick_blocks_k2((size_t)W * H)), dim3(256), 0, s,
                                      pl, pitch, W, H, black_thr, atan_lut, phase, valid);
     return hipGetLastError();
 }

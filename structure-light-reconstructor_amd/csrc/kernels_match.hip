@@ -113,6 +113,14 @@ __device__ __forceinline__ void apply_T(const float *T, float X[3])
     X[0] = Y[0]; X[1] = Y[1]; X[2] = Y[2];
 }
 
+// mfreconstruct.cpp:295 fabs(cam1Pix[0] - cam2Pix[0]) < 0.1.  Strict IEEE (default): the f32 difference is rounded before it
+// widens, and |d| < 0.1 (double) <=> |d| < 0.1f for a float d.  SLR_OPT_EVAL_MODEL = 1: the reference's x87 binary keeps the
+// difference of the two floats on the 53-bit stack (exact here) and hands it to fabs(double) unrounded.
+__device__ __forceinline__ bool phase_match(float a, float b, int x87)
+{
+    return x87 ? fabs((double)a - (double)b) < 0.1 : fabsf(a - b) < 0.1f;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // K4 (exact brute-force form): one workgroup per row; right-row phase in LDS with NaN marking "no phase"
 // (NaN never passes fabsf(d) < 0.1f), each lane owns left pixels j, every lane sweeps k ascending and
@@ -141,8 +149,8 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
         for (int k = 0; k < Wp; k += 4) {
             if (!__any(searching)) break;
             const float4 r = *reinterpret_cast<const float4 *>(phR + k);
-            const bool c0 = fabsf(pl - r.x) < 0.1f, c1 = fabsf(pl - r.y) < 0.1f;
-            const bool c2 = fabsf(pl - r.z) < 0.1f, c3 = fabsf(pl - r.w) < 0.1f;
+            const bool c0 = phase_match(pl, r.x, cal.eval_x87), c1 = phase_match(pl, r.y, cal.eval_x87);
+            const bool c2 = phase_match(pl, r.z, cal.eval_x87), c3 = phase_match(pl, r.w, cal.eval_x87);
             if (searching && (c0 | c1 | c2 | c3)) {
                 best = k + (c0 ? 0 : (c1 ? 1 : (c2 ? 2 : 3)));
                 searching = false;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void mf_match_kernel(const float *__restrict__
             float ulx, uly, urx, ury;
             undistort_point((float)j, (float)row, cal.cam[0], ulx, uly);      // mfreconstruct.cpp:297
             undistort_point((float)best, (float)row, cal.cam[1], urx, ury);   // :298
-            reproject(cal.Q, 0, (double)ulx, (double)uly, (double)(float)(ulx - urx), X);   // :299-311 (literal form)
+            reproject(cal.Q, 0, (double)ulx, (double)uly, cal.eval_x87 ? (double)ulx - (double)urx : (double)(float)(ulx - urx), X);   // :299-311 (literal form)
             if (cal.has_T) apply_T(cal.T, X);                                 // :315-323
         }
         float *o = xyz + 3 * (base + j);
@@ -286,7 +294,9 @@ __device__ __forceinline__ void k4_emit(const int best[IPT], size_t base, int k0
             const int i = i0 + q;
             float X[3] = {0.0f, 0.0f, 0.0f};
             if (best[i] >= 0) {
-                reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], (double)(float)(ulx[i] - urx[i]), X);
+                // :299 camPixelUDL.x - camPixelUDR.x stored to a double: rounded to f32 first under strict IEEE, unrounded on x87
+                const double disp = cal.eval_x87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i]);
+                reproject(cal.Q, cal.q_simple, (double)ulx[i], (double)uly[i], disp, X);
                 if (cal.has_T) apply_T(T, X);
             }
             out[3 * q] = X[0]; out[3 * q + 1] = X[1]; out[3 * q + 2] = X[2];
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_binne
             for (int q = 0; q < 4; q++) c[q] = sh.b.pk[idx + q < N ? idx + q : N - 1];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                const bool hit = idx + q < qi1[i] && phase_match(pl[i], c[q].x, cal.eval_x87);
                 const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
                 bk = kk < bk ? kk : bk;
             }
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
                     for (int q = 0; q < 4; q++) c[q] = sh.b.pk[idx + q < N ? idx + q : N - 1];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                        const bool hit = idx + q < qi1[i] && phase_match(pl[i], c[q].x, cal.eval_x87);
                         const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
                         bk = kk < bk ? kk : bk;
                     }
@@ -1006,7 +1016,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorte
             for (int q = 0; q < 4; q++) c[q] = sh.d.pk[idx + q < N ? idx + q : N - 1];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const bool hit = idx + q < qi1[i] && fabsf(pl[i] - c[q].x) < 0.1f;
+                const bool hit = idx + q < qi1[i] && phase_match(pl[i], c[q].x, cal.eval_x87);
                 const unsigned kk = hit ? __float_as_uint(c[q].y) : 0xFFFFFFFFu;
                 bk = kk < bk ? kk : bk;
             }
@@ -1077,7 +1087,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                vec_ok, undL, undRx, xyz, has, match_k)
 #endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
-        if (algo == 0 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+        if (algo == 0 && !cal.eval_x87 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
             K4Lean kc;
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];

@@ -113,6 +113,186 @@ __global__ __launch_bounds__(256) void mfn_decode_kernel(MfnPlanes pl, MfnTrig t
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Rectification for the generalised decode (BASELINE config 5 through the whole path; build extension, parity unpinned).
+// cv::remap has no fp16 mode in OpenCV 2.4, so the GEOMETRY is the reference's -- map1 / map2 of cv::initUndistortRectifyMap as
+// stereoRect::doStereoRectify applies them (stereorect.cpp:26-34): integer source position, two 5-bit fractions, the four taps
+// (sx, sy) .. (sx + 1, sy + 1), BORDER_CONSTANT 0 -- and the ARITHMETIC is f32:
+//     w00 = (32 - fx)(32 - fy), w01 = fx (32 - fy), w10 = (32 - fx) fy, w11 = fx fy            (integers, sum 1024)
+//     sample = ((t00 w00 + t01 w01) + (t10 w10 + t11 w11)) * (1 / 1024)                          (each operation rounded to f32)
+// (a product of an fp16 tap and a weight below 2^11 is exact in f32, so the sample carries two roundings at most), and the
+// sample goes into the DFT sums as f32: nothing is rounded back to fp16.  Fused with mfn_decode_kernel's per-pixel decode.
+// Row bands (one 8192 x 6000 frame over 8 GPUs): a launch decodes destination rows [row0, row0 + rows) into a
+// band-sized output; the planes hold SOURCE rows [src_row0, src_row0 + src_rows) only (plane pointers address source row
+// src_row0).  A tap outside that window reads 0 like a tap outside the image; slr_rectify_source_rows gives the window a band
+// needs, and with it a band's result is the whole frame's, bit for bit.
+// This is the per-pixel gather form (every tap a 2-byte load through L1 / L2; a quad of 4 adjacent pixels per thread so that
+// neighbouring lanes touch neighbouring lines): the LDS-tiled form of the u8 path is not built for fp16 yet.
+// ------------------------------------------------------------------------------------------------------
+template <int V, int FS, int NS>
+__global__ __launch_bounds__(256) void mfn_rect_decode_kernel(MfnPlanes pl, MfnTrig tr, int n_freq_rt, int n_step_rt, int pitch, int W,
+                                                              int H, float black_thr, const int16_t *__restrict__ map_xy,
+                                                              const uint16_t *__restrict__ map_frac, int row0, int rows,
+                                                              int src_row0, int src_rows, float *__restrict__ phase,
+                                                              uint8_t *__restrict__ valid)
+{
+    const int n_freq = FS ? FS : n_freq_rt, n_step = NS ? NS : n_step_rt;
+    const unsigned gpr = (unsigned)(W / V);
+    const unsigned total = gpr * (unsigned)rows;
+    // XCD-aware order (as mf_rect_decode_kernel): workgroup b runs on XCD b % 8; every XCD gets a contiguous band of rows, so the
+    // source rows shared by vertically adjacent destination rows are served by one L2
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    unsigned vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (nb % 8 != 0) vb = blockIdx.x;
+    for (unsigned g = vb * 256u + threadIdx.x; g < total; g += nb * 256u) {
+        const unsigned brow = g / gpr, col0 = (g - brow * gpr) * V;
+        const size_t m = (size_t)(brow + (unsigned)row0) * W + col0, oo = (size_t)brow * W + col0;
+        int off[V];                                      // element offset of the upper left tap inside the plane window
+        unsigned inb[V];                                 // bit 0..3: tap (0,0) (0,1) (1,0) (1,1) is readable
+        float w00[V], w01[V], w10[V], w11[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int sx = map_xy[2 * (m + v)], sy = map_xy[2 * (m + v) + 1];
+            const unsigned f = map_frac[m + v] & 1023u, fx = f & 31u, fy = f >> 5;
+            w00[v] = (float)((32u - fx) * (32u - fy)); w01[v] = (float)(fx * (32u - fy));
+            w10[v] = (float)((32u - fx) * fy); w11[v] = (float)(fx * fy);
+            const bool x0 = (unsigned)sx < (unsigned)W, x1 = (unsigned)(sx + 1) < (unsigned)W;
+            const bool y0 = (unsigned)sy < (unsigned)H && (unsigned)(sy - src_row0) < (unsigned)src_rows;
+            const bool y1 = (unsigned)(sy + 1) < (unsigned)H && (unsigned)(sy + 1 - src_row0) < (unsigned)src_rows;
+            inb[v] = (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
+            off[v] = (sy - src_row0) * pitch + sx;
+        }
+        auto load = [&](int p, float out[V]) {
+            const uint16_t *q = pl.p[p];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const float t00 = (inb[v] & 1u) ? h2f(q[off[v]]) : 0.0f, t01 = (inb[v] & 2u) ? h2f(q[off[v] + 1]) : 0.0f;
+                const float t10 = (inb[v] & 4u) ? h2f(q[off[v] + pitch]) : 0.0f, t11 = (inb[v] & 8u) ? h2f(q[off[v] + pitch + 1]) : 0.0f;
+                out[v] = ((t00 * w00[v] + t01 * w01[v]) + (t10 * w10[v] + t11 * w11[v])) * (1.0f / 1024.0f);
+            }
+        };
+        float wh[V], bk[V];
+        load(0, wh);
+        load(1, bk);
+        float D[V][SLR_MFN_MAX_FREQ];
+        bool ok[V];
+        const float mod2 = (0.25f * n_step) * (0.25f * n_step);
+#pragma unroll
+        for (int v = 0; v < V; v++) ok[v] = wh[v] - bk[v] > black_thr;
+#pragma unroll
+        for (int f = 0; f < n_freq; f++) {
+            float S[V], C[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < n_step; k++) {
+                float I[V];
+                load(2 + f * n_step + k, I);
+#pragma unroll
+                for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+            }
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                float p = atan2f(-S[v], C[v]);
+                if (p < 0.0f) p += kTrue2PI;
+                ok[v] = ok[v] && (S[v] * S[v] + C[v] * C[v] > mod2);
+#pragma unroll
+                for (int q = 0; q < SLR_MFN_MAX_FREQ; q++) if (q == f) D[v][q] = p;
+            }
+        }
+#pragma unroll
+        for (int lvl = 1; lvl < SLR_MFN_MAX_FREQ; lvl++) {
+            if (lvl < n_freq) {
+#pragma unroll
+                for (int i = 0; i + 1 < SLR_MFN_MAX_FREQ; i++) {
+                    if (i + lvl < n_freq) {
+#pragma unroll
+                        for (int v = 0; v < V; v++) {
+                            const float a = D[v][i], b = D[v][i + 1];
+                            D[v][i] = (a > b) ? (a - b) : (a - b + kTrue2PI);
+                        }
+                    }
+                }
+            }
+        }
+        float out[V];
+        unsigned vw = 0;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            out[v] = (wh[v] - bk[v] > black_thr) ? D[v][0] / kTrue2PI * 255 : 0.0f;
+            vw |= (ok[v] ? 1u : 0u) << (8 * v);
+        }
+        if constexpr (V == 4) {
+            *reinterpret_cast<float4 *>(phase + oo) = make_float4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<unsigned *>(valid + oo) = vw;
+        } else {
+            phase[oo] = out[0];
+            valid[oo] = (uint8_t)vw;
+        }
+    }
+}
+
+// source rows [lo, hi] that destination rows [row0, row0 + rows) read through a map (taps sy and sy + 1, clipped to the image);
+// out[0] = min sy, out[1] = max sy + 1 over the pixels whose footprint touches the image (initialised by the launcher)
+__global__ __launch_bounds__(256) void map_source_rows_kernel(const int16_t *__restrict__ map_xy, int W, int H, int row0, int rows,
+                                                              int *__restrict__ out)
+{
+    int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+    const size_t n = (size_t)rows * W, base = (size_t)row0 * W;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        const int sx = map_xy[2 * (base + i)], sy = map_xy[2 * (base + i) + 1];
+        if (sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0) continue;
+        lo = sy < lo ? sy : lo; hi = sy + 1 > hi ? sy + 1 : hi;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int a = __shfl_xor(lo, d), b = __shfl_xor(hi, d);
+        lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lo != 0x7FFFFFFF) atomicMin(out, lo);
+        if (hi != -0x7FFFFFFF) atomicMax(out + 1, hi);
+    }
+}
+
+hipError_t launch_map_source_rows(const int16_t *map_xy, int W, int H, int row0, int rows, int *d_out /* 2 ints */, hipStream_t s)
+{
+    const int init[2] = {0x7FFFFFFF, -0x7FFFFFFF};
+    hipError_t e = hipMemcpyAsync(d_out, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    const size_t n = (size_t)rows * W;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    SLR_LAUNCH(map_source_rows_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, map_xy, W, H, row0, rows, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
+                                  const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
+                                  float *phase, uint8_t *valid, hipStream_t s)
+{
+    MfnPlanes pl;
+    const int np = 2 + n_freq * n_step;
+    for (int i = 0; i < SLR_MFN_MAX_PLANES; i++) pl.p[i] = i < np ? planes[i] : nullptr;
+    const bool a4 = W % 4 == 0 && (uintptr_t)phase % 16 == 0 && (uintptr_t)valid % 4 == 0;
+    MfnTrig tr;
+    for (int k = 0; k < SLR_MFN_MAX_STEPS; k++) {
+        const double a = 2.0 * 3.14159265358979323846 * k / (double)n_step;
+        tr.cs[k] = k < n_step ? (float)cos(a) : 0.0f;
+        tr.sn[k] = k < n_step ? (float)sin(a) : 0.0f;
+    }
+    const size_t groups = a4 ? (size_t)(W / 4) * rows : (size_t)W * rows;
+    unsigned blocks = (unsigned)((groups + 255) / 256 < 65536 ? (groups + 255) / 256 : 65536);
+    blocks = (blocks + 7u) & ~7u;                            // (a multiple of 8: the XCD-banded order)
+#define SLR_MFNR(V, FS, NS)                                                                                            \
+    SLR_LAUNCH((mfn_rect_decode_kernel<V, FS, NS>), dim3(blocks ? blocks : 8), dim3(256), 0, s, pl, tr, n_freq, n_step, \
+               pitch, W, H, black_thr, map_xy, map_frac, row0, rows, src_row0, src_rows, phase, valid)
+    if (a4 && n_freq == 4 && n_step == 8) SLR_MFNR(4, 4, 8);         // BASELINE config 5
+    else if (a4) SLR_MFNR(4, 0, 0);
+    else SLR_MFNR(1, 0, 0);
+#undef SLR_MFNR
+    return hipGetLastError();
+}
+
 hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                              float *phase, uint8_t *valid, hipStream_t s)
 {

@@ -23,7 +23,7 @@ const char *kKernelNames[K_COUNT] = {
     "slr_mf_match_triangulate", "slr_ge_match_triangulate", "slr_ray_count", "slr_ray_scan", "slr_ray_scatter",
     "slr_ray_triangulate",
     "slr_pc_from_grid", "slr_pc_get", "slr_undistort_table", "slr_ray_table", "slr_mf_rectify_decode_pair", "slr_mfn_decode",
-    "slr_gray_rectify_decode_pair", "slr_hybrid_rectify_decode_pair"};
+    "slr_gray_rectify_decode_pair", "slr_hybrid_rectify_decode_pair", "slr_mfn_rectify_decode"};
 
 // scratch slots (device buffers owned by the ctx, grown on demand, reused across calls)
 enum Slot {
@@ -49,7 +49,10 @@ struct slr_ctx {
     bool has_calib = false;
     DevCalib cal;
     float *d_lut = nullptr;
-    unsigned *d_sched = nullptr;                // tile tickets of the LDS-DMA fused decodes (zero between launches)
+    // tile tickets of the LDS-DMA fused decodes: zero between launches (the last workgroup of a launch clears them), which holds
+    // because every fused decode of a context runs on c->stream, one launch after the other, and slr_set_stream drains the old stream
+    // before it switches; a launch that faults leaves the context unusable anyway (every later call returns the HIP error)
+    unsigned *d_sched = nullptr;
     int16_t *d_map_xy[2] = {nullptr, nullptr};
     uint16_t *d_map_frac[2] = {nullptr, nullptr};
     void *d_tile_box[2] = {nullptr, nullptr};   // per-tile source bounding boxes of the maps (launch_tile_boxes)
@@ -126,6 +129,7 @@ int mf_rect_algo(const slr_ctx *c, int a, int b)
 bool dma_form_wanted(const slr_ctx *c, int a, int b)
 {
     if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return false;
+    if (c->debug.eval_x87) return false;                    // SLR_OPT_EVAL_MODEL = 1 runs the plain forms (launch_mf_decode_x87)
     for (int cam = a; cam <= b; cam++) {
         if (!c->d_dma_tiles[cam] || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
         if (4ull * c->dma_stats[cam][0] > dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape)) return false;
@@ -484,6 +488,52 @@ int slr_current_device(int *device_id)
     return hipGetDevice(device_id) == hipSuccess ? SLR_OK : SLR_ERR_HIP;
 }
 
+// decode tables (kernels_decode.hip, wrapped_phase_q24): per difference d the 16-bit reciprocal of |d| with the
+// table slot of sgn d in the top byte, and the wrapped phase itself -- atanf over the integer quotient (SURVEY
+// Q1) plus the quadrant offset of mfreconstruct.cpp:246-261, evaluated by the host libm in the reference's f32
+// arithmetic so the device never evaluates a transcendental (no libm-vs-ocml ULP drift) -- as 2^24-scaled integers.
+// x87 (SLR_OPT_EVAL_MODEL = 1): the offsets are added the way the reference's MSVC2010 x87 / fp:precise binary adds them -- float +
+// float on the 53-bit stack, stored to the double P[count] WITHOUT an f32 rounding (and 3*PI/2 without rounding 3*PI first):
+// the sums are exact, still multiples of 2^-24 below 2^27, so the same integer table holds them.
+static bool build_decode_lut(int lut[kDecodeLutWords], bool x87)
+{
+    memset(lut, 0, sizeof(int) * kDecodeLutWords);
+    bool used[kDecodeLutWords] = {}, bad = false;
+    const float PI = kPI;
+    const float off[3][3] = {{PI, PI, PI},                  /* d < 0 : atan + PI             (:256-257) */
+                             {PI / 2, 0.0f, 3 * PI / 2},    /* d == 0: n<0 PI/2, n==0 undefined, n>0 3PI/2 (:250-255) */
+                             {0.0f, 0.0f, 2 * PI}};         /* d > 0 : n>0 atan + 2PI else atan (:258-261, :246-247) */
+    const double off87[3][3] = {{(double)PI, (double)PI, (double)PI},
+                                {(double)PI / 2.0, 0.0, 3.0 * (double)PI / 2.0},
+                                {0.0, 0.0, 2.0 * (double)PI}};
+    const int slot[3] = {2, 9, 6};
+    for (int d = -255; d <= 255; d++) {
+        const int sd = (d > 0) - (d < 0);
+        const unsigned R = d == 0 ? 0u : 65536u / (unsigned)(d < 0 ? -d : d) + 1u;
+        lut[d + 255] = (int)(R | (unsigned)slot[sd + 1] << 24);
+    }
+    for (int sd = -1; sd <= 1; sd++)
+        for (int sn = -1; sn <= 1; sn++)
+            for (int qa = 0; qa <= 255; qa++) {
+                if ((sd == 0 || sn == 0) && qa != 0) continue;
+                const int q = sd * sn * qa;                          /* the C quotient n / d */
+                const int sidx = sn < 0 && sd != 0 ? ~qa : qa;        /* (n * R) >> 16, arithmetic */
+                double scaled;
+                if (x87) {
+                    volatile float a = sd != 0 ? atanf((float)q) : 0.0f;      /* MSVC x86: (float)atan((double)q) -- the same 511 floats */
+                    scaled = ((double)a + off87[sd + 1][sn + 1]) * 16777216.0;
+                } else {
+                    volatile float P = atanf((float)q) + off[sd + 1][sn + 1];
+                    scaled = (double)P * 16777216.0;
+                }
+                const int w = 512 + ((slot[sd + 1] + sn) << 8) + sidx;
+                if (scaled != (double)(int)scaled || w < 512 || w >= kDecodeLutWords || used[w]) { bad = true; continue; }
+                lut[w] = (int)scaled;
+                used[w] = true;
+            }
+    return !bad;
+}
+
 int slr_create(int device_id, slr_ctx **out)
 {
     if (!out) return SLR_ERR_INVALID_ARG;
@@ -499,38 +549,8 @@ int slr_create(int device_id, slr_ctx **out)
         if (hipSetDevice(device_id) != hipSuccess) { st = SLR_ERR_NO_DEVICE; break; }
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { st = SLR_ERR_HIP; break; }
         c->own_stream = true;
-        // decode tables (kernels_decode.hip, wrapped_phase_q24): per difference d the 16-bit reciprocal of |d| with the
-        // table slot of sgn d in the top byte, and the wrapped phase itself -- atanf over the integer quotient (SURVEY
-        // Q1) plus the quadrant offset of mfreconstruct.cpp:246-261, evaluated by the host libm in the reference's f32
-        // arithmetic so the device never evaluates a transcendental (no libm-vs-ocml ULP drift) -- as 2^24-scaled integers
-        int lut[kDecodeLutWords] = {};
-        {
-            bool used[kDecodeLutWords] = {}, bad = false;
-            const float PI = kPI;
-            const float off[3][3] = {{PI, PI, PI},                  /* d < 0 : atan + PI             (:256-257) */
-                                     {PI / 2, 0.0f, 3 * PI / 2},    /* d == 0: n<0 PI/2, n==0 undefined, n>0 3PI/2 (:250-255) */
-                                     {0.0f, 0.0f, 2 * PI}};         /* d > 0 : n>0 atan + 2PI else atan (:258-261, :246-247) */
-            const int slot[3] = {2, 9, 6};
-            for (int d = -255; d <= 255; d++) {
-                const int sd = (d > 0) - (d < 0);
-                const unsigned R = d == 0 ? 0u : 65536u / (unsigned)(d < 0 ? -d : d) + 1u;
-                lut[d + 255] = (int)(R | (unsigned)slot[sd + 1] << 24);
-            }
-            for (int sd = -1; sd <= 1; sd++)
-                for (int sn = -1; sn <= 1; sn++)
-                    for (int qa = 0; qa <= 255; qa++) {
-                        if ((sd == 0 || sn == 0) && qa != 0) continue;
-                        const int q = sd * sn * qa;                          /* the C quotient n / d */
-                        const int sidx = sn < 0 && sd != 0 ? ~qa : qa;        /* (n * R) >> 16, arithmetic */
-                        volatile float P = atanf((float)q) + off[sd + 1][sn + 1];
-                        const double scaled = (double)P * 16777216.0;
-                        const int w = 512 + ((slot[sd + 1] + sn) << 8) + sidx;
-                        if (scaled != (double)(int)scaled || w < 512 || w >= kDecodeLutWords || used[w]) { bad = true; continue; }
-                        lut[w] = (int)scaled;
-                        used[w] = true;
-                    }
-            if (bad) { st = SLR_ERR_HIP; break; }       /* cannot happen: the table layout is checked here once per context */
-        }
+        int lut[kDecodeLutWords];
+        if (!build_decode_lut(lut, false)) { st = SLR_ERR_HIP; break; }   /* cannot happen: the table layout is checked once per context */
         if (hipMalloc((void **)&c->d_lut, sizeof(lut)) != hipSuccess) { st = SLR_ERR_OOM; break; }
         if (hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice) != hipSuccess) { st = SLR_ERR_HIP; break; }
         if (hipMalloc((void **)&c->d_sched, dma_sched_bytes()) != hipSuccess) { st = SLR_ERR_OOM; break; }
@@ -704,7 +724,10 @@ int slr_get_rectify_info(slr_ctx *c, int cam, slr_rectify_info *out)
     memset(out, 0, sizeof *out);
     out->W = c->map_w; out->H = c->map_h;
     const bool dma = dma_form_wanted(c, cam, cam);
-    out->mf_form = dma ? 7 : (c->opt_rect_algo != 0 && c->opt_rect_algo != 7 ? c->opt_rect_algo : mf_rect_algo(c, cam, cam));
+    // an explicit 7 that these maps do not allow (no tables, or too many tiles that no split makes fit) makes the decode calls
+    // fail with SLR_ERR_UNSUPPORTED: report that (-1), not the form auto would have fallen back to
+    out->mf_form = dma ? 7 : c->opt_rect_algo == 7 ? -1
+                 : (c->opt_rect_algo != 0 ? c->opt_rect_algo : mf_rect_algo(c, cam, cam));
     out->dma_shape = c->opt_dma_shape; out->dma_depth = c->opt_dma_depth;
     if (c->d_dma_tiles[cam] && c->dma_shape_built[cam] == c->opt_dma_shape) {
         const unsigned *st = c->dma_stats[cam];
@@ -836,6 +859,71 @@ int slr_mfn_decode(slr_ctx *c, const uint16_t *const *planes, int n_freq, int n_
       SLR_HIP(c, launch_mfn_decode(dp, n_freq, n_step, pitch, W, H, black_thr, (float *)dph, (uint8_t *)dv, c->stream)); }
     if (mem != SLR_MEM_DEVICE) {
         const size_t n = (size_t)W * H;
+        SLR_HIP(c, hipMemcpyAsync(phase, dph, n * 4, hipMemcpyDeviceToHost, c->stream));
+        SLR_HIP(c, hipMemcpyAsync(valid, dv, n, hipMemcpyDeviceToHost, c->stream));
+        SLR_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return SLR_OK;
+}
+
+int slr_rectify_source_rows(slr_ctx *c, int cam, int row0, int rows, int *src_row0, int *src_rows)
+{
+    if (!c || !src_row0 || !src_rows) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 (left) or 1 (right)");
+    if (!c->d_map_xy[cam]) return fail(c, SLR_ERR_NOT_CONFIGURED, "rectify maps not set (slr_set_rectify_maps)");
+    if (row0 < 0 || rows < 0 || row0 + rows > c->map_h) return fail(c, SLR_ERR_INVALID_ARG, "row band outside the image");
+    SLR_TRY(use_device(c));
+    *src_row0 = 0; *src_rows = 0;
+    if (rows == 0) return SLR_OK;
+    void *d;
+    SLR_TRY(get_scratch(c, S_STAGE0 + 3, 2 * sizeof(int), &d));
+    SLR_HIP(c, launch_map_source_rows(c->d_map_xy[cam], c->map_w, c->map_h, row0, rows, (int *)d, c->stream));
+    int r[2];
+    SLR_HIP(c, hipMemcpyAsync(r, d, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    if (r[0] > r[1]) return SLR_OK;                      // the band samples nothing
+    const int lo = r[0] < 0 ? 0 : r[0], hi = r[1] > c->map_h - 1 ? c->map_h - 1 : r[1];
+    *src_row0 = lo; *src_rows = hi - lo + 1;
+    return SLR_OK;
+}
+
+int slr_mfn_rectify_decode(slr_ctx *c, int cam, const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H,
+                           float black_thr, int row0, int rows, int src_row0, int src_rows, float *phase, uint8_t *valid, slr_mem mem)
+{
+    if (!c || !planes || !phase || !valid) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (cam < 0 || cam > 1) return fail(c, SLR_ERR_INVALID_ARG, "cam must be 0 (left) or 1 (right)");
+    if (n_freq < 2 || n_freq > SLR_MFN_MAX_FREQ || n_step < 3 || n_step > SLR_MFN_MAX_STEPS)
+        return fail(c, SLR_ERR_INVALID_ARG, "n_freq must be 2..6 and n_step 3..16");
+    const int np = 2 + n_freq * n_step;
+    for (int i = 0; i < np; i++) if (!planes[i]) return fail(c, SLR_ERR_INVALID_ARG, "null plane");
+    SLR_TRY(check_dims(c, W, H, pitch));
+    if (row0 < 0 || rows < 0 || row0 + rows > H) return fail(c, SLR_ERR_INVALID_ARG, "destination row band outside the image");
+    if (src_row0 < 0 || src_rows < 0 || src_row0 + src_rows > H) return fail(c, SLR_ERR_INVALID_ARG, "source row window outside the image");
+    if ((size_t)pitch * (size_t)(src_rows > 0 ? src_rows : 1) >= (1ull << 31)) return fail(c, SLR_ERR_UNSUPPORTED, "plane window beyond 2^31 elements");
+    SLR_TRY(use_device(c));
+    SLR_TRY(need_maps(c, cam, W, H));
+    if (rows == 0) return SLR_OK;
+    const uint16_t *dp[SLR_MFN_MAX_PLANES];
+    void *dph, *dv;
+    const size_t n = (size_t)W * rows;
+    if (mem == SLR_MEM_DEVICE) {
+        for (int i = 0; i < np; i++) dp[i] = planes[i];
+        dph = phase; dv = valid;
+    } else {                                             // one contiguous staging buffer for the window of every plane
+        const size_t plane = (size_t)pitch * (src_rows > 0 ? src_rows : 1) * 2;
+        void *d;
+        SLR_TRY(get_scratch(c, S_STAGE0, plane * np, &d));
+        for (int i = 0; i < np; i++) {
+            if (src_rows > 0) SLR_HIP(c, hipMemcpyAsync((uint8_t *)d + plane * i, planes[i], plane, hipMemcpyHostToDevice, c->stream));
+            dp[i] = (const uint16_t *)((uint8_t *)d + plane * i);
+        }
+        SLR_TRY(get_scratch(c, S_STAGE0 + 1, n * 4, &dph));
+        SLR_TRY(get_scratch(c, S_STAGE0 + 2, n, &dv));
+    }
+    { ProfScope ps(c, K_MFN_RECT_DECODE, true);
+      SLR_HIP(c, launch_mfn_rect_decode(dp, n_freq, n_step, pitch, W, H, black_thr, c->d_map_xy[cam], c->d_map_frac[cam], row0, rows,
+                                        src_row0, src_rows, (float *)dph, (uint8_t *)dv, c->stream)); }
+    if (mem != SLR_MEM_DEVICE) {
         SLR_HIP(c, hipMemcpyAsync(phase, dph, n * 4, hipMemcpyDeviceToHost, c->stream));
         SLR_HIP(c, hipMemcpyAsync(valid, dv, n, hipMemcpyDeviceToHost, c->stream));
         SLR_HIP(c, hipStreamSynchronize(c->stream));
@@ -1617,8 +1705,17 @@ int slr_reconstruct_batch(slr_ctx *c, const slr_batch_desc *d, const uint8_t *st
             const bool piped = d->n_frames > 1 && c->opt_batch_streams > 1;
             const int odd = piped ? f & 1 : 0;
             if (piped && !c->pipe) {
-                SLR_HIP(c, hipStreamCreateWithFlags(&c->pipe, hipStreamNonBlocking));
-                for (int k = 0; k < 2; k++) SLR_HIP(c, hipEventCreateWithFlags(&c->ev_pipe[k], hipEventDisableTiming));
+                // all three or none: a context with a second stream but a null event would be broken for every later batch
+                hipStream_t ps = nullptr;
+                hipEvent_t pe[2] = {nullptr, nullptr};
+                hipError_t pe_err = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking);
+                for (int k = 0; k < 2 && pe_err == hipSuccess; k++) pe_err = hipEventCreateWithFlags(&pe[k], hipEventDisableTiming);
+                if (pe_err != hipSuccess) {
+                    for (int k = 0; k < 2; k++) if (pe[k]) (void)hipEventDestroy(pe[k]);
+                    if (ps) (void)hipStreamDestroy(ps);
+                    SLR_HIP(c, pe_err);
+                }
+                c->pipe = ps; c->ev_pipe[0] = pe[0]; c->ev_pipe[1] = pe[1];
             }
             if (f == 0 && piped) c->mid_event = c->ev_pipe[0];
             if (f == 1 && piped) SLR_HIP(c, hipStreamWaitEvent(c->pipe, c->ev_pipe[0], 0));
@@ -1686,6 +1783,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.gray_small_tiles = (value & 16) != 0;
             if (c->debug.no_quad_sort != ((value & 32) != 0)) {      // the map digests of the LDS-DMA forms are built either way
                 c->debug.no_quad_sort = (value & 32) != 0;
+                SLR_TRY(use_device(c));                              // (the rebuild launches kernels: on the context's device)
                 for (int cam = 0; cam < 2; cam++)
                     if (c->d_map_xy[cam] && c->d_dma_tiles[cam]) SLR_TRY(build_dma_tiles(c, cam));
                 SLR_HIP(c, hipStreamSynchronize(c->stream));
@@ -1708,6 +1806,19 @@ int slr_set_option(slr_ctx *c, int option, int value)
             if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_POISON_SCRATCH must be 0 or 1");
             c->debug.poison_scratch = value != 0;
             return SLR_OK;
+        case SLR_OPT_EVAL_MODEL: {
+            if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_EVAL_MODEL must be 0 (strict IEEE) or 1 (x87)");
+            if ((value != 0) != c->debug.eval_x87) {
+                int lut[kDecodeLutWords];
+                if (!build_decode_lut(lut, value != 0)) return fail(c, SLR_ERR_HIP, "decode table layout");
+                SLR_TRY(use_device(c));
+                SLR_HIP(c, hipStreamSynchronize(c->stream));         // no launch may still be reading the old tables
+                SLR_HIP(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+                c->debug.eval_x87 = value != 0;
+                c->cal.eval_x87 = value;
+            }
+            return SLR_OK;
+        }
         case SLR_OPT_HYBRID_ONE_PASS:
             if (value < 0 || value > 1) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_HYBRID_ONE_PASS must be 0 or 1");
             c->opt_hybrid_one_pass = value;

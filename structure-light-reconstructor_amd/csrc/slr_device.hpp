@@ -42,12 +42,13 @@ struct DevCalib {
     float T[12];
     int has_T;
     int q_simple;                      // Q has cv::stereoRectify's zero/one pattern (kernels_match.hip reproject)
+    int eval_x87;                      // SLR_OPT_EVAL_MODEL = 1: match predicate and disparity as the reference's x87 binary forms them
 };
 
 // kernel ids for the built-in HIP-event profiler (bench.py reads these)
 enum KernelId {
     K_REMAP = 0, K_MF_DECODE, K_MF_RECT_DECODE, K_GRAY_DECODE, K_GRAY_RECT_DECODE,
-    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_GRAY_RECT_DECODE_PAIR, K_HYBRID_RECT_DECODE_PAIR, K_COUNT
+    K_MF_MATCH, K_GE_MATCH, K_RAY_COUNT, K_RAY_SCAN, K_RAY_SCATTER, K_RAY_TRI, K_PC_FROM_GRID, K_PC_GET, K_UNDISTORT_TABLE, K_RAY_TABLE, K_MF_RECT_DECODE_PAIR, K_MFN_DECODE, K_GRAY_RECT_DECODE_PAIR, K_HYBRID_RECT_DECODE_PAIR, K_MFN_RECT_DECODE, K_COUNT
 };
 
 // Every kernel launch goes through SLR_LAUNCH.  When the C-ABI layer's profiler has armed a pair of events for the
@@ -70,6 +71,7 @@ struct DebugKnobs {
     bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
     int k4_stop = 0;
     bool poison_scratch = false; // SLR_OPT_DEBUG_POISON_SCRATCH
+    bool eval_x87 = false;       // SLR_OPT_EVAL_MODEL = 1 (not a debug knob, but it travels the same way: per call, per thread)
 };
 extern thread_local DebugKnobs tl_debug;
 #define SLR_LAUNCH(kernel, grid, block, lds, stream, ...)                                                            \
@@ -175,6 +177,10 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
 // build extension: generalised n_freq x n_step fp16 multi-frequency decode (kernels_mfn.hip)
 hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                              float *phase, uint8_t *valid, hipStream_t s);
+hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
+                                  const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
+                                  float *phase, uint8_t *valid, hipStream_t s);
+hipError_t launch_map_source_rows(const int16_t *map_xy, int W, int H, int row0, int rows, int *d_out, hipStream_t s);
 
 // GRAY_ONLY: counting sort of camera pixels by projector cell (both cameras share one histogram / offsets
 // array: left cells [0,nb), right cells [nb,2nb), +1 pad), then one thread per cell

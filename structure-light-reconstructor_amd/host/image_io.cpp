@@ -132,7 +132,8 @@ struct Inflater {
 };
 
 // `rows` scanlines of a (sub-)image pw pixels wide, filtered, at `raw`: undo the filters in place (`prev` = the line above,
-// unfiltered, or null on the first line) and grey-convert into dst at (x0 + i*dx, y + j*dy).  Returns the last line.
+// unfiltered, or null on the first line) and grey-convert into dst at (x0 + i*dx, y + j*dy).  Returns the last line, or null when
+// a scanline names a filter type the format does not have.
 const uint8_t *png_rows(uint8_t *raw, const PngInfo &f, int pw, int rows, const uint8_t *prev, uint8_t *dst, int x0, int y, int dx, int dy)
 {
     const int bps = f.depth / 8, bpp = f.channels * bps;
@@ -159,7 +160,8 @@ const uint8_t *png_rows(uint8_t *raw, const PngInfo &f, int pw, int rows, const 
             if (prev) for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - bpp], prev[i], prev[i - bpp]));
             else for (size_t i = bpp; i < stride; i++) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - bpp], 0, 0));
             break;
-        default: break;                                      // 0, and (as before) anything a corrupt file puts there
+        case 0: break;
+        default: return nullptr;                             // filter types are 0 .. 4 (PNG spec 9.2): a corrupt or hostile file
         }
         uint8_t *out = dst + (size_t)(y + j * dy) * f.w + x0;
         if (bpp == 1 && dx == 1) memcpy(out, cur, (size_t)pw);
@@ -200,6 +202,7 @@ bool decode_png_into(const uint8_t *buf, size_t size, int want_w, int want_h, ui
             const int rows = ph - j < band_rows ? ph - j : band_rows;
             if (inf.read(band.data(), pline * rows) != pline * rows) { err = bad; return false; }
             const uint8_t *last = png_rows(band.data(), f, pw, rows, prev, dst, x0, y0 + j * dy, dx, dy);
+            if (!last) { err = "invalid PNG filter type"; return false; }
             memcpy(above.data(), last, pline - 1);           // the band buffer is about to be overwritten
             prev = above.data();
         }

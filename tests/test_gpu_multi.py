@@ -224,6 +224,9 @@ def test_bench_two_ranks_with_a_collective_on_this_box():
             assert d["config"]["frames_per_gpu_per_step"] == 2 and "all-gather" in d["config"]["parallelism"]
             assert d["collective_backend"] == backend and d["collective_ranks"] == 2, d.get("collective")
             assert len(d["collective"]["devices"]) == 2 and d["collective"]["distinct_devices"] == 1   # both ranks on the one GPU
+            # the exchange proves itself: every rank compared all 4 frames of its assembled cloud with their owners' checksums
+            assert d["gather_proof"]["all_ranks_ok"] and d["gather_proof"]["frames_verified_on_every_rank"] == 4, d["gather_proof"]
+            assert d["gather_inclusive_value"] is not None
             print("collective leg ran over %s (RCCL refused: %r)" % (backend, refused))
             return
         if backend == "nccl":

@@ -166,6 +166,10 @@ def test_png_decoder_rejects_what_it_cannot_trust(host, tmp_path):
     open(tmp_path / "trail.png", "wb").write(trailing)                                               # bytes behind the zlib stream
     rc, out = read(tmp_path / "trail.png", img.shape)
     assert rc == 1 and np.array_equal(out, img)
+    rawf = bytearray(raw); rawf[5 * 35] = 5                                                         # a scanline with filter type 5
+    badf = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 34, 21, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(rawf))) + chunk(b"IEND", b"")
+    open(tmp_path / "filter5.png", "wb").write(badf)                                                 # valid CRCs and sizes, invalid content
+    assert read(tmp_path / "filter5.png", img.shape)[0] == 0
     # 16-bit grey keeps the high byte; RGB goes through OpenCV's fixed-point grey conversion
     g16 = rng.integers(0, 65536, size=(7, 11)).astype(">u2")
     raw16 = b"".join(b"\0" + g16[y].tobytes() for y in range(7))

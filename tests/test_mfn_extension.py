@@ -117,3 +117,127 @@ def test_gpu_row_bands_equal_the_whole_frame(ctx, oracle, synth, slr, algo):
     exyz, ehas, emk = oracle.mf_triangulate(full[0][0].cpu().numpy(), full[0][1].cpu().numpy(), full[1][0].cpu().numpy(),
                                             full[1][1].cpu().numpy(), camL, camR, Q, T)
     assert bits_equal(fk.cpu().numpy(), emk) and bits_equal(fx.cpu().numpy(), exyz)
+
+
+# ---- through the rectification (slr_mfn_rectify_decode): BASELINE config 5 on the north_star path ------------------------------
+def _close_to_model(ph, v, exp, ev):
+    """the comparison of test_gpu_mfn_decode_vs_f64_model, with the valid flags allowed to differ where the f32 and f64 modulation /
+    shadow tests sit on their thresholds (counted)"""
+    d = np.abs(ph.astype(np.float64) - exp)
+    tol = 2e-3 + 1e-4 * np.abs(exp)
+    bad = d > tol
+    flips = bad & (_circ(ph, exp) <= tol)
+    vdiff = v != ev
+    assert (bad & ~flips & ~vdiff).sum() == 0, float(d[bad & ~flips & ~vdiff].max())
+    assert flips.sum() <= 1e-3 * ph.size and vdiff.sum() <= 1e-4 * ph.size + 1, (int(flips.sum()), int(vdiff.sum()))
+
+
+def test_f64_rect_model_is_remap_then_decode(oracle, synth):
+    """the rectified model == the unrectified model on planes remapped in f64 (identity maps: the input itself; half-pixel maps:
+    the mean of two neighbours; out-of-image taps: 0)"""
+    W, H, F, N = 64, 20, 3, 4
+    st = synth.render_mfn_stack(W, H, F, N, noise=0.0)[0].numpy()
+    mx, mf = synth.identity_maps(W, H)
+    p0, v0 = oracle.mfn_decode_f64(st, F, N, 40.0)
+    p1, v1 = oracle.mfn_rect_decode_f64(st, F, N, 40.0, mx.numpy(), mf.numpy())
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+    mx, mf = synth.identity_maps(W, H, fx=16)                          # half a pixel to the right
+    p2, v2 = oracle.mfn_rect_decode_f64(st, F, N, 40.0, mx.numpy(), mf.numpy())
+    sh = st.astype(np.float64)
+    half = np.zeros_like(sh)
+    half[:, :, :-1] = 0.5 * (sh[:, :, :-1] + sh[:, :, 1:])
+    half[:, :, -1] = 0.5 * sh[:, :, -1]                                # the right neighbour is outside: BORDER_CONSTANT 0
+    # (not representable as float16 planes, so decode by hand with the same formulas on one row)
+    row = 7
+    for col in (0, 5, W - 1):
+        I = half[:, row, col]
+        mask = I[0] - I[1] > 40.0
+        assert bool(v2[row, col]) <= bool(mask)
+        if mask:
+            D = []
+            for f in range(F):
+                k = np.arange(N)
+                S, Cc = (I[2 + f * N:2 + (f + 1) * N] * np.sin(2 * np.pi * k / N)).sum(), (I[2 + f * N:2 + (f + 1) * N] * np.cos(2 * np.pi * k / N)).sum()
+                p = np.arctan2(-S, Cc)
+                D.append(p + 2 * np.pi if p < 0 else p)
+            for lvl in range(1, F):
+                for i in range(F - lvl):
+                    D[i] = D[i] - D[i + 1] if D[i] > D[i + 1] else D[i] - D[i + 1] + 2 * np.pi
+            assert abs(p2[row, col] - D[0] / (2 * np.pi) * 255) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,F,N", [(256, 64, 4, 8), (132, 33, 3, 5), (64, 16, 6, 16), (131, 20, 2, 3)])
+def test_gpu_mfn_rectify_decode_vs_f64_model(ctx, oracle, synth, W, H, F, N):
+    st = synth.render_mfn_stack(W, H, F, N, noise=0.5, seed=W + 1)
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=3.0)      # strong enough that taps leave the image at the borders
+        ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
+        exp, ev = oracle.mfn_rect_decode_f64(st[cam].numpy(), F, N, 40.0, mx.numpy(), mf.numpy())
+        for planes in (st[cam].numpy(), st[cam].cuda()):                # host and device entry
+            ph, v = ctx.mfn_rectify_decode(cam, planes, F, N, 40.0)
+            ctx.synchronize()
+            ph = ph.cpu().numpy() if hasattr(ph, "cpu") else ph
+            v = v.cpu().numpy() if hasattr(v, "cpu") else v
+            _close_to_model(ph, v, exp, ev)
+            assert (v != 0).sum() > 0.3 * v.size
+    # identity maps: the rectifying decode IS the plain decode (w00 = 1024: the sample is the tap, exactly)
+    mx, mf = synth.identity_maps(W, H)
+    ctx.set_rectify_maps(0, mx.numpy(), mf.numpy())
+    a = ctx.mfn_rectify_decode(0, st[0].cuda(), F, N, 40.0)
+    b = ctx.mfn_decode(st[0].cuda(), F, N, 40.0)
+    ctx.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+def test_gpu_mfn_rectified_row_bands_with_source_windows(ctx, oracle, synth):
+    """config 5's 8-GPU split: every band decodes its destination rows from ONLY the source rows slr_rectify_source_rows names
+    (a copy of that window, nothing else of the frame on the 'device'), then matches them with absolute rows; the bands
+    concatenated == the whole frame, bit for bit -- decode and XYZ"""
+    W, H, F, N = 384, 61, 4, 8
+    np_ = 2 + F * N
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    ctx.set_calibration(calib)
+    maps = [synth.make_rectify_maps(W, H, cam, strength=4.0) for cam in range(2)]
+    for cam in range(2):
+        ctx.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    st = synth.render_mfn_stack(W, H, F, N, noise=0.25, seed=11).cuda()
+    full = [ctx.mfn_rectify_decode(cam, st[cam], F, N, 40.0) for cam in range(2)]
+    fx, fh, fk = ctx.mf_triangulate(full[0][0], full[0][1], full[1][0], full[1][1])
+    ctx.synchronize()
+    world = 8
+    band = (H + world - 1) // world
+    parts, windows = [], []
+    for r in range(world):
+        r0, r1 = min(H, r * band), min(H, (r + 1) * band)
+        if r1 <= r0:
+            continue
+        dec = []
+        for cam in range(2):
+            s0, sn = ctx.rectify_source_rows(cam, r0, r1 - r0)
+            windows.append((r0, r1, s0, sn))
+            assert 0 <= s0 and s0 + sn <= H and sn >= 1
+            window = [st[cam, p, s0:s0 + sn].clone() for p in range(np_)]     # what this GPU would hold of the frame
+            dec.append(ctx.mfn_rectify_decode(cam, window, F, N, 40.0, W=W, H=H, row0=r0, rows=r1 - r0, src_row0=s0))
+        parts.append((r0, r1, dec, ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], row0=r0, image_h=H)))
+    ctx.synchronize()
+    for cam in range(2):
+        assert torch.equal(torch.cat([p[2][cam][0] for p in parts]), full[cam][0])
+        assert torch.equal(torch.cat([p[2][cam][1] for p in parts]), full[cam][1])
+    assert torch.equal(torch.cat([p[3][0] for p in parts]), fx) and torch.equal(torch.cat([p[3][1] for p in parts]), fh)
+    assert torch.equal(torch.cat([p[3][2] for p in parts]), fk)
+    assert any(sn < H for (_, _, _, sn) in windows) and fh.float().mean().item() > 0.2
+    # the windows are the oracle-side min / max of the maps over the band
+    for (r0, r1, s0, sn), cam in zip(windows[:2], (0, 1)):
+        sy = maps[cam][0].numpy()[r0:r1, :, 1].astype(np.int64)
+        sx = maps[cam][0].numpy()[r0:r1, :, 0].astype(np.int64)
+        touch = ~((sx >= W) | (sx + 1 < 0) | (sy >= H) | (sy + 1 < 0))
+        assert s0 == max(0, sy[touch].min()) and s0 + sn - 1 == min(H - 1, sy[touch].max() + 1)
+    # a window one row short of what the band needs must change the result (the proof that the window is really used)
+    r0, r1, s0, sn = windows[2]
+    cam = 0
+    short = [st[cam, p, s0 + 1:s0 + sn].clone() for p in range(np_)]
+    d2 = ctx.mfn_rectify_decode(cam, short, F, N, 40.0, W=W, H=H, row0=r0, rows=r1 - r0, src_row0=s0 + 1)
+    ctx.synchronize()
+    assert not torch.equal(d2[0], full[cam][0][r0:r1])
