@@ -63,6 +63,8 @@ ALG_BYTES = {
     "slr_hybrid_rectify_decode_pair": 100.0,
     # GRAY_ONLY, per st-px of the CAMERA image (the projector's 1280x1024 cells add 29 B each = 3 B per camera pixel here)
     "slr_ray_triangulate": 35.0,       # 2 x (4 item + 12 ray) read + per cell 16 offsets read + 13 sum/count write
+    # BASELINE config 5 through the rectification, per cam-px: 34 fp16 planes + 6 map bytes read, 4 phase + 1 valid written
+    "slr_mfn_rectify_decode": 79.0,
     "slr_ray_count": 34.0,             # both cameras: 2 x (4 + 4 code + 1 valid read, 4 cell + 4 rank write); inside
                                        # slr_reconstruct_gray it is part of the decode kernel since round 3 (no such launch)
 }
@@ -80,6 +82,7 @@ DEVICE_KERNEL = {
     "slr_ge_match_triangulate": ("ge_match_lean_kernel", "ge_match_kernel"),
     "slr_ray_triangulate": ("ray_triangulate_small_kernel", "ray_triangulate_staged_kernel"),
     "slr_ray_count": ("ray_count_kernel",),
+    "slr_mfn_rectify_decode": ("mfn_rect_decode_kernel",),
 }
 
 
@@ -88,10 +91,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["mf", "ge", "gray", "hybrid"], default="mf",
+    ap.add_argument("--mode", choices=["mf", "ge", "gray", "hybrid", "mfn"], default="mf",
                     help="mf: the metric's 3-freq x 4-step path (default); ge: GRAY_EPI (Gray columns + rectification); gray: GRAY_ONLY "
                          "(Gray columns + rows, ray-ray triangulation, 1280x1024 projector); hybrid: BASELINE config 3 -- Gray columns + "
-                         "3-freq x 4-step fringes in one stack (38 planes per camera), decoded in ONE pass, then phase match + triangulation")
+                         "3-freq x 4-step fringes in one stack (38 planes per camera), decoded in ONE pass, then phase match + triangulation; "
+                         "mfn: BASELINE config 5 -- one 8192x6000 stereo frame, 4 frequencies x 8 steps of fp16 planes, f32 accumulation, "
+                         "rectified (a build extension: the reference is hard-wired to 3 x 4 steps of u8); N > 1 shards ROW BANDS")
     ap.add_argument("--frames", type=int, default=0, help="distinct HBM-resident stereo frames per GPU per step (0 = 8; hybrid: 4)")
     ap.add_argument("--traffic", choices=["auto", "live", "file", "off"], default="auto",
                     help="roofline.traffic: live = two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of a 3-step child run, "
@@ -362,6 +367,151 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
     return out
 
 
+def main_mfn(args):
+    """BASELINE config 5: one 8192x6000 stereo frame per step unit, 4 x 8 fp16 planes per camera (6.7 GB per frame), raw camera
+    images through the rectification (slr_mfn_rectify_decode), then the match + triangulation of the 8192-pixel rows (chunked K4).
+    N > 1: the FRAME is split into N row bands: every rank holds only the source rows its bands' maps point into
+    (slr_rectify_source_rows), decodes and matches its band, and one all-gather assembles the cloud -- total work is fixed
+    ("scaling": "strong")."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("SLR_BENCH_ONE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        backend = os.environ.get("SLR_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, device_id=dev) if backend == "nccl" else dist.init_process_group(backend)
+    slr = importlib.import_module("structure-light-reconstructor_amd")
+    synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+    sdist = importlib.import_module("structure-light-reconstructor_amd.dist")
+    W, H = (8192, 6000) if (args.width, args.height) == (4096, 3000) else (args.width, args.height)
+    F = args.frames if args.frames > 0 else 1
+    NF, NS = 4, 8
+    NP = 2 + NF * NS
+    ctx = slr.Context(local)
+    rig = synth.make_verged_rig(W, H, 0.2, -0.15)
+    ctx.set_calibration(rig["calib"])
+    synth.install_verged_maps(ctx, rig, W, H)
+    r0, r1 = sdist.shard_rows(H, rank, world)
+    rows = r1 - r0
+    win = [ctx.rectify_source_rows(cam, r0, rows) for cam in range(2)]           # (src_row0, src_rows) per camera
+    # this rank's share of the frames: ONLY the source rows of its band (rendered whole, the window kept)
+    stacks = []
+    for f in range(F):
+        full = synth.render_mfn_stack(W, H, NF, NS, seed=1234 + f, noise=0.5, device=dev)
+        stacks.append([full[cam, :, win[cam][0]:win[cam][0] + win[cam][1]].contiguous() for cam in range(2)])
+        del full
+    torch.cuda.synchronize()
+    band = (H + world - 1) // world
+    g_xyz = torch.zeros((F, world * band, W, 3), dtype=torch.float32, device=dev)
+    g_has = torch.zeros((F, world * band, W), dtype=torch.uint8, device=dev)
+    ph = [torch.empty((max(rows, 1), W), dtype=torch.float32, device=dev) for _ in range(2)]
+    vd = [torch.empty((max(rows, 1), W), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def step(i):
+        for f in range(F):
+            if rows <= 0:
+                continue
+            for cam in range(2):
+                ctx.mfn_rectify_decode(cam, stacks[f][cam], NF, NS, float(BLACK_THR), W=W, H=H, row0=r0, rows=rows,
+                                       src_row0=win[cam][0], phase=ph[cam][:rows], valid=vd[cam][:rows])
+            x, h, _ = ctx.mf_triangulate(ph[0][:rows], vd[0][:rows], ph[1][:rows], vd[1][:rows], want_match=False, row0=r0, image_h=H)
+            if world > 1:                                   # (the band's place in the assembled frame; K4 has no output-view entry)
+                with torch.cuda.stream(ctx.stream):
+                    g_xyz[f, rank * band:rank * band + rows].copy_(x, non_blocking=True)
+                    g_has[f, rank * band:rank * band + rows].copy_(h, non_blocking=True)
+
+    def sync_all():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    ctx.set_option(slr.capi.OPT_PROFILE_STRIDE, 1)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile()
+    ctx.profile_enable(False)
+    gather_ms, proof = None, None
+    if world > 1:                                           # the bands of every frame -> the whole cloud on every rank
+        tg = time.perf_counter()
+        for f in range(F):
+            loc_x, loc_h = g_xyz[f, rank * band:(rank + 1) * band], g_has[f, rank * band:(rank + 1) * band]
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(g_xyz[f], loc_x)
+                dist.all_gather_into_tensor(g_has[f], loc_h)
+            else:
+                cx, ch = torch.empty(g_xyz[f].shape), torch.empty(g_has[f].shape, dtype=torch.uint8)
+                dist.all_gather_into_tensor(cx, loc_x.cpu()); dist.all_gather_into_tensor(ch, loc_h.cpu())
+                g_xyz[f].copy_(cx); g_has[f].copy_(ch)
+        sync_all()
+        tt = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        gather_ms = float(tt.item()) * 1e3
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # every rank's assembled frames must carry the same checksums (each band was computed by exactly one rank)
+        words = sdist.frame_checksums(g_xyz, g_has)
+        if dist.get_backend() != "nccl":
+            words = words.cpu()
+        allw = [torch.empty_like(words) for _ in range(world)]
+        dist.all_gather(allw, words)
+        proof = {"frames": F, "all_ranks_agree": bool(all(torch.equal(w, words) for w in allw))}
+        if not proof["all_ranks_agree"]:
+            raise SystemExit("bench.py --mode mfn: the ranks' assembled clouds differ")
+    npix = float(W) * H
+    value = npix * F * args.steps / elapsed / 1e6
+    kernels = []
+    for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        ent = {"name": name, "launches": n, "avg_us": round(ms / n * 1e3, 2), "total_ms": round(ms, 3)}
+        if name in ALG_BYTES:
+            per_launch = ALG_BYTES[name] * W * rows                 # per launch = one camera's band
+            gbs = per_launch / (ms / n * 1e-3) / 1e9
+            ent.update({"alg_bytes_per_px": ALG_BYTES[name], "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        kernels.append(ent)
+    k0 = kernels[0] if kernels else None
+    roofline = None
+    if k0 and k0.get("achieved_GBs"):
+        roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": k0["frac_hbm_peak"], "traffic": None, "avg_launch_us": k0["avg_us"],
+                    "alg_bytes_per_launch": ALG_BYTES[k0["name"]] * W * rows,
+                    "form": "per-pixel gather (L1 / L2 serve the taps); the LDS-tiled form of the u8 path is not built for fp16"}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mpixels/s decode+unwrap+triangulate, 4096x3000 stereo, 1/2/4/8 GPU", "value": round(value, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp16 in, f32 accumulate / phase / XYZ (f64 undistort + Q reprojection)", "data": "synthetic",
+            "ms_per_frame": round(elapsed / args.steps / F * 1e3, 4),
+            "config": {"workload": "BASELINE config 5 (NOT the headline config): %dx%d stereo, 4 frequencies x 8 steps of fp16 planes (34 per "
+                                   "camera), rectify+decode+unwrap (build extension, no reference counterpart) + match+triangulate; a step "
+                                   "= %d frame(s), each split into %d row band(s)" % (W, H, F, world),
+                       "maps": "verged stereo head, 0.2 rad, k1 -0.15 (stereoRectify + slr_init_rectify_maps)", "mode": "mfn",
+                       "rows_of_this_rank": [r0, r1], "source_rows_held": [list(w) for w in win],
+                       "parallelism": "one frame's rows split over %d GPU(s): row bands with read-only source windows, one all-gather" % world},
+            "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3), "gather_proof": proof,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 _T0 = time.perf_counter()
 
 
@@ -373,6 +523,8 @@ def _trace(what):
 
 def main():
     args = parse_args()
+    if args.mode == "mfn":
+        return main_mfn(args)
     import numpy as np
     import torch
     import torch.distributed as dist

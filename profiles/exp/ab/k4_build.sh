@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../.."
 C=structure-light-reconstructor_amd/csrc
 mkdir -p profiles/exp/ab/so
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Wno-unused-function"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -DSLR_EXPERIMENTS -Wno-unused-function"
 while [ $# -ge 2 ]; do
   n=$1; d=$2; shift 2
   /opt/rocm/bin/hipcc $FL $d -c $C/kernels_match.hip -o /tmp/k4_$n.o

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../../.."
 C=structure-light-reconstructor_amd/csrc
 F=$1; shift
 mkdir -p profiles/exp/ab/so
-FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -Wno-unused-function -Wno-inline-asm"
+FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Iinclude -DSLR_EXPERIMENTS -Wno-unused-function -Wno-inline-asm"
 while [ $# -ge 2 ]; do
   n=$1; d=$2; shift 2
   /opt/rocm/bin/hipcc $FL $d -c $C/$F -o /tmp/var_$n.o 2>/dev/null

@@ -18,6 +18,9 @@
 
 // stage ablation of the match kernels (profiles/k4_stages.sh): "leave after stage N, outputs are not written".  Only builds with
 // -DSLR_DEBUG_HOOKS contain the exits; the production kernels carry none of them.
+#if !defined(SLR_EXPERIMENTS) && (defined(SLR_K4_ABL) || defined(SLR_DEBUG_HOOKS))
+#error "SLR_K4_ABL / SLR_DEBUG_HOOKS are experiment switches: build with -DSLR_EXPERIMENTS"
+#endif
 #if defined(SLR_DEBUG_HOOKS)
 #define SLR_K4_STOP_AT(n) do { if (stop == (n)) return; } while (0)
 #define SLR_K4_STOP_AT5(best0) do { if (stop == 5) { if ((best0) == 12345678) has[0] = 1; return; } } while (0)

@@ -23,6 +23,16 @@
 
 #include <stdlib.h>
 
+// Experiment switches.  The ablations and probes the measurements of DESIGN.md / LABNOTES.md were taken with -- SLR_DMA_ABL (1 no
+// source traffic, 2 no LDS tap reads, 3 no barriers, 4 neither reads nor blend, 5 reads without blend, 6 = 1 + 2), SLR_DMA_FORCE_MODE
+// (one read mode for every wave: wrong results, timing only) and SLR_DMA_CLOCKPROBE (per-workgroup timeline) -- compile only with
+// -DSLR_EXPERIMENTS (profiles/exp/ab/var_build.sh passes it); a production build that names one of them is an error, and every
+// other former switch (static priorities, computed weights, flush-now / safe Gray forms, the tunable pair counts) is gone: the
+// results are in LABNOTES.md.
+#if !defined(SLR_EXPERIMENTS) && (defined(SLR_DMA_ABL) || defined(SLR_DMA_FORCE_MODE) || defined(SLR_DMA_CLOCKPROBE))
+#error "SLR_DMA_ABL / SLR_DMA_FORCE_MODE / SLR_DMA_CLOCKPROBE are experiment switches: build with -DSLR_EXPERIMENTS"
+#endif
+
 namespace slr {
 
 constexpr unsigned kDmaInvalid = 0x80000000u;    // buffer offset beyond every descriptor's range: loads 0, stores nothing
@@ -576,9 +586,7 @@ __device__ __forceinline__ int dma_tap_setup(const uint8_t *smem, unsigned lds0,
         else { w0 = wt[WT_OFF / 4]; w1 = wt[WT1_OFF / 4]; }
         if (mode == 1) {                                     // weights of rows 0, 1, 2 of the quad (the pixel's own rows: st, st + 1)
             const bool st = ((e[q] >> 1) & 1u) != 0;
-#if !defined(SLR_DMA_NO_SECOND)
             if (__ballot(st) != 0ull) second |= 1u << q;     // (wave-uniform: does ANY lane's pixel q reach into row 2?)
-#endif
             tap[q].w0 = __builtin_bit_cast(u16x2, st ? 0u : w0);
             tap[q].w1 = __builtin_bit_cast(u16x2, st ? w0 : w1);
             tap[q].a0 = st ? w1 : 0u;
@@ -820,12 +828,8 @@ struct DmaDecode {
     // waits concern its own DMAs only, the barrier behind them covers everybody else's -- so there is no scratch slot for dummy
     // transfers: with it the triple buffer of DMA depth 2 plus the 8 KB weight tables would miss three workgroups per CU by 1 KB.
     static constexpr int DIG_OFF = D * 2 * PS, DIG_BYTES = TW * TH * 4;
-#if defined(SLR_DMA_NOWT)            // experiment: blend weights computed per tile instead of tabulated (8 KB of LDS back)
-    static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF, WT_BYTES = 0, TAP_WT = -1;
-#else
     static constexpr int WT_OFF = DIG_OFF + DIG_BYTES, WT1_OFF = WT_OFF + 1026 * 4, WT_BYTES = 2 * 1026 * 4;   // two tables: w0[1025], w1[1025]
     static constexpr int TAP_WT = WT_OFF;
-#endif
     static constexpr int LUT_OFF = WT_OFF + WT_BYTES;
     static constexpr int TKT_OFF = LUT_OFF + (kLutWords + 1) * 4;        // the next tile's ticket (wave 0 -> everybody)
     static constexpr int LDS_BYTES = TKT_OFF + 12;
@@ -1094,12 +1098,6 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
     }
 
     d.wave_off = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 1024u);
-#if defined(SLR_DMA_STATIC_PRIO)
-    {   // static priorities: 1 = by wave, 2 = by workgroup
-        const unsigned w = __builtin_amdgcn_readfirstlane(SLR_DMA_STATIC_PRIO == 1 ? (threadIdx.x >> 6) & 3u : (blockIdx.x >> 3) & 3u);
-        if (w == 0) __builtin_amdgcn_s_setprio(0); else if (w == 1) __builtin_amdgcn_s_setprio(1); else if (w == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
-    }
-#endif
     {
         const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         constexpr unsigned wpp = (unsigned)Gm::NCH / 64u;    // waves per plane image
@@ -1311,10 +1309,7 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
     return hipGetLastError();
 }
 
-#ifndef SLR_DMA_A2
-#define SLR_DMA_A2 2            // DMA issue distance of SLR_OPT_RECT_DMA_DEPTH = 2 (experiments: 3 with -DSLR_DMA_NOWT)
-#endif
-#define SLR_DMA_DEPTH2(TW, TH, NT) ((TW) == 128 && (TH) == 16 && (NT) == 512 ? SLR_DMA_A2 : 2)   // (only the default shape has the LDS for more)
+#define SLR_DMA_DEPTH2(TW, TH, NT) 2   // DMA issue distance of SLR_OPT_RECT_DMA_DEPTH = 2 (3 was measured with computed weights: slower, LABNOTES.md)
 // one camera (n == 1) or both cameras of a stereo frame (n == 2) in one launch.  *done = false: this form does not apply
 // (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
@@ -1384,12 +1379,8 @@ struct GrayDmaJob {
 };
 struct GrayDmaJobs { GrayDmaJob j[2]; };
 
-#ifndef SLR_GRAY_DMA_WAVES1
-#define SLR_GRAY_DMA_WAVES1 6
-#endif
-#ifndef SLR_GRAY_DMA_NPP
-#define SLR_GRAY_DMA_NPP 2
-#endif
+constexpr int kGrayDmaWaves1 = 6;     // waves per SIMD the one-pair-per-phase Gray form is compiled for
+constexpr int kGrayDmaNpp = 2;        // plane pairs per phase of the fused Gray decode (1 and 2 measured equal)
 // HYB (BASELINE config 3, "Gray-code + phase hybrid decode"): the stack carries the 12 fringe planes of the multi-frequency
 // method behind the Gray pairs -- white, black, 2 * bits Gray planes, 3 x 4 fringes -- and the tile goes through six more plane
 // pairs, (G1, G3) and (G2, G4) of each frequency, decoded exactly as the multi-frequency kernel above decodes them (same tables,
@@ -1553,22 +1544,14 @@ struct GrayDma {
             out_ok |= (ok ? 1u : 0u) << q;
         }
         if constexpr (!HYB) { out_ty = ty; out_tx = tx; out_pending = true; }
-#if defined(SLR_GRAY_DMA_FLUSH_NOW)
-        if constexpr (!HYB) { flush(); out_pending = false; }
-#endif
     }
     // phase k of a tile in buffer B: plane pairs 2k and 2k + 1 (pair 0 = white, black; pair j = code bit j - 1).  FIRST: k == 0.
     // A pair's sample difference is consumed as soon as it exists; the tap reads run one (pixel, pair) ahead of their use.
     template <int B, bool FIRST>
     __device__ __forceinline__ void phase(int k, int ty, int tx, bool act, unsigned voff_cur)
     {
-#if defined(SLR_GRAY_DMA_SAFE)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-#else
         if (plane_wave || FIRST) wait_vm<0>();              // (a wave without chunks only waits for its share of the digest)
         asm volatile("s_barrier" ::: "memory");
-#endif
         // the schedule: wave 0 draws the next tile's ticket around the tap loop of phase 0, every wave picks it up here in phase 1
         // (nq >= 2); the next tile's digest and its first planes are fetched in the tile's last phase
         if constexpr (FIRST) sc.draw();
@@ -1633,7 +1616,7 @@ struct GrayDma {
 template <int LDS_BYTES, int NT, int NPP>
 constexpr int gray_dma_waves()
 {
-    constexpr int cap = NPP == 1 ? SLR_GRAY_DMA_WAVES1 : 6;
+    constexpr int cap = NPP == 1 ? kGrayDmaWaves1 : 6;
     return dma_waves_per_simd<LDS_BYTES, NT>() > cap ? cap : dma_waves_per_simd<LDS_BYTES, NT>();
 }
 
@@ -1810,7 +1793,7 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     }
     if (n == 1) j.j[1] = j.j[0];
     *done = true;
-    constexpr int NPP = SLR_GRAY_DMA_NPP;
+    constexpr int NPP = kGrayDmaNpp;
     const bool odd = ((((1 + ncol + nrow) + NPP - 1) / NPP) & 1) != 0;   // phases (of NPP plane pairs) per tile
     hipError_t e = hipSuccess;
 #define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
@@ -1847,9 +1830,7 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     return e;
 }
 
-#ifndef SLR_HYB_NPP
-#define SLR_HYB_NPP 1           // plane pairs per phase of the hybrid kernel
-#endif
+constexpr int kHybNpp = 1;            // plane pairs per phase of the hybrid kernel
 // BASELINE config 3: one pass over a hybrid stack (white, black, 2 * ncol Gray planes, 12 fringe planes; equally spaced) of one
 // camera (n == 1) or both (n == 2): code_x (-1 where invalid) and phase (NaN where invalid).  *done = false: the form does not
 // apply (stack layout, image width, maps), nothing was launched -- the caller runs the two separate fused decodes instead.
@@ -1873,7 +1854,7 @@ hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, 
     }
     if (n == 1) j.j[1] = j.j[0];
     *done = true;
-    constexpr int NPP = SLR_HYB_NPP;
+    constexpr int NPP = kHybNpp;
     const bool odd = ((((1 + ncol + 6) + NPP - 1) / NPP) & 1) != 0;     // phases (of NPP plane pairs) per tile
     hipError_t e = odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
                        : launch_gray_dma_variant<128, 16, 512, NPP, false, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut);

@@ -87,19 +87,15 @@ def test_header_is_plain_c_and_links(tmp_path):
                     os.path.join(ROOT, "include"), str(src)], check=True, capture_output=True)
 
 
-def test_ticket_register_of_the_fused_decodes_is_untouched(tmp_path):
-    """The LDS-DMA fused decodes draw the next tile's ticket with a scalar atomic whose result arrives a phase later in a FIXED
-    SGPR (kernels_rectdma.hip, SLR_TICKET_SGPR) that the kernels keep out of register allocation -- a compiler-visible register
-    was copied before the result had arrived (entries of split tiles never decoded).  The invariant is checked on the device code
-    of the library as built: inside every *_rect_decode_dma_kernel that register is written by the issue (s_mov 1, s_atomic_add),
-    read by the take (s_mov to another SGPR) and named by nothing else."""
+def check_ticket_register(lib_path, tmp_path):
+    """the invariant of test_ticket_register_of_the_fused_decodes_is_untouched on the library file `lib_path`"""
     import shutil
     import subprocess
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
     if not os.path.exists(objdump):
         pytest.skip("no llvm-objdump in this image")
     lib = tmp_path / "lib.so"
-    shutil.copy(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), lib)
+    shutil.copy(lib_path, lib)
     subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)   # unbundles next to the copy
     reg = re.search(r'#define\s+SLR_TICKET_SGPR\s+"s(\d+)"',
                     open(os.path.join(ROOT, "structure-light-reconstructor_amd", "csrc", "kernels_rectdma.hip")).read())
@@ -135,6 +131,17 @@ def test_ticket_register_of_the_fused_decodes_is_untouched(tmp_path):
             issues += 1 if ins.startswith("s_atomic_add") else 0
             takes += 1 if allowed[2].match(ins) else 0
     assert kernels >= 6 and issues >= kernels and takes >= kernels, (kernels, issues, takes)
+    return kernels
+
+
+def test_ticket_register_of_the_fused_decodes_is_untouched(tmp_path):
+    """The LDS-DMA fused decodes draw the next tile's ticket with a scalar atomic whose result arrives a phase later in a FIXED
+    SGPR (kernels_rectdma.hip, SLR_TICKET_SGPR) that the kernels keep out of register allocation -- a compiler-visible register
+    was copied before the result had arrived (entries of split tiles never decoded).  The invariant is checked on the device code
+    of the library as built: inside every *_rect_decode_dma_kernel that register is written by the issue (s_mov 1, s_atomic_add),
+    read by the take (s_mov to another SGPR) and named by nothing else.  (tests/test_gpu_disasm.py runs the same check, under
+    -m gpu, on the library file the GPU box's test process has actually mapped.)"""
+    check_ticket_register(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), tmp_path)
 
 
 def _lds_inflight_violations(listing, kernel_substr="rect_decode_dma_kernel"):
@@ -184,6 +191,30 @@ def _lds_inflight_violations(listing, kernel_substr="rect_decode_dma_kernel"):
     return reads, viol
 
 
+def check_lds_reads_in_flight(lib_path, tmp_path):
+    """the invariant of test_lds_reads_in_flight_are_not_touched on the library file `lib_path`"""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    lib = tmp_path / "lib.so"
+    shutil.copy(lib_path, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
+    reads = 0
+    for f in sorted(os.listdir(tmp_path)):
+        if not f.endswith("gfx950"):
+            continue
+        text = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        if "rect_decode_dma_kernel" not in text:
+            continue
+        n, viol = _lds_inflight_violations(text)
+        assert not viol, viol[:5]
+        reads += n
+    assert reads > 5000, reads          # (the default build: ~19 000 tap reads over 18 kernel instances)
+    return reads
+
+
 def test_lds_reads_in_flight_are_not_touched(tmp_path):
     """The tap reads of the LDS-DMA fused decodes are inline-asm ds_read_b32 issued a pixel ahead of their use and retired by
     COUNTED s_waitcnt lgkmcnt (kernels_rectdma.hip, dma_rd / dma_rd_wait).  Between the two statements the compiler believes the
@@ -198,23 +229,7 @@ def test_lds_reads_in_flight_are_not_touched(tmp_path):
     n, v = _lds_inflight_violations(bad)
     assert n == 2 and len(v) == 1 and v[0][2] == [2], v
     assert _lds_inflight_violations(bad.replace("lgkmcnt(1)", "lgkmcnt(0)"))[1] == []
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("no llvm-objdump in this image")
-    lib = tmp_path / "lib.so"
-    shutil.copy(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), lib)
-    subprocess.run([objdump, "--offloading", str(lib)], cwd=tmp_path, check=True, capture_output=True)
-    reads = 0
-    for f in sorted(os.listdir(tmp_path)):
-        if not f.endswith("gfx950"):
-            continue
-        text = subprocess.run([objdump, "-d", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
-        if "rect_decode_dma_kernel" not in text:
-            continue
-        n, viol = _lds_inflight_violations(text)
-        assert not viol, viol[:5]
-        reads += n
-    assert reads > 5000, reads          # (the default build: ~19 000 tap reads over 18 kernel instances)
+    check_lds_reads_in_flight(os.path.join(ROOT, "structure-light-reconstructor_amd", "libslr_hip.so"), tmp_path)
 
 
 def test_the_suite_runs_with_poisoned_buffers(slr):
