@@ -238,9 +238,9 @@ int slr_mfn_decode(slr_ctx *ctx, const uint16_t *const *planes, int n_freq, int 
 /* ... and THROUGH THE RECTIFICATION (BASELINE config 5 on the north_star path; build extension, parity unpinned): raw fp16
  * camera planes, camera `cam`'s maps applied with cv::remap's geometry as stereoRect::doStereoRectify uses it (stereorect.cpp:26-34:
  * CV_16SC2 + CV_16UC1 maps, 5-bit fractions, the four taps (sx, sy) .. (sx + 1, sy + 1), BORDER_CONSTANT 0) and f32 arithmetic --
- *     sample = ((t00 w00 + t01 w01) + (t10 w10 + t11 w11)) * (1 / 1024),  w00 = (32 - fx)(32 - fy), w01 = fx (32 - fy), ...
- * every operation rounded to f32 (OpenCV 2.4's remap has no fp16 mode, so there is nothing to be bit-equal to) -- fused with the
- * decode above: the rectified samples go into the DFT sums as f32.
+ *     1024 x sample = (t00 w00 + t01 w01) + (t10 w10 + t11 w11),  w00 = (32 - fx)(32 - fy), w01 = fx (32 - fy), ...
+ * the four products exact, summed in f32 row sy first, then row sy + 1 (v_dot2_f32_f16; OpenCV 2.4's remap has no fp16 mode, so
+ * there is nothing to be bit-equal to) -- fused with the decode above: the rectified samples go into the DFT sums as f32.
  * ROW BANDS (one huge frame over several GPUs): the call decodes destination rows [row0, row0 + rows) of the H-row
  * image into phase / valid of [rows][W] elements.  The planes hold SOURCE rows [src_row0, src_row0 + src_rows) only: planes[i]
  * points at source row src_row0, pitch in elements; a tap outside that window reads 0.  slr_rectify_source_rows returns the window
@@ -421,6 +421,14 @@ int slr_prefix_index(slr_ctx *ctx, const uint8_t *flags, int w, int h, int colum
                      uint32_t *index, uint32_t *total, slr_mem mem);
 int slr_compact_points(slr_ctx *ctx, const float *xyz, const uint8_t *has, size_t n, float *out_xyz, uint32_t *out_src,
                        uint32_t *count, slr_mem mem);
+
+/* The proof of an exchange.  slr_cloud_checksums: one 64-bit word per frame of a device-resident cloud (xyz [n][H][W][3], has
+ * [n][H][W] on ctx's device; position-weighted sums of the raw bits) -> out[n_frames] on the host.  slr_verify_assembled: every
+ * context checksums the assembled arrays it holds after slr_reconstruct_mf_allgather (or any other all-gather) on ITS device and
+ * the words are compared: *mismatches = (context, frame) pairs that differ from context 0's.  Synchronous. */
+int slr_cloud_checksums(slr_ctx *ctx, int n_frames, int W, int H, const float *xyz, const uint8_t *has, uint64_t *out);
+int slr_verify_assembled(slr_ctx *const *ctxs, int n_ctx, int n_frames, int W, int H, float *const *xyz_all,
+                         uint8_t *const *has_all, int *mismatches);
 
 /* page-locked host memory (the H2D / D2H copies of SLR_MEM_HOST calls are truly asynchronous only from / to it) */
 int slr_host_alloc(void **ptr, size_t bytes);

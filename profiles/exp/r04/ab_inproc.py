@@ -11,6 +11,7 @@ sweep does), and with --k4 1 the whole batch entry with the library's per-kernel
 a median table at the end.
 """
 import argparse
+import time
 import ctypes as C
 import importlib
 import os
@@ -21,6 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.a
 sys.path.insert(0, ROOT)
 os.environ.pop("SLR_POISON_OUTPUTS", None)
 os.environ.pop("SLR_POISON_SCRATCH", None)
+
+
+_T0 = time.perf_counter()
+
+
+def trace(what):
+    if os.environ.get("SLR_AB_TRACE"):
+        print("[ab %7.1f s] %s" % (time.perf_counter() - _T0, what), flush=True)
 
 
 def main():
@@ -38,6 +47,7 @@ def main():
     ap.add_argument("--mode", default="mf", choices=["mf", "ge"])
     args = ap.parse_args()
     import torch
+    trace("torch imported")
     slr = importlib.import_module("structure-light-reconstructor_amd")
     synth = importlib.import_module("structure-light-reconstructor_amd.synth")
     capi = slr.capi
@@ -53,6 +63,7 @@ def main():
         capi._lib = None
         capi.LIB_PATH = path
         libs[name] = capi.load_library()
+    trace("libraries loaded")
     scan_w = W
     ncol = synth.gray_num_bits(scan_w)
     if args.mode == "mf":
@@ -60,6 +71,7 @@ def main():
     else:
         stack = torch.stack([synth.render_gray_stack(W, H, scan_w, seed=1234 + f, noise=2, device=dev) for f in range(F)])
     torch.cuda.synchronize()
+    trace("frames rendered")
     rigs = {}
     for m in args.maps.split(","):
         if m.startswith("verged"):
@@ -67,6 +79,7 @@ def main():
             rigs[m] = synth.make_verged_rig(W, H, float(parts[1]) if len(parts) > 1 else 0.2, float(parts[2]) if len(parts) > 2 else -0.15)
         else:
             rigs[m] = None
+    trace("rigs made")
     near = [synth.make_rectify_maps(W, H, cam, device=dev) for cam in range(2)]
     calib0, _ = synth.make_calibration(W, H)
     ph = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
@@ -77,6 +90,7 @@ def main():
         for name, _ in variants:
             capi._lib = libs[name]
             ctx = slr.Context(0)
+            trace("context of %s" % name)
             for m in args.maps.split(","):
                 rig = rigs[m]
                 ctx.set_calibration(rig["calib"] if rig else calib0)
@@ -93,6 +107,7 @@ def main():
                             else:
                                 for cam in range(2):
                                     ctx.set_rectify_maps(cam, near[cam][0], near[cam][1])
+                            trace("maps installed")
                             key = (name, m, shape, depth, fl)
                             if args.mode == "mf":
                                 for f in range(2):

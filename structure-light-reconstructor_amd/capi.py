@@ -45,7 +45,7 @@ SYMBOLS = [
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_line_line_intersections", "slr_pointcloud_from_grid", "slr_pointcloud_get",
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
-    "slr_prefix_index", "slr_compact_points",
+    "slr_prefix_index", "slr_compact_points", "slr_cloud_checksums", "slr_verify_assembled",
     "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
@@ -660,6 +660,14 @@ class Context:
         return out[:k], src[:k]
 
     # -- measurement
+    def cloud_checksums(self, xyz, has):
+        """one 64-bit word per frame of a device-resident cloud xyz [n][H][W][3] / has [n][H][W]"""
+        nf, H, W = has.shape
+        self._mem([xyz, has])
+        out = np.zeros(nf, np.uint64)
+        self._chk(self.lib.slr_cloud_checksums(self.h, C.c_int(nf), C.c_int(W), C.c_int(H), _ptr(xyz), _ptr(has), _ptr(out)))
+        return out
+
     def timer_begin(self):
         self._chk(self.lib.slr_timer_begin(self.h))
 
@@ -728,6 +736,20 @@ def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0)
                                               _ptr(xa), _ptr(ha))
     ctxs[0]._chk(st)
     return (xa, ha) if gather_ctx >= 0 else (xyz, has)
+
+
+def verify_assembled(ctxs, xyz_all, has_all):
+    """slr_verify_assembled: every context checksums its assembled cloud on its own device; returns the number of (context, frame)
+    pairs that differ from context 0's (0 = the exchange is proven)."""
+    n = len(ctxs)
+    nf, H, W = has_all[0].shape
+    _sync_devices(list(xyz_all) + list(has_all))
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    xs = (C.c_void_p * n)(*[_ptr(x).value for x in xyz_all])
+    hh = (C.c_void_p * n)(*[_ptr(h).value for h in has_all])
+    mism = C.c_int(-1)
+    ctxs[0]._chk(ctxs[0].lib.slr_verify_assembled(hs, C.c_int(n), C.c_int(nf), C.c_int(W), C.c_int(H), xs, hh, C.byref(mism)))
+    return mism.value
 
 
 def reconstruct_mf_allgather(ctxs, stacks, black_thr, rectify, W=None, require_peer=False):

@@ -125,4 +125,35 @@ hipError_t launch_flag_scan(const uint8_t *flags, size_t n, int w, int h, int co
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// One 64-bit checksum per frame of an assembled cloud (slr_cloud_checksums): position-weighted sums of the raw XYZ words and of
+// the mask bytes, wrapping arithmetic.  Used to PROVE an exchange: every device checksums what it holds after the peer copies /
+// the all-gather, the host compares the words.  Pure streaming (13 B per pixel read), one launch for all frames.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cloud_checksum_kernel(const unsigned *__restrict__ xyz, const uint8_t *__restrict__ has,
+                                                             size_t n_px, unsigned long long *__restrict__ out)
+{
+    const unsigned f = blockIdx.y;
+    const unsigned *x = xyz + (size_t)f * n_px * 3;
+    const uint8_t *h = has + (size_t)f * n_px;
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n_px; i += (size_t)gridDim.x * 256u) {
+        const unsigned long long w = (unsigned long long)(i % 65521u) + 1ull;
+        acc += w * ((unsigned long long)x[3 * i] + 3ull * x[3 * i + 1] + 7ull * x[3 * i + 2]) + 1000003ull * w * h[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + f, acc);
+}
+
+hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_frames, size_t n_px, unsigned long long *d_out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * (size_t)n_frames, s);
+    if (e != hipSuccess || n_frames == 0) return e;
+    const unsigned bx = (unsigned)((n_px + 255) / 256 < 2048 ? (n_px + 255) / 256 : 2048);
+    SLR_LAUNCH(cloud_checksum_kernel, dim3(bx ? bx : 1, (unsigned)n_frames), dim3(256), 0, s, reinterpret_cast<const unsigned *>(xyz), has,
+               n_px, d_out);
+    return hipGetLastError();
+}
+
 }  // namespace slr

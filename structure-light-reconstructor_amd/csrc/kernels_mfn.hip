@@ -27,6 +27,8 @@ struct MfnPlanes { const uint16_t *p[SLR_MFN_MAX_PLANES]; };
 struct MfnTrig { float cs[SLR_MFN_MAX_STEPS], sn[SLR_MFN_MAX_STEPS]; };
 
 __device__ __forceinline__ float h2f(unsigned short b) { return __half2float(__ushort_as_half(b)); }
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32a2 __attribute__((aligned(2)));      // a dword at a 2-byte aligned address (two adjacent binary16 taps)
 
 // V pixels per thread: 4 (8-byte loads; W % 4 == 0, aligned planes) or 1.  FS x NS != 0: compile-time frequency and
 // step counts -- the plane loop unrolls completely and all 2 + FS*NS loads of a thread are in flight at once (the
@@ -119,24 +121,150 @@ __global__ __launch_bounds__(256) void mfn_decode_kernel(MfnPlanes pl, MfnTrig t
 // stereoRect::doStereoRectify applies them (stereorect.cpp:26-34): integer source position, two 5-bit fractions, the four taps
 // (sx, sy) .. (sx + 1, sy + 1), BORDER_CONSTANT 0 -- and the ARITHMETIC is f32:
 //     w00 = (32 - fx)(32 - fy), w01 = fx (32 - fy), w10 = (32 - fx) fy, w11 = fx fy            (integers, sum 1024)
-//     sample = ((t00 w00 + t01 w01) + (t10 w10 + t11 w11)) * (1 / 1024)                          (each operation rounded to f32)
-// (a product of an fp16 tap and a weight below 2^11 is exact in f32, so the sample carries two roundings at most), and the
-// sample goes into the DFT sums as f32: nothing is rounded back to fp16.  Fused with mfn_decode_kernel's per-pixel decode.
+//     1024 x sample = dot2((t10, t11), (w10, w11), dot2((t00, t01), (w00, w01), 0))              (v_dot2_f32_f16: f32 accumulation)
+// (a product of an fp16 tap and a weight of at most 2^10 is exact in f32; the four of them are summed row sy first, then row
+// sy + 1), and the sample goes into the DFT sums as f32: nothing is rounded back to fp16.  Fused with mfn_decode_kernel's decode.
 // Row bands (one 8192 x 6000 frame over 8 GPUs): a launch decodes destination rows [row0, row0 + rows) into a
 // band-sized output; the planes hold SOURCE rows [src_row0, src_row0 + src_rows) only (plane pointers address source row
 // src_row0).  A tap outside that window reads 0 like a tap outside the image; slr_rectify_source_rows gives the window a band
 // needs, and with it a band's result is the whole frame's, bit for bit.
-// This is the per-pixel gather form (every tap a 2-byte load through L1 / L2; a quad of 4 adjacent pixels per thread so that
-// neighbouring lanes touch neighbouring lines): the LDS-tiled form of the u8 path is not built for fp16 yet.
+// This is the per-pixel gather form (the two taps of a source row are one 4-byte load through L1 / L2; a quad of 4 adjacent pixels
+// per thread so that neighbouring lanes touch neighbouring lines): the LDS-tiled form of the u8 path is not built for fp16 yet.
 // ------------------------------------------------------------------------------------------------------
-template <int V, int FS, int NS>
-__global__ __launch_bounds__(256) void mfn_rect_decode_kernel(MfnPlanes pl, MfnTrig tr, int n_freq_rt, int n_step_rt, int pitch, int W,
-                                                              int H, float black_thr, const int16_t *__restrict__ map_xy,
-                                                              const uint16_t *__restrict__ map_frac, int row0, int rows,
-                                                              int src_row0, int src_rows, float *__restrict__ phase,
-                                                              uint8_t *__restrict__ valid)
+// Where the taps come from.  A contiguous stack (equally spaced planes, what BASELINE's configurations hold in HBM) is ONE buffer
+// descriptor: the plane is the scalar offset of a buffer load, a tap's position a 32-bit vector offset that is computed once per
+// pixel -- no 64-bit address per load (the first version computed 272 of them per thread, kept two VGPRs each and spilled 600
+// registers; its 34 plane pointers alone were 68 scalar registers, re-read from vector lanes before every load).  Any other
+// layout takes the pointer form.  pair(): the two binary16 taps of a source row as one dword (2-byte aligned: buffer and global
+// loads take it); half(): one tap.
+struct MfnPtrPlanes {
+    MfnPlanes pl;
+    __device__ __forceinline__ unsigned pair(int p, unsigned e) const { return *reinterpret_cast<const u32a2 *>(pl.p[p] + e); }
+    __device__ __forceinline__ unsigned half(int p, unsigned e) const { return pl.p[p][e]; }
+};
+struct MfnStridedPlanes {
+    __amdgpu_buffer_rsrc_t rsrc; unsigned stride_bytes;
+    __device__ __forceinline__ unsigned pair(int p, unsigned e) const { return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsrc, e * 2u, (unsigned)p * stride_bytes, 0); }
+    __device__ __forceinline__ unsigned half(int p, unsigned e) const { return (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rsrc, e * 2u, (unsigned)p * stride_bytes, 0); }
+};
+struct MfnStridedArg { const uint16_t *base; unsigned stride_bytes, total_bytes; };   // (the descriptor is made in the kernel)
+template <int N> struct MfnTrigN { float cs[N], sn[N]; };   // cos / sin (2 pi k / n_step) / 1024, k < n_step (N = 16: any step count)
+
+// the decode of one thread's V pixels; INSIDE: every footprint lies inside the image and the source window -> pair loads, no masks
+template <int V, int FS, int NS, bool INSIDE, typename Src, typename Trig>
+__device__ __forceinline__ void mfn_rect_quad(const Src &src, const Trig &tr, int n_freq, int n_step, unsigned pitch, float black_thr,
+                                              const unsigned off[V], const unsigned inb[V], const h16x2 w0[V], const h16x2 w1[V],
+                                              float out[V], unsigned &vw)
+{
+    unsigned o01[V], o10[V], o11[V], o00[V], k0[V], k1[V];
+    if constexpr (!INSIDE) {                             // clamped (always readable) offsets + masks: no branch per tap
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            o00[v] = (inb[v] & 1u) ? off[v] : 0u; o01[v] = (inb[v] & 2u) ? off[v] + 1u : 0u;
+            o10[v] = (inb[v] & 4u) ? off[v] + pitch : 0u; o11[v] = (inb[v] & 8u) ? off[v] + pitch + 1u : 0u;
+            k0[v] = ((inb[v] & 1u) ? 0xFFFFu : 0u) | ((inb[v] & 2u) ? 0xFFFF0000u : 0u);
+            k1[v] = ((inb[v] & 4u) ? 0xFFFFu : 0u) | ((inb[v] & 8u) ? 0xFFFF0000u : 0u);
+        }
+    }
+    // smp[v] = 1024 x the rectified sample: the four exact products summed by two v_dot2_f32_f16 -- row sy first, then row sy + 1
+    auto load = [&](int p, float smp[V]) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            unsigned u0, u1;
+            if constexpr (INSIDE) { u0 = src.pair(p, off[v]); u1 = src.pair(p, off[v] + pitch); }
+            else {
+                u0 = (src.half(p, o00[v]) | src.half(p, o01[v]) << 16) & k0[v];
+                u1 = (src.half(p, o10[v]) | src.half(p, o11[v]) << 16) & k1[v];
+            }
+            const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[v], 0.0f, false);
+            smp[v] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[v], a, false);
+        }
+    };
+    // (the samples stay scaled by 1024 -- an exact power of two: the shadow test compares against 1024 x the threshold and the
+    //  DFT uses sin / cos scaled by 1 / 1024 (tr: scaled by the launcher), so S and C are the sums of the UNscaled samples, rounded
+    //  exactly as mfn_decode_kernel rounds them; with identity maps the two kernels agree bit for bit)
+    float wh[V], bk[V];
+    load(0, wh);
+    load(1, bk);
+    float D[V][SLR_MFN_MAX_FREQ];
+    bool ok[V];
+    const float mod2 = (0.25f * n_step) * (0.25f * n_step);
+    const float thr1024 = black_thr * 1024.0f;
+#pragma unroll
+    for (int v = 0; v < V; v++) ok[v] = wh[v] - bk[v] > thr1024;
+#pragma unroll
+    for (int f = 0; f < (FS ? FS : SLR_MFN_MAX_FREQ); f++) {
+        if (f < n_freq) {
+            float S[V], C[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < (NS ? NS : SLR_MFN_MAX_STEPS); k++) {
+                if (k < n_step) {
+                    float I[V];
+                    load(2 + f * n_step + k, I);
+#pragma unroll
+                    for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+                    // four planes' tap loads (2 x 4 x V dwords) are in flight together; later ones must not be hoisted above this
+                    // point (all 272 of a 4 x 8 stack at once need 300 registers -- one wave per SIMD --, a whole frequency's 64
+                    // still spill at the 128 registers of four waves per SIMD)
+                    if ((k & 3) == 3) asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                float p = atan2f(-S[v], C[v]);
+                if (p < 0.0f) p += kTrue2PI;
+                // modulation B = 2/N * |DFT bin| below half a grey level: the phase is noise (cf. Q5) -> invalid
+                ok[v] = ok[v] && (S[v] * S[v] + C[v] * C[v] > mod2);
+#pragma unroll
+                for (int q = 0; q < SLR_MFN_MAX_FREQ; q++) if (q == f) D[v][q] = p;
+            }
+        }
+    }
+#pragma unroll
+    for (int lvl = 1; lvl < SLR_MFN_MAX_FREQ; lvl++) {
+        if (lvl < n_freq) {
+#pragma unroll
+            for (int i = 0; i + 1 < SLR_MFN_MAX_FREQ; i++) {
+                if (i + lvl < n_freq) {
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        const float a = D[v][i], b = D[v][i + 1];
+                        D[v][i] = (a > b) ? (a - b) : (a - b + kTrue2PI);
+                    }
+                }
+            }
+        }
+    }
+    vw = 0;
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        out[v] = (wh[v] - bk[v] > thr1024) ? D[v][0] / kTrue2PI * 255 : 0.0f;
+        vw |= (ok[v] ? 1u : 0u) << (8 * v);
+    }
+}
+
+// Pixels per thread of the specialised 4 x 8 instances: ONE.  Measured at 8192 x 6000 (profiles/exp/r04/mfn_time.py): a quad per thread
+// (272 tap loads per iteration, 168 registers, 390 of them spilled) 6.6 / 8.4 ms per camera, one pixel per thread (77 registers, no
+// spill) 2.2 / 2.4 ms -- the same at 4, 6 and 8 waves per SIMD, i.e. bound by the taps' path through L1 / L2, not by latency.
+constexpr int kMfnRectV = 1;
+template <int V, int FS, int NS, typename Arg>
+__global__ __launch_bounds__(256, (V == 1 ? 6 : 3)) void mfn_rect_decode_kernel(Arg arg, MfnTrigN<(NS ? NS : SLR_MFN_MAX_STEPS)> tr, int n_freq_rt,
+                                                                 int n_step_rt, int pitch, int W, int H, float black_thr,
+                                                                 const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                                 int row0, int rows, int src_row0, int src_rows,
+                                                                 float *__restrict__ phase, uint8_t *__restrict__ valid)
 {
     const int n_freq = FS ? FS : n_freq_rt, n_step = NS ? NS : n_step_rt;
+    auto make_src = [&]() {
+        if constexpr (sizeof(Arg) == sizeof(MfnStridedArg))
+            return MfnStridedPlanes{__builtin_amdgcn_make_buffer_rsrc((void *)arg.base, 0, (int)arg.total_bytes, 0x00020000), arg.stride_bytes};
+        else
+            return arg;
+    };
+    const auto src = make_src();
     const unsigned gpr = (unsigned)(W / V);
     const unsigned total = gpr * (unsigned)rows;
     // XCD-aware order (as mf_rect_decode_kernel): workgroup b runs on XCD b % 8; every XCD gets a contiguous band of rows, so the
@@ -147,80 +275,30 @@ __global__ __launch_bounds__(256) void mfn_rect_decode_kernel(MfnPlanes pl, MfnT
     for (unsigned g = vb * 256u + threadIdx.x; g < total; g += nb * 256u) {
         const unsigned brow = g / gpr, col0 = (g - brow * gpr) * V;
         const size_t m = (size_t)(brow + (unsigned)row0) * W + col0, oo = (size_t)brow * W + col0;
-        int off[V];                                      // element offset of the upper left tap inside the plane window
+        unsigned off[V];                                 // element offset of the upper left tap inside the plane window
         unsigned inb[V];                                 // bit 0..3: tap (0,0) (0,1) (1,0) (1,1) is readable
-        float w00[V], w01[V], w10[V], w11[V];
+        h16x2 w0[V], w1[V];                              // (w00, w01), (w10, w11): integers up to 1024, exact in binary16
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int sx = map_xy[2 * (m + v)], sy = map_xy[2 * (m + v) + 1];
             const unsigned f = map_frac[m + v] & 1023u, fx = f & 31u, fy = f >> 5;
-            w00[v] = (float)((32u - fx) * (32u - fy)); w01[v] = (float)(fx * (32u - fy));
-            w10[v] = (float)((32u - fx) * fy); w11[v] = (float)(fx * fy);
+            w0[v] = h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))};
+            w1[v] = h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)};
             const bool x0 = (unsigned)sx < (unsigned)W, x1 = (unsigned)(sx + 1) < (unsigned)W;
             const bool y0 = (unsigned)sy < (unsigned)H && (unsigned)(sy - src_row0) < (unsigned)src_rows;
             const bool y1 = (unsigned)(sy + 1) < (unsigned)H && (unsigned)(sy + 1 - src_row0) < (unsigned)src_rows;
             inb[v] = (x0 && y0 ? 1u : 0u) | (x1 && y0 ? 2u : 0u) | (x0 && y1 ? 4u : 0u) | (x1 && y1 ? 8u : 0u);
-            off[v] = (sy - src_row0) * pitch + sx;
-        }
-        auto load = [&](int p, float out[V]) {
-            const uint16_t *q = pl.p[p];
-#pragma unroll
-            for (int v = 0; v < V; v++) {
-                const float t00 = (inb[v] & 1u) ? h2f(q[off[v]]) : 0.0f, t01 = (inb[v] & 2u) ? h2f(q[off[v] + 1]) : 0.0f;
-                const float t10 = (inb[v] & 4u) ? h2f(q[off[v] + pitch]) : 0.0f, t11 = (inb[v] & 8u) ? h2f(q[off[v] + pitch + 1]) : 0.0f;
-                out[v] = ((t00 * w00[v] + t01 * w01[v]) + (t10 * w10[v] + t11 * w11[v])) * (1.0f / 1024.0f);
-            }
-        };
-        float wh[V], bk[V];
-        load(0, wh);
-        load(1, bk);
-        float D[V][SLR_MFN_MAX_FREQ];
-        bool ok[V];
-        const float mod2 = (0.25f * n_step) * (0.25f * n_step);
-#pragma unroll
-        for (int v = 0; v < V; v++) ok[v] = wh[v] - bk[v] > black_thr;
-#pragma unroll
-        for (int f = 0; f < n_freq; f++) {
-            float S[V], C[V];
-#pragma unroll
-            for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < n_step; k++) {
-                float I[V];
-                load(2 + f * n_step + k, I);
-#pragma unroll
-                for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
-            }
-#pragma unroll
-            for (int v = 0; v < V; v++) {
-                float p = atan2f(-S[v], C[v]);
-                if (p < 0.0f) p += kTrue2PI;
-                ok[v] = ok[v] && (S[v] * S[v] + C[v] * C[v] > mod2);
-#pragma unroll
-                for (int q = 0; q < SLR_MFN_MAX_FREQ; q++) if (q == f) D[v][q] = p;
-            }
-        }
-#pragma unroll
-        for (int lvl = 1; lvl < SLR_MFN_MAX_FREQ; lvl++) {
-            if (lvl < n_freq) {
-#pragma unroll
-                for (int i = 0; i + 1 < SLR_MFN_MAX_FREQ; i++) {
-                    if (i + lvl < n_freq) {
-#pragma unroll
-                        for (int v = 0; v < V; v++) {
-                            const float a = D[v][i], b = D[v][i + 1];
-                            D[v][i] = (a > b) ? (a - b) : (a - b + kTrue2PI);
-                        }
-                    }
-                }
-            }
+            off[v] = (unsigned)((sy - src_row0) * pitch + sx);     // (only used where a tap is readable)
         }
         float out[V];
-        unsigned vw = 0;
+        unsigned vw;
+        const bool inside = (inb[0] & inb[V > 1 ? 1 : 0] & inb[V > 2 ? 2 : 0] & inb[V > 3 ? 3 : 0]) == 15u;
+        if (inside) mfn_rect_quad<V, FS, NS, true>(src, tr, n_freq, n_step, (unsigned)pitch, black_thr, off, inb, w0, w1, out, vw);
+        else if (src_rows > 0) mfn_rect_quad<V, FS, NS, false>(src, tr, n_freq, n_step, (unsigned)pitch, black_thr, off, inb, w0, w1, out, vw);
+        else {                                           // (no source rows at all: every sample is 0)
 #pragma unroll
-        for (int v = 0; v < V; v++) {
-            out[v] = (wh[v] - bk[v] > black_thr) ? D[v][0] / kTrue2PI * 255 : 0.0f;
-            vw |= (ok[v] ? 1u : 0u) << (8 * v);
+            for (int v = 0; v < V; v++) out[v] = 0.0f;
+            vw = 0;
         }
         if constexpr (V == 4) {
             *reinterpret_cast<float4 *>(phase + oo) = make_float4(out[0], out[1], out[2], out[3]);
@@ -270,25 +348,37 @@ hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int
                                   const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
                                   float *phase, uint8_t *valid, hipStream_t s)
 {
-    MfnPlanes pl;
+    MfnPtrPlanes pp;
     const int np = 2 + n_freq * n_step;
-    for (int i = 0; i < SLR_MFN_MAX_PLANES; i++) pl.p[i] = i < np ? planes[i] : nullptr;
+    for (int i = 0; i < SLR_MFN_MAX_PLANES; i++) pp.pl.p[i] = i < np ? planes[i] : nullptr;
+    // equally spaced planes (a contiguous stack) whose windows end below 4 GiB from the first: one buffer descriptor
+    bool strided = planes[1] > planes[0];
+    const size_t stride = strided ? (size_t)(planes[1] - planes[0]) : 0;
+    for (int i = 1; i < np && strided; i++) strided = planes[i] == planes[0] + stride * (size_t)i;
+    const size_t span = (stride * (size_t)(np - 1) + (size_t)pitch * (size_t)(src_rows > 0 ? src_rows : 1)) * 2;
+    strided = strided && span < (1ull << 32) && stride * 2 < (1ull << 32);
+    const MfnStridedArg sp{planes[0], (unsigned)(stride * 2), (unsigned)span};
     const bool a4 = W % 4 == 0 && (uintptr_t)phase % 16 == 0 && (uintptr_t)valid % 4 == 0;
-    MfnTrig tr;
-    for (int k = 0; k < SLR_MFN_MAX_STEPS; k++) {
+    constexpr int VQ = kMfnRectV;                            // pixels per thread of the specialised 4 x 8 instances
+    MfnTrigN<SLR_MFN_MAX_STEPS> tr;
+    MfnTrigN<8> tr8;
+    for (int k = 0; k < SLR_MFN_MAX_STEPS; k++) {            // (the kernel's samples are x 1024: the trigonometric factors / 1024)
         const double a = 2.0 * 3.14159265358979323846 * k / (double)n_step;
-        tr.cs[k] = k < n_step ? (float)cos(a) : 0.0f;
-        tr.sn[k] = k < n_step ? (float)sin(a) : 0.0f;
+        tr.cs[k] = k < n_step ? (float)cos(a) * (1.0f / 1024.0f) : 0.0f;
+        tr.sn[k] = k < n_step ? (float)sin(a) * (1.0f / 1024.0f) : 0.0f;
+        if (k < 8) { tr8.cs[k] = tr.cs[k]; tr8.sn[k] = tr.sn[k]; }
     }
-    const size_t groups = a4 ? (size_t)(W / 4) * rows : (size_t)W * rows;
+    const bool spec = n_freq == 4 && n_step == 8 && (VQ == 1 || a4);
+    const size_t groups = spec ? (size_t)(W / VQ) * rows : a4 ? (size_t)(W / 4) * rows : (size_t)W * rows;
     unsigned blocks = (unsigned)((groups + 255) / 256 < 65536 ? (groups + 255) / 256 : 65536);
     blocks = (blocks + 7u) & ~7u;                            // (a multiple of 8: the XCD-banded order)
-#define SLR_MFNR(V, FS, NS)                                                                                            \
-    SLR_LAUNCH((mfn_rect_decode_kernel<V, FS, NS>), dim3(blocks ? blocks : 8), dim3(256), 0, s, pl, tr, n_freq, n_step, \
+#define SLR_MFNR(V, FS, NS, SRC, TR)                                                                                       \
+    SLR_LAUNCH((mfn_rect_decode_kernel<V, FS, NS, decltype(SRC)>), dim3(blocks ? blocks : 8), dim3(256), 0, s, SRC, TR, n_freq, n_step, \
                pitch, W, H, black_thr, map_xy, map_frac, row0, rows, src_row0, src_rows, phase, valid)
-    if (a4 && n_freq == 4 && n_step == 8) SLR_MFNR(4, 4, 8);         // BASELINE config 5
-    else if (a4) SLR_MFNR(4, 0, 0);
-    else SLR_MFNR(1, 0, 0);
+    if (spec && strided) SLR_MFNR(VQ, 4, 8, sp, tr8);        // BASELINE config 5, a contiguous stack
+    else if (spec) SLR_MFNR(VQ, 4, 8, pp, tr8);
+    else if (a4) SLR_MFNR(4, 0, 0, pp, tr);
+    else SLR_MFNR(1, 0, 0, pp, tr);
 #undef SLR_MFNR
     return hipGetLastError();
 }

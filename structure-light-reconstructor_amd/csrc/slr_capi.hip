@@ -1644,6 +1644,40 @@ int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, 
     return SLR_OK;
 }
 
+// One checksum per frame of a device-resident cloud; and the proof of an exchange: every context checksums the assembled arrays
+// on ITS device, the words are compared on the host.
+int slr_cloud_checksums(slr_ctx *c, int n_frames, int W, int H, const float *xyz, const uint8_t *has, uint64_t *out)
+{
+    if (!c || !xyz || !has || !out || n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
+    SLR_TRY(check_dims(c, W, H, W));
+    SLR_TRY(use_device(c));
+    if (n_frames == 0) return SLR_OK;
+    void *d;
+    SLR_TRY(get_scratch(c, S_STAGE0 + 4, sizeof(unsigned long long) * (size_t)n_frames, &d));
+    SLR_HIP(c, launch_cloud_checksums(xyz, has, n_frames, (size_t)W * H, (unsigned long long *)d, c->stream));
+    SLR_HIP(c, hipMemcpyAsync(out, d, sizeof(uint64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+    SLR_HIP(c, hipStreamSynchronize(c->stream));
+    return SLR_OK;
+}
+
+int slr_verify_assembled(slr_ctx *const *ctxs, int n_ctx, int n_frames, int W, int H, float *const *xyz_all, uint8_t *const *has_all,
+                         int *mismatches)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c0 = ctxs[0];
+    if (!xyz_all || !has_all || !mismatches || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
+    for (int k = 0; k < n_ctx; k++) if (!ctxs[k] || !xyz_all[k] || !has_all[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null context or array");
+    *mismatches = 0;
+    std::vector<uint64_t> ref((size_t)n_frames), cur((size_t)n_frames);
+    for (int k = 0; k < n_ctx; k++) {
+        const int st = slr_cloud_checksums(ctxs[k], n_frames, W, H, xyz_all[k], has_all[k], k == 0 ? ref.data() : cur.data());
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "checksum failed", slr_last_error(ctxs[k])); return st; }
+        if (k > 0)
+            for (int f = 0; f < n_frames; f++) if (cur[(size_t)f] != ref[(size_t)f]) ++*mismatches;
+    }
+    return SLR_OK;
+}
+
 // pinned host memory for callers that feed SLR_MEM_HOST buffers (PNG decoders, camera SDK ring buffers): the H2D / D2H
 // copies of the host-buffer entry points are only asynchronous (SLR_OPT_ASYNC_HOST) from page-locked memory
 int slr_host_alloc(void **p, size_t bytes)

@@ -177,6 +177,7 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
 // build extension: generalised n_freq x n_step fp16 multi-frequency decode (kernels_mfn.hip)
 hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                              float *phase, uint8_t *valid, hipStream_t s);
+hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_frames, size_t n_px, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                                   const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
                                   float *phase, uint8_t *valid, hipStream_t s);

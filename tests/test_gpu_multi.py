@@ -112,6 +112,15 @@ def test_allgather_entry_every_context_gets_the_whole_cloud(slr, synth, n_ctx, n
         for k in range(n_ctx):
             assert torch.equal(hs[k], ha) and torch.equal(xs[k], xa), k
         assert ha.float().mean().item() > 0.2
+        # the exchange proves itself on the devices: every context's checksums of its assembled cloud agree (slr_verify_assembled),
+        # and the proof can fail -- one word changed in one context's copy
+        assert slr.capi.verify_assembled(ctxs, xs, hs) == 0
+        words = ctxs[0].cloud_checksums(xs[0], hs[0])
+        assert len(set(int(w) for w in words)) == n_frames              # distinct frames, distinct words
+        if n_ctx > 1:
+            xs[n_ctx - 1][n_frames - 1, 5, 7, 1] += 1.0
+            torch.cuda.synchronize()
+            assert slr.capi.verify_assembled(ctxs, xs, hs) == 1
     finally:
         for c in ctxs:
             c.close()
@@ -170,6 +179,7 @@ def test_multi_entries_on_two_physical_devices(slr, synth):
         print("peer access between the two GPUs:", direct)
         for k in range(2):
             assert xs[k].device.index == k and torch.equal(hs[k].cpu(), eh.cpu()) and torch.equal(xs[k].cpu(), ex.cpu())
+        assert slr.capi.verify_assembled(ctxs, xs, hs) == 0             # each GPU checksums its own copy, the words agree
     finally:
         for c in ctxs + one:
             c.close()
