@@ -24,8 +24,9 @@ for name, path in variants:
     capi.load_library()
     ctx = slr.Context(0)
     ctx.set_calibration(rig["calib"]); synth.install_verged_maps(ctx, rig, W, H)
-    for rep in range(3):
-        line = []
+    for rep in range(4):
+        ctx.set_option(capi.OPT_DEBUG_FLAGS, rep & 1)          # odd repetitions: the per-pixel gather form (bit 0)
+        line = ["gather" if rep & 1 else "tiled "]
         for cam in range(2):
             ctx.mfn_rectify_decode(cam, st[cam], 4, 8, 40.0, phase=ph, valid=vd)
             ctx.synchronize(); ctx.timer_begin()
@@ -34,6 +35,7 @@ for name, path in variants:
             us = ctx.timer_end() / 3 * 1e3
             line.append("cam%d %.0f us (%.3f of 8 TB/s at 79 B/px)" % (cam, us, 79.0 * W * H / (us * 1e-6) / 8e12))
         print(name, "rep", rep, "  ".join(line), flush=True)
+    ctx.set_option(capi.OPT_DEBUG_FLAGS, 0)
     cur = (ph.clone(), vd.clone())
     if ref is None:
         ref = cur

@@ -310,6 +310,238 @@ __global__ __launch_bounds__(256, (V == 1 ? 6 : 3)) void mfn_rect_decode_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The LDS-tiled form of the rectifying 4 x 8 decode (BASELINE config 5; a contiguous stack, W % 8 == 0).  The gather form above
+// sends every tap through L1 / L2 (68 four-byte loads per pixel: 2.2 ms per 8192 x 6000 camera whatever the occupancy); here a
+// 256-thread workgroup owns a 64 x 16 destination tile: the tile's source box (bounding box of its map entries, found with wave
+// reductions; x0 aligned to 16 bytes, at most 80 x 24 elements: keystone slopes up to ~0.1) is copied plane by plane into LDS with
+// 16-byte buffer loads -- chunks outside the image or the source window become zeros, which IS BORDER_CONSTANT -- four planes at a
+// time, double buffered (the loads of the next four planes are in flight while these are decoded; one barrier per group); every
+// tap pair is two aligned LDS dwords and a v_alignbit.  Same arithmetic, same order as the gather form: bit-identical results (a
+// tile whose box does not fit runs the gather code).  A thread's 4 pixels sit in 4 different tile rows, so a wave stores 256
+// contiguous bytes of phases.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 16, kBoxW = 80, kBoxH = 24, kTileG = 4;      // pixels, box elements, planes per group
+constexpr int kTileNT = 512, kTileNW = kTileNT / 64, kTilePx = kTileW * kTileH / kTileNT;   // threads, waves, pixels per thread (2: rows wv, wv + 8)
+constexpr int kBoxRowBytes = kBoxW * 2, kBoxPlaneBytes = kBoxRowBytes * kBoxH, kBoxChunks = (kBoxW / 8) * kBoxH;
+
+constexpr int kTileLoads = (kTileG * kBoxChunks + kTileNT - 1) / kTileNT;                    // 16-byte loads per thread and group
+
+__global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg arg, MfnTrigN<8> tr, int pitch, int W, int H, float black_thr,
+                                                               const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                               int row0, int rows, int src_row0, int src_rows, int tiles_x,
+                                                               float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char box[2][kTileG][kBoxPlaneBytes];
+    __shared__ int red[kTileNW][4];
+    const MfnStridedPlanes src{__builtin_amdgcn_make_buffer_rsrc((void *)arg.base, 0, (int)arg.total_bytes, 0x00020000), arg.stride_bytes};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tiles_y = (rows + kTileH - 1) / kTileH, ntiles = tiles_x * tiles_y;
+    // XCD-banded tile order (workgroup b runs on XCD b % 8): an XCD walks a contiguous band of tile rows
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    unsigned vb = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    if (nb % 8 != 0) vb = blockIdx.x;
+    for (int t = (int)vb; t < ntiles; t += (int)nb) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int col = tx * kTileW + lane;
+        // this thread's pixels: column col, band rows ty*16 + wv + kTileNW j
+        int sx[kTilePx], sy[kTilePx];
+        unsigned fr[kTilePx];
+        bool live[kTilePx];
+        int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) {
+            const int brow = ty * kTileH + wv + kTileNW * j;
+            live[j] = brow < rows && col < W;
+            sx[j] = sy[j] = 0; fr[j] = 0;
+            if (live[j]) {
+                const size_t m = (size_t)(brow + row0) * W + col;
+                sx[j] = map_xy[2 * m]; sy[j] = map_xy[2 * m + 1]; fr[j] = map_frac[m] & 1023u;
+                if (!(sx[j] >= W || sx[j] + 1 < 0 || sy[j] >= H || sy[j] + 1 < 0)) {       // footprints completely outside read 0
+                    mnx = sx[j] < mnx ? sx[j] : mnx; mxx = sx[j] > mxx ? sx[j] : mxx;
+                    mny = sy[j] < mny ? sy[j] : mny; mxy = sy[j] > mxy ? sy[j] : mxy;
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            int v;
+            v = __shfl_xor(mnx, d); mnx = v < mnx ? v : mnx;
+            v = __shfl_xor(mxx, d); mxx = v > mxx ? v : mxx;
+            v = __shfl_xor(mny, d); mny = v < mny ? v : mny;
+            v = __shfl_xor(mxy, d); mxy = v > mxy ? v : mxy;
+        }
+        __syncthreads();                                  // (the previous tile's readers of red[] and box[] are done)
+        if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kTileNW; w++) {
+            mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
+            mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+        }
+        const bool empty = mnx > mxx;                     // the tile samples nothing
+        const int x0 = empty ? 0 : (mnx & ~7), y0 = empty ? 0 : mny;
+        const bool fits = empty || ((mxx + 1) - x0 < kBoxW && (mxy + 1) - y0 < kBoxH);
+        float out[kTilePx];
+        unsigned okm = 0;                                 // bit j: pixel j valid
+        if (!fits) {                                      // (block-uniform) a box beyond the LDS image: the gather code, pixel by pixel
+#pragma unroll 1
+            for (int j = 0; j < kTilePx; j++) {
+                out[j] = 0.0f;
+                if (!live[j]) continue;
+                const unsigned fx = fr[j] & 31u, fy = fr[j] >> 5;
+                const h16x2 w0[1] = {h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))}};
+                const h16x2 w1[1] = {h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)}};
+                const bool bx0 = (unsigned)sx[j] < (unsigned)W, bx1 = (unsigned)(sx[j] + 1) < (unsigned)W;
+                const bool by0 = (unsigned)sy[j] < (unsigned)H && (unsigned)(sy[j] - src_row0) < (unsigned)src_rows;
+                const bool by1 = (unsigned)(sy[j] + 1) < (unsigned)H && (unsigned)(sy[j] + 1 - src_row0) < (unsigned)src_rows;
+                const unsigned inb[1] = {(bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u)};
+                const unsigned off[1] = {(unsigned)((sy[j] - src_row0) * pitch + sx[j])};
+                float o1[1];
+                unsigned vw1 = 0;
+                if (src_rows > 0) mfn_rect_quad<1, 4, 8, false>(src, tr, 4, 8, (unsigned)pitch, black_thr, off, inb, w0, w1, o1, vw1);
+                else o1[0] = 0.0f;
+                out[j] = o1[0];
+                okm |= (vw1 & 1u) << j;
+            }
+        } else {
+            // LDS byte offset of the pixel's upper left tap in a plane image (rounded down to its dword), the alignbit shift, weights
+            unsigned ta[kTilePx], tsh[kTilePx];
+            h16x2 w0[kTilePx], w1[kTilePx];
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) {
+                const unsigned fx = fr[j] & 31u, fy = fr[j] >> 5;
+                w0[j] = h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))};
+                w1[j] = h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)};
+                const bool touch = live[j] && !(sx[j] >= W || sx[j] + 1 < 0 || sy[j] >= H || sy[j] + 1 < 0);
+                const unsigned b = touch ? (unsigned)((sy[j] - y0) * kBoxRowBytes + (sx[j] - x0) * 2) : 0u;
+                ta[j] = b & ~3u; tsh[j] = (b & 2u) * 8u;
+                if (!touch) { w0[j] = h16x2{(_Float16)0.0f, (_Float16)0.0f}; w1[j] = w0[j]; }       // every sample 0
+            }
+            // this thread's chunks of a group: id = threadIdx + 256 i -> (plane of the group, box row, 16-byte column)
+            unsigned cvoff[kTileLoads], cdst[kTileLoads];
+            bool cin[kTileLoads];
+#pragma unroll
+            for (int i = 0; i < kTileLoads; i++) {
+                const int id = (int)threadIdx.x + kTileNT * i, pg = id / kBoxChunks, w = id - pg * kBoxChunks, r = w / (kBoxW / 8), c = w - r * (kBoxW / 8);
+                const int gy = y0 + r, gx = x0 + 8 * c;
+                cin[i] = pg < kTileG && !empty && (unsigned)gy < (unsigned)H && (unsigned)(gy - src_row0) < (unsigned)src_rows && (unsigned)gx < (unsigned)W;
+                cvoff[i] = cin[i] ? (unsigned)(((gy - src_row0) * pitch + gx) * 2) : 0u;
+                cdst[i] = (unsigned)(pg * kBoxPlaneBytes + r * kBoxRowBytes + c * 16);
+            }
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t preA[kTileLoads], preB[kTileLoads];      // two groups in flight: the loads of a group get two decode phases of time
+            auto fetch = [&](u32x4_t pre[kTileLoads], int first, int count) {   // planes first .. first + count - 1 -> image slots 0 .. count - 1
+#pragma unroll
+                for (int i = 0; i < kTileLoads; i++) {
+                    const int id = (int)threadIdx.x + kTileNT * i, pg = id / kBoxChunks;
+                    const bool on = cin[i] && pg < count;
+                    // (the plane of the group goes into the VECTOR offset: a per-thread scalar offset makes the compiler loop over its values)
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, cvoff[i] + (unsigned)(pg < count ? pg : 0) * src.stride_bytes,
+                                                                            (unsigned)first * src.stride_bytes, 0);
+                    pre[i] = on ? v : u32x4_t{0u, 0u, 0u, 0u};
+                }
+            };
+            auto commit = [&](const u32x4_t pre[kTileLoads], int buf) {
+#pragma unroll
+                for (int i = 0; i < kTileLoads; i++) {
+                    const int id = (int)threadIdx.x + kTileNT * i;
+                    if (id < kTileG * kBoxChunks) *reinterpret_cast<u32x4_t *>(&box[buf][0][0] + cdst[i]) = pre[i];
+                }
+            };
+            float wh[kTilePx], bk[kTilePx], L0[kTilePx], L1[kTilePx], L2[kTilePx], fin[kTilePx];
+            bool ok[kTilePx];
+            const float mod2 = 4.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2
+            // the rectified samples (x 1024) of plane image `img` for the thread's 4 pixels
+            auto samples = [&](const unsigned char *img, float smp[kTilePx]) {
+                asm volatile("" ::: "memory");                // (one plane's tap reads at a time: hoisting four planes' reads spills)
+#pragma unroll
+                for (int j = 0; j < kTilePx; j++) {
+                    const unsigned *r0 = reinterpret_cast<const unsigned *>(img + ta[j]);
+                    const unsigned *r1 = reinterpret_cast<const unsigned *>(img + ta[j] + kBoxRowBytes);
+                    const unsigned u0 = __builtin_amdgcn_alignbit(r0[1], r0[0], tsh[j]);
+                    const unsigned u1 = __builtin_amdgcn_alignbit(r1[1], r1[0], tsh[j]);
+                    const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[j], 0.0f, false);
+                    smp[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[j], a, false);
+                }
+            };
+            // groups: (white, black) in buffer 0, then per frequency its steps 0-3 in buffer 1 (register set A) and 4-7 in buffer 0 (set
+            // B); a group's loads are issued two decode phases before they are committed to LDS, one barrier per group
+            fetch(preB, 0, 2);
+            commit(preB, 0);
+            fetch(preA, 2, 4);
+            __syncthreads();
+            fetch(preB, 6, 4);
+            {
+                float smp[kTilePx];
+                samples(&box[0][0][0], smp);
+#pragma unroll
+                for (int j = 0; j < kTilePx; j++) wh[j] = smp[j];
+                samples(&box[0][1][0], smp);
+#pragma unroll
+                for (int j = 0; j < kTilePx; j++) { bk[j] = smp[j]; ok[j] = wh[j] - bk[j] > thr1024; L0[j] = L1[j] = L2[j] = fin[j] = 0.0f; }
+            }
+            commit(preA, 1);
+            __syncthreads();
+#pragma unroll 1
+            for (int f = 0; f < 4; f++) {
+                float S[kTilePx], C[kTilePx];
+                if (f < 3) fetch(preA, 2 + 8 * (f + 1), 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float smp[kTilePx];
+                    samples(&box[1][k][0], smp);
+#pragma unroll
+                    for (int j = 0; j < kTilePx; j++) {
+                        if (k == 0) S[j] = C[j] = 0.0f;
+                        S[j] += smp[j] * tr.sn[k]; C[j] += smp[j] * tr.cs[k];
+                    }
+                }
+                commit(preB, 0);
+                __syncthreads();
+                if (f < 3) fetch(preB, 2 + 8 * (f + 1) + 4, 4);
+#pragma unroll
+                for (int k = 4; k < 8; k++) {
+                    float smp[kTilePx];
+                    samples(&box[0][k - 4][0], smp);
+#pragma unroll
+                    for (int j = 0; j < kTilePx; j++) { S[j] += smp[j] * tr.sn[k]; C[j] += smp[j] * tr.cs[k]; }
+                }
+#pragma unroll
+                for (int j = 0; j < kTilePx; j++) {
+                    float p = atan2f(-S[j], C[j]);
+                    if (p < 0.0f) p += kTrue2PI;
+                    ok[j] = ok[j] && (S[j] * S[j] + C[j] * C[j] > mod2);
+                    // the cascade of neighbouring differences, streamed: level 1 from (P_{f-1}, P_f), level 2 from the last two level-1
+                    // values, level 3 from the two level-2 values -- the same operations in the same order as the array form
+                    auto wrapd = [](float a, float b) { return (a > b) ? (a - b) : (a - b + kTrue2PI); };
+                    const float d1 = wrapd(L0[j], p);                    // (f >= 1)
+                    const float d2 = wrapd(L1[j], d1);                   // (f >= 2)
+                    const float d3 = wrapd(L2[j], d2);                   // (f == 3)
+                    fin[j] = f == 3 ? d3 : fin[j];
+                    L2[j] = f >= 2 ? d2 : L2[j];
+                    L1[j] = f >= 1 ? d1 : L1[j];
+                    L0[j] = p;
+                }
+                if (f < 3) commit(preA, 1);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) {
+                out[j] = (wh[j] - bk[j] > thr1024) ? fin[j] / kTrue2PI * 255 : 0.0f;
+                okm |= (ok[j] ? 1u : 0u) << j;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) {
+            if (!live[j]) continue;
+            const size_t oo = (size_t)(ty * kTileH + wv + kTileNW * j) * W + col;
+            phase[oo] = out[j];
+            valid[oo] = (uint8_t)((okm >> j) & 1u);
+        }
+    }
+}
+
 // source rows [lo, hi] that destination rows [row0, row0 + rows) read through a map (taps sy and sy + 1, clipped to the image);
 // out[0] = min sy, out[1] = max sy + 1 over the pixels whose footprint touches the image (initialised by the launcher)
 __global__ __launch_bounds__(256) void map_source_rows_kernel(const int16_t *__restrict__ map_xy, int W, int H, int row0, int rows,
@@ -375,7 +607,15 @@ hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int
 #define SLR_MFNR(V, FS, NS, SRC, TR)                                                                                       \
     SLR_LAUNCH((mfn_rect_decode_kernel<V, FS, NS, decltype(SRC)>), dim3(blocks ? blocks : 8), dim3(256), 0, s, SRC, TR, n_freq, n_step, \
                pitch, W, H, black_thr, map_xy, map_frac, row0, rows, src_row0, src_rows, phase, valid)
-    if (spec && strided) SLR_MFNR(VQ, 4, 8, sp, tr8);        // BASELINE config 5, a contiguous stack
+    if (spec && strided && W % 8 == 0 && ((uintptr_t)planes[0] % 16) == 0 && ((size_t)pitch * 2) % 16 == 0 && (stride * 2) % 16 == 0 &&
+        !tl_debug.no_tiled_map) {                            // the LDS-tiled form (SLR_OPT_DEBUG_FLAGS bit 0 keeps the gather form: tests)
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
+        unsigned tb = (unsigned)(tiles_x * tiles_y < 8 * 256 * 4 ? tiles_x * tiles_y : 8 * 256 * 4);
+        tb = (tb + 7u) & ~7u;
+        SLR_LAUNCH(mfn_rect_tile_kernel, dim3(tb ? tb : 8), dim3(kTileNT), 0, s, sp, tr8, pitch, W, H, black_thr, map_xy, map_frac, row0, rows,
+                   src_row0, src_rows, tiles_x, phase, valid);
+    }
+    else if (spec && strided) SLR_MFNR(VQ, 4, 8, sp, tr8);   // BASELINE config 5, a contiguous stack: the gather form
     else if (spec) SLR_MFNR(VQ, 4, 8, pp, tr8);
     else if (a4) SLR_MFNR(4, 0, 0, pp, tr);
     else SLR_MFNR(1, 0, 0, pp, tr);

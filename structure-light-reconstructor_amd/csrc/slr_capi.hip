@@ -680,7 +680,7 @@ static int build_dma_tiles(slr_ctx *c, int cam)
                                 !c->debug.no_quad_sort, c->dma_stats[cam], c->stream));
     SLR_HIP(c, hipStreamSynchronize(c->stream));
     const unsigned long long waves = (unsigned long long)c->dma_stats[cam][4] + c->dma_stats[cam][5] + c->dma_stats[cam][6];
-    if (c->dma_stats[cam][5] > 0 && 100ull * c->dma_stats[cam][5] <= 35ull * waves) {
+    if (c->dma_stats[cam][5] > 0 && 100ull * c->dma_stats[cam][5] <= 35ull * waves && !c->debug.no_promote) {
         SLR_HIP(c, launch_dma_tiles(c->d_map_xy[cam], c->d_map_frac[cam], W, H, c->d_dma_tiles[cam], c->opt_dma_shape, true,
                                     !c->debug.no_quad_sort, c->dma_stats[cam], c->stream));
         SLR_HIP(c, hipStreamSynchronize(c->stream));
@@ -1809,14 +1809,15 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 63) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..63");
+            if (value < 0 || value > 127) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..127");
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
             c->debug.no_ge_lean = (value & 4) != 0;
             c->debug.no_decode_count = (value & 8) != 0;
             c->debug.gray_small_tiles = (value & 16) != 0;
-            if (c->debug.no_quad_sort != ((value & 32) != 0)) {      // the map digests of the LDS-DMA forms are built either way
+            if (c->debug.no_quad_sort != ((value & 32) != 0) || c->debug.no_promote != ((value & 64) != 0)) {   // the map digests of the LDS-DMA forms are built either way
                 c->debug.no_quad_sort = (value & 32) != 0;
+                c->debug.no_promote = (value & 64) != 0;
                 SLR_TRY(use_device(c));                              // (the rebuild launches kernels: on the context's device)
                 for (int cam = 0; cam < 2; cam++)
                     if (c->d_map_xy[cam] && c->d_dma_tiles[cam]) SLR_TRY(build_dma_tiles(c, cam));

@@ -68,6 +68,7 @@ struct DebugKnobs {
     bool no_ge_lean = false;     // K5: the general kernel for every row
     bool no_decode_count = false;// GRAY_ONLY: separate decode and bucket-histogram kernels
     bool no_quad_sort = false;   // LDS-DMA fused decodes: every wave keeps the quads of its own block of the tile (read when maps are installed)
+    bool no_promote = false;     // LDS-DMA fused decodes: straddling waves keep the three-row read mode (no promotion to per-pixel reads)
     bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
     int k4_stop = 0;
     bool poison_scratch = false; // SLR_OPT_DEBUG_POISON_SCRATCH

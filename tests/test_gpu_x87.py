@@ -117,6 +117,7 @@ def test_x87_fullsize_decode_and_sampled_match(xctx, oracle, synth):
     ph, vd = [], []
     for cam in range(2):
         p, v = xctx.mf_decode(st[cam], BLACK, rectify_cam=cam)
+        xctx.synchronize()                               # (the kernels run on the ctx stream: torch must not read before they are done)
         ph.append(p.cpu().numpy()); vd.append(v.cpu().numpy())
     mx, mf = xctx.get_rectify_maps(0, W, H)
     pl = np.stack([oracle.remap_u8(st[0, p].cpu().numpy(), mx, mf) for p in range(14)])

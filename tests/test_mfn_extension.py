@@ -241,3 +241,34 @@ def test_gpu_mfn_rectified_row_bands_with_source_windows(ctx, oracle, synth):
     d2 = ctx.mfn_rectify_decode(cam, short, F, N, 40.0, W=W, H=H, row0=r0, rows=r1 - r0, src_row0=s0 + 1)
     ctx.synchronize()
     assert not torch.equal(d2[0], full[cam][0][r0:r1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,strength", [(1024, 200, 1.0), (512, 77, 6.0), (2048, 64, 40.0), (64, 16, 1.0), (8, 3, 1.0)])
+def test_gpu_mfn_rectify_tiled_form_equals_the_gather_form(ctx, slr, synth, W, H, strength):
+    """the LDS-tiled form of the 4 x 8 rectifying decode (contiguous stack, W % 8 == 0: what config 5 runs) against the per-pixel
+    gather form (SLR_OPT_DEBUG_FLAGS bit 0), bit for bit: ragged last tiles, borders, maps whose tile boxes do not fit the LDS image
+    (strength 40: those tiles run the gather code inside the tiled kernel), row bands with source windows"""
+    F, N = 4, 8
+    st = synth.render_mfn_stack(W, H, F, N, noise=0.5, seed=W + H).cuda()
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=strength)
+        ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
+    res = {}
+    for flags in (1, 0):
+        ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
+        out = []
+        for cam in range(2):
+            out.append(ctx.mfn_rectify_decode(cam, st[cam], F, N, 40.0))
+            r0, r1 = H // 3, max(H // 3 + 1, 2 * H // 3)
+            s0, sn = ctx.rectify_source_rows(cam, r0, r1 - r0)
+            if sn > 0:
+                win = st[cam][:, s0:s0 + sn].contiguous()
+                out.append(ctx.mfn_rectify_decode(cam, win, F, N, 40.0, W=W, H=H, row0=r0, rows=r1 - r0, src_row0=s0))
+        ctx.synchronize()
+        res[flags] = out
+    ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert res[0][0][1].float().mean().item() > (0.2 if strength < 10 else 0.0)
