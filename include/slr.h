@@ -89,7 +89,11 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * mfreconstruct.cpp:289-331), 2 = indexed exact form built by an LDS radix sort (distinct phases), 3 = indexed exact form
  * built by an LDS counting sort (rows wider than 4096 pixels are matched against the right row in chunks of 4096 columns, up to
  * 32768 pixels; wider rows take the sweep).  0 picks 3, in its lean variant (same index, fewer instructions) when the rows are
- * aligned, 513..1024 or 2049..4096 pixels wide and Q has cv::stereoRectify's pattern.  All give identical results. */
+ * aligned, 513..1024 or 2049..4096 pixels wide and Q has cv::stereoRectify's pattern.  4 / 5 / 6 pin the lean variant's
+ * shapes for rows of 2049..4096 pixels (0 picks 1024 threads x 4 pixels with the row's XYZ stored through LDS; 4 = the same
+ * with per-thread stores, round 2; 5 / 6 = 512 threads x 8 pixels with two / three rows per CU) and behave as 0 where the
+ * lean variant does not apply.  All give
+ * identical results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libslr_hip.so")
 MF_PLANES = 14
 MAX_GRAY_BITS = 16
 MEM_HOST, MEM_DEVICE = 0, 1
-OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort)
+OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort), 4/5/6 lean shapes (1024x4, 512x8 two rows per CU, 512x8 three rows per CU)
 OPT_RECT_DECODE_ALGO = 3       # fused rectify+decode: 0 auto (5, else 6), 1 direct gather, 2 LDS tiles 64x16, 3 sliding LDS
                                # window down tile columns, 4 tiles 128x8 / 256 threads, 5 tiles 128x8 / 512 threads,
                                # 6 tiles 64x8 / 256 threads
@@ -427,12 +427,13 @@ class Context:
         return cx, cy, valid
 
     # -- K4
-    def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True, row0=0, image_h=None):
-        """row0 / image_h: the arrays are a band of rows [row0, row0 + H) of an image_h-row image (row-band sharding)."""
+    def mf_triangulate(self, phaseL, validL, phaseR, validR, want_match=True, row0=0, image_h=None, xyz=None, has=None):
+        """row0 / image_h: the arrays are a band of rows [row0, row0 + H) of an image_h-row image (row-band sharding).
+        xyz / has: caller-owned outputs (same memory kind as the inputs)."""
         H, W = phaseL.shape
-        mem = self._mem([phaseL, validL, phaseR, validR])
-        xyz = self._new(mem, (H, W, 3), np.float32, phaseL)
-        has = self._new(mem, (H, W), np.uint8, phaseL)
+        mem = self._mem([phaseL, validL, phaseR, validR, xyz, has])
+        xyz = self._new(mem, (H, W, 3), np.float32, phaseL) if xyz is None else xyz
+        has = self._new(mem, (H, W), np.uint8, phaseL) if has is None else has
         mk = self._new(mem, (H, W), np.int32, phaseL) if want_match else None
         if image_h is None and row0 == 0:
             self._chk(self.lib.slr_mf_triangulate(self.h, _ptr(phaseL), _ptr(validL), _ptr(phaseR), _ptr(validR),

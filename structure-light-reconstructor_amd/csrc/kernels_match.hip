@@ -489,7 +489,7 @@ struct K4Lean {
     double T[12];                      // matCoordTrans widened to f64 (exact)
 };
 
-template <int BLOCK, bool HAS_T>
+template <int BLOCK, bool HAS_T, bool XCHG = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
                                                               int W, int H, int row0, K4Lean kc, int stop,
@@ -638,7 +638,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         best[i] = (int)bk;                               // 0xFFFFFFFF == -1: no match
     }
     SLR_K4_STOP_AT5(best[0]);
-    if (!inrow) return;
+    if (!XCHG && !inrow) return;
+    if (XCHG) __syncthreads();                           // every wave is done with the index: the row's XYZ goes through its LDS
 
     // triangulation (mfreconstruct.cpp:297-326), branch-free for the 4 pixels
 #if defined(SLR_K4_ABL) && (SLR_K4_ABL & 2)
@@ -647,11 +648,12 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
 #pragma unroll
     for (int i = 0; i < IPT; i++) urx[i] = (float)best[i];
 #else
-    const f32x4 ua = *reinterpret_cast<const f32x4 *>(undL + (trow + k0) / 2);
-    const f32x4 ub = *(reinterpret_cast<const f32x4 *>(undL + (trow + k0) / 2) + 1);
+    const size_t tk0 = trow + (inrow ? k0 : 0);          // (XCHG: threads beyond the row stay for the barriers)
+    const f32x4 ua = *reinterpret_cast<const f32x4 *>(undL + tk0 / 2);
+    const f32x4 ub = *(reinterpret_cast<const f32x4 *>(undL + tk0 / 2) + 1);
     float urx[IPT];
 #pragma unroll
-    for (int i = 0; i < IPT; i++) urx[i] = undRx[trow + (best[i] >= 0 ? best[i] : 0)];
+    for (int i = 0; i < IPT; i++) urx[i] = undRx[trow + (inrow && best[i] >= 0 ? best[i] : 0)];
 #endif
     const float ulx[IPT] = {ua.x, ua.z, ub.x, ub.z}, uly[IPT] = {ua.y, ua.w, ub.y, ub.w};
     float out[12];
@@ -717,11 +719,314 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
 #if defined(SLR_K4_ABL) && (SLR_K4_ABL & 1)
     if (out[0] + out[5] + out[10] != 1.2345e-30f) return;
 #endif
-    __builtin_nontemporal_store(v0, d4);
-    __builtin_nontemporal_store(v1, d4 + 1);
-    __builtin_nontemporal_store(v2, d4 + 2);
+    if constexpr (XCHG) {
+        // the row's XYZ transposed through the dead index: a wave's store instruction then writes 1 KB of consecutive bytes
+        // instead of 16 bytes per lane at a 48-byte stride
+        f32x4 *const x4 = reinterpret_cast<f32x4 *>(&sh);
+        x4[3 * tid] = v0; x4[3 * tid + 1] = v1; x4[3 * tid + 2] = v2;
+        __syncthreads();
+        f32x4 *const r4 = reinterpret_cast<f32x4 *>(xyz + 3 * base);
+        const int n4 = 3 * W / 4;                        // 16-byte words of the row
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (tid + q * BLOCK < n4) __builtin_nontemporal_store(x4[tid + q * BLOCK], r4 + tid + q * BLOCK);
+        if (!inrow) return;
+    } else {
+        __builtin_nontemporal_store(v0, d4);
+        __builtin_nontemporal_store(v1, d4 + 1);
+        __builtin_nontemporal_store(v2, d4 + 2);
+    }
     __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
     if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[0], best[1], best[2], best[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4 (exact indexed form, lean, round 4): the same index as mf_match_lean_kernel -- hash dedup, representatives counting-sorted
+// into 0.25-wide bins, exact predicate on the window's pairs -- cut for instruction-level instead of wave-level parallelism:
+//   * 512 threads x 8 pixels (two runs of 4: columns 4t.. and 2048 + 4t.., so that a wave's global accesses keep the 1024-thread
+//     form's shape): a row is 8 waves instead of 16 (half the barrier population, an 8-wave DPP scan), a thread keeps 8
+//     independent LDS atomics / reads in flight where the 1024-thread form keeps 4;
+//   * TS (hash slots) = 8192 -> 64 KB, two rows per CU at up to 128 VGPRs; TS = 6144 -> 48 KB, THREE rows per CU at 80 VGPRs:
+//     three workgroups in different stages fill each other's barrier waits (the 1024-thread form is pinned to two by the
+//     CU's 32 wave slots).  A slot is (hash >> 16) * TS >> 16; linear probing wraps by compare;
+//   * the query reads the first 8 pairs of EVERY pixel's window unconditionally (4 ds_read_b128 per pixel, two pixels = 8 reads
+//     in flight, no loop-carried branch between them; 8 NaN sentinels close the array) -- 95 % of the windows of a scene's rows end there;
+//     a loop continues for the rest.  An inactive pixel queries with a NaN (never matches);
+//   * the exponent guard of the shared-reciprocal quotients looks at w only: r0 = ulx + q3 and r1 = uly + q7 are sums of a
+//     finite f32 and a host-checked double (K4Lean is only built when q3, q7, q11 are finite, not -0 and zero or within
+//     2^+-100), so they are zero or within 2^-152 .. 2^129 whenever the table entries are finite -- one v_cmp_class each;
+//   * the hash table is cleared with 16-byte stores.
+// Bit-equal to mf_match_lean_kernel / the general forms / the oracle (tests/test_gpu_lean.py, test_gpu_fullsize.py).
+// ------------------------------------------------------------------------------------------------------
+template <bool HAS_T, int TS, int WPS>
+__global__ __launch_bounds__(512, WPS) void mf_match_lean8_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                              const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                              int W, int H, int row0, K4Lean kc, int stop,
+                                                              const float4 *__restrict__ undL, const float *__restrict__ undRx,
+                                                              float *__restrict__ xyz,
+                                                              uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int BLOCK = 512, IPT = 8;
+    constexpr int N = BLOCK * IPT;                       // 4096 pixels
+    constexpr int kPer = kBins / BLOCK;                  // bins per thread
+    constexpr unsigned kEmpty = 0xFFFFFFFFu;             // a NaN pattern: never a candidate's phase bits
+    constexpr int kSent = 8;                             // NaN pairs behind the last candidate
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    static_assert(TS >= kBins + BLOCK && TS % (2 * BLOCK) == 0 && TS <= 65536, "bin counters live in the key half; 16-byte clears");
+    constexpr bool kPow2 = (TS & (TS - 1)) == 0;
+    __shared__ union {
+        struct { unsigned key[TS]; unsigned mink[TS]; } t;                         // phase bits -> smallest column
+        struct { f32x4 pk2[(N + kSent + 2) / 2]; unsigned bs[kBins + 3]; } b;      // (phi, column) pairs by bin + sentinels + a sink; bin index
+    } sh;
+    __shared__ unsigned scan_tmp[BLOCK / 64];
+    static_assert(sizeof(sh.b.pk2) >= (size_t)(kBins + BLOCK) * 4, "the bin index must not overlap the live bin counters");
+
+    const int row = blockIdx.x + row0, tid = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * W;
+    // a thread's 8 pixels are two runs of 4: columns [4 tid, 4 tid + 4) and [2048 + 4 tid, ...) -- every global access of a wave is
+    // then the 1024-thread form's (16 bytes per lane at a 16-byte stride in, 48 bytes per lane at a 48-byte stride out); 8
+    // CONSECUTIVE pixels per thread cost 86 instead of 11 us of stores (96-byte lane stride)
+    const int kg[2] = {4 * tid, N / 2 + 4 * tid};
+    const bool ing[2] = {kg[0] < W, kg[1] < W};          // W % 4 == 0: a run is all inside or all outside
+#define SLR_KCOL(i) (kg[(i) >> 2] + ((i) & 3))
+
+    float pr[IPT], pl[IPT];
+    unsigned vr[IPT], vl[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) { pr[i] = 0.0f; pl[i] = 0.0f; vr[i] = 0u; vl[i] = 0u; }
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+        if (ing[g]) {
+            load_f32_blocked<4>(phaseR + base, kg[g], kg[g] + 4, true, pr + 4 * g);
+            load_valid_blocked<4>(validR, base, kg[g], kg[g] + 4, true, vr + 4 * g);
+            load_f32_blocked<4>(phaseL + base, kg[g], kg[g] + 4, true, pl + 4 * g);
+            load_valid_blocked<4>(validL, base, kg[g], kg[g] + 4, true, vl + 4 * g);
+        }
+    const size_t trow = (size_t)row * W;
+    {
+        const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+        u32x4 *const t4 = reinterpret_cast<u32x4 *>(sh.t.key);
+#pragma unroll
+        for (int q = 0; q < 2 * TS / 4 / BLOCK; q++) t4[tid + q * BLOCK] = e4;
+    }
+    __syncthreads();
+    SLR_K4_STOP_AT(1);
+
+    // A. distinct values and their smallest column
+    unsigned slot[IPT], old[IPT];
+    unsigned candm = 0;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const unsigned bits = __float_as_uint(pr[i]);
+        const bool ok = ing[i >> 2] && vr[i] && (pr[i] == pr[i]);
+        const bool dup = (i & 3) > 0 && ok && vr[i - 1] && bits == __float_as_uint(pr[i - 1]);
+        candm |= (ok && !dup ? 1u : 0u) << i;
+        const unsigned h = bits * 2654435761u;
+        slot[i] = kPow2 ? h >> (32 - __builtin_ctz(TS)) : ((h >> 16) * (unsigned)TS) >> 16;
+    }
+#pragma unroll
+    for (int i = 0; i < IPT; i++) old[i] = (candm >> i) & 1u ? atomicCAS(&sh.t.key[slot[i]], kEmpty, __float_as_uint(pr[i])) : kEmpty;
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        if ((candm >> i) & 1u) {
+            const unsigned bits = __float_as_uint(pr[i]);
+            unsigned h = slot[i], o = old[i];
+            while (o != kEmpty && o != bits) {
+                h = kPow2 ? (h + 1) & (TS - 1) : (h + 1 == (unsigned)TS ? 0u : h + 1);
+                o = atomicCAS(&sh.t.key[h], kEmpty, bits);
+            }
+            atomicMin(&sh.t.mink[h], (unsigned)SLR_KCOL(i));
+            slot[i] = h;
+        }
+    }
+    __syncthreads();
+    unsigned *const cnt = sh.t.key;                      // the key half is dead: bin counters (+ one sink per thread)
+    unsigned repmask = 0;
+    {
+        unsigned mk[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) mk[i] = sh.t.mink[slot[i]];
+        {
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            u32x4 *const c4 = reinterpret_cast<u32x4 *>(cnt);
+#pragma unroll
+            for (int q = 0; q < kPer / 4; q++) c4[tid + q * BLOCK] = z4;
+            cnt[kBins + tid] = 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < IPT; i++)
+            if (((candm >> i) & 1u) && mk[i] == (unsigned)SLR_KCOL(i)) repmask |= 1u << i;
+    }
+    __syncthreads();                                     // the whole table is dead from here on
+    SLR_K4_STOP_AT(2);
+
+    // B. counting sort of the representatives by phase bin
+    unsigned bin[IPT], rank[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) bin[i] = (repmask >> i) & 1u ? (unsigned)phase_bin(pr[i]) : (unsigned)(kBins + tid);
+#pragma unroll
+    for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&cnt[bin[i]], 1u);
+    __syncthreads();
+    float2 *const pk = reinterpret_cast<float2 *>(sh.b.pk2);
+    {
+        unsigned c[kPer], sum = 0;
+        const u32x4 *const c4 = reinterpret_cast<const u32x4 *>(cnt + tid * kPer);
+#pragma unroll
+        for (int q = 0; q < kPer / 4; q++) {
+            const u32x4 v = c4[q];
+            c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            sum += v.x + v.y + v.z + v.w;
+        }
+        unsigned total;
+        unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }
+        if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
+    }
+    __syncthreads();
+    {
+        const unsigned total = sh.b.bs[kBins + 1];
+        if (tid < kSent) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
+        unsigned st[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) st[i] = sh.b.bs[1 + ((repmask >> i) & 1u ? bin[i] : (unsigned)kBins)];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const unsigned at = (repmask >> i) & 1u ? st[i] + rank[i] : (unsigned)(N + kSent);   // (the sink)
+            pk[at] = make_float2(pr[i], __uint_as_float((unsigned)SLR_KCOL(i)));
+        }
+    }
+    __syncthreads();
+    SLR_K4_STOP_AT(4);
+
+    // queries: the reference's predicate on the pairs of bins [b-1, b+1] (and a few neighbours), smallest column wins
+    int best[IPT];
+    unsigned qa[IPT], qe[IPT];                           // byte offsets into pk: first 16-byte word, end of the window
+    float pq[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; i++) {
+        const bool act = ing[i >> 2] && vl[i] && pl[i] == pl[i];
+        const int b = phase_bin(pl[i]);                  // (a NaN lands in bin 0; it queries with a NaN and an empty window)
+        const unsigned i0 = sh.b.bs[b], i1 = sh.b.bs[b + 3];
+        qa[i] = (i0 & ~1u) * 8u;
+        qe[i] = act ? i1 * 8u : 0u;
+        pq[i] = act ? pl[i] : __builtin_nanf("");
+    }
+    const char *const pkb = reinterpret_cast<const char *>(sh.b.pk2);
+    auto hit4 = [](float p, const f32x4 &c0, const f32x4 &c1) -> unsigned {
+        const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+        const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+        const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+        const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+        return min(min(h0, h1), min(h2, h3));
+    };
+#pragma unroll
+    for (int i = 0; i < IPT; i += 2) {                   // two pixels' first 8 pairs each: 8 independent 16-byte reads
+        f32x4 c[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[j][q] = *reinterpret_cast<const f32x4 *>(pkb + qa[i + j] + 16 * q);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            unsigned bk = min(hit4(pq[i + j], c[j][0], c[j][1]), hit4(pq[i + j], c[j][2], c[j][3]));
+            for (unsigned a = qa[i + j] + 64u; a < qe[i + j]; a += 32u) {
+                const f32x4 d0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                bk = min(bk, hit4(pq[i + j], d0, d1));
+            }
+            best[i + j] = (int)bk;                       // 0xFFFFFFFF == -1: no match
+        }
+    }
+    SLR_K4_STOP_AT5(best[0]);
+
+    // triangulation (mfreconstruct.cpp:297-326), branch-free, 4 pixels at a time.  All table reads before the first store (vmcnt
+    // counts stores too: a later run's loads would wait for an earlier run's stores to reach memory)
+    float urx[IPT];
+    f32x4 ul4[IPT / 2];
+#pragma unroll
+    for (int g = 0; g < IPT; g += 4) {
+        const bool in = ing[g >> 2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) urx[g + i] = undRx[trow + (in && best[g + i] >= 0 ? best[g + i] : 0)];
+        const f32x4 *const u4 = reinterpret_cast<const f32x4 *>(undL + (trow + (in ? kg[g >> 2] : 0)) / 2);
+        ul4[g / 2] = u4[0]; ul4[g / 2 + 1] = u4[1];
+    }
+#pragma unroll
+    for (int g = 0; g < IPT; g += 4) {
+        const f32x4 ua = ul4[g / 2], ub = ul4[g / 2 + 1];
+        float out[12];
+        unsigned hw = 0;
+        const float ulx[4] = {ua.x, ua.z, ub.x, ub.z}, uly[4] = {ua.y, ua.w, ub.y, ub.w};
+        unsigned bad = 0;                                // pixels whose quotients need the real divisions
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+            const double w = kc.q14 * (double)(float)(ulx[i] - urx[g + i]) + kc.q15;
+            const unsigned ew = ((unsigned)__double2hiint(w) >> 20) & 0x7FFu;
+            const bool fin = __builtin_isfinite(ulx[i]) && __builtin_isfinite(uly[i]);
+            if (!(ew - (1023u - 200u) < 400u && fin) && best[g + i] >= 0) bad |= 1u << i;
+            double y = __builtin_amdgcn_rcp(w);          // the three IEEE quotients from one refined reciprocal (mf_match_lean_kernel)
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            const double r[3] = {r0, r1, r2};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double q = r[c] * y;
+                const double e = __builtin_fma(-w, q, r[c]);
+                out[3 * i + c] = (float)__builtin_fma(e, y, q);
+            }
+        }
+#if defined(SLR_K4_ABL) && (SLR_K4_ABL & 4)
+        bad = 0;
+#endif
+        if (__builtin_expect(bad != 0, 0)) {             // w == 0, NaN, extreme exponents, non-finite table entries: the real divisions
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                if (!((bad >> i) & 1u)) continue;
+                float ux = 0.0f, uy = 0.0f, ur = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j == i) { ux = ulx[j]; uy = uly[j]; ur = urx[g + j]; }
+                const double r0 = (double)ux + kc.q3, r1 = (double)uy + kc.q7, r2 = kc.q11;
+                const double w = kc.q14 * (double)(float)(ux - ur) + kc.q15;
+                const float X0 = (float)(r0 / w), X1 = (float)(r1 / w), X2 = (float)(r2 / w);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j == i) { out[3 * j] = X0; out[3 * j + 1] = X1; out[3 * j + 2] = X2; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if constexpr (HAS_T) {                       // matCoordTrans(3x4 f32) * [X;1]: f64 accumulate, narrow once
+                const double X0 = (double)out[3 * i], X1 = (double)out[3 * i + 1], X2 = (double)out[3 * i + 2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double s = __builtin_fma(kc.T[c * 4], X0, 0.0);
+                    s = __builtin_fma(kc.T[c * 4 + 1], X1, s);
+                    s = __builtin_fma(kc.T[c * 4 + 2], X2, s);
+                    out[3 * i + c] = (float)(s + kc.T[c * 4 + 3]);
+                }
+            }
+            const bool m = best[g + i] >= 0;
+            out[3 * i] = m ? out[3 * i] : 0.0f; out[3 * i + 1] = m ? out[3 * i + 1] : 0.0f; out[3 * i + 2] = m ? out[3 * i + 2] : 0.0f;
+            hw |= (m ? 1u : 0u) << (8 * i);
+        }
+#if defined(SLR_K4_ABL) && (SLR_K4_ABL & 1)
+        if (out[0] + out[5] + out[10] != 1.2345e-30f) continue;
+#endif
+        if (!ing[g >> 2]) continue;
+        const size_t o = base + kg[g >> 2];
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(xyz + 3 * o);  // streaming output: non-temporal stores
+        const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+        __builtin_nontemporal_store(v0, d4);
+        __builtin_nontemporal_store(v1, d4 + 1);
+        __builtin_nontemporal_store(v2, d4 + 2);
+        __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
+        if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[g], best[g + 1], best[g + 2], best[g + 3]);
+    }
+#undef SLR_KCOL
 }
 
 // K4 for rows wider than 4096 pixels.  The hash table of a whole 8192-pixel right row needs 128 KB of LDS (one 1024-thread
@@ -1090,7 +1395,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                vec_ok, undL, undRx, xyz, has, match_k)
 #endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
-        if (algo == 0 && !cal.eval_x87 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+        if ((algo == 0 || (algo >= 4 && algo <= 6)) && !cal.eval_x87 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
             K4Lean kc;
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
@@ -1103,6 +1408,32 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
         else SLR_LAUNCH((mf_match_lean_kernel<BLOCK, false>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR,         \
                         W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                               \
     } while (0)
+            // round 4, rows of 2049..4096 pixels: algo 0 = 1024 threads x 4 pixels with the row's XYZ stored through LDS (whole
+            // kilobytes per store instruction: 86 vs 91 us in the batch); 4 = the same without the exchange (round 2); 5 / 6 = 512
+            // threads x 8 pixels with two / three rows per CU (measured: 98 / 94 us, not faster; their quotient guard needs a tame Q)
+            auto tame = [](double q, bool zero_ok) {
+                return (q == 0.0 && zero_ok && !signbit(q)) || (isfinite(q) && fabs(q) >= 0x1p-100 && fabs(q) <= 0x1p100);
+            };
+            const bool q_tame = tame(kc.q3, true) && tame(kc.q7, true) && tame(kc.q11, false);
+            if (W > 2048 && (algo == 5 || algo == 6) && q_tame) {
+#define SLR_LEAN8(TS, WPS)                                                                                                       \
+    do {                                                                                                                         \
+        if (cal.has_T) SLR_LAUNCH((mf_match_lean8_kernel<true, TS, WPS>), dim3(H), dim3(512), 0, s, phaseL, validL, phaseR, validR, \
+                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                     \
+        else SLR_LAUNCH((mf_match_lean8_kernel<false, TS, WPS>), dim3(H), dim3(512), 0, s, phaseL, validL, phaseR, validR,        \
+                        W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                               \
+    } while (0)
+                if (algo == 5) SLR_LEAN8(8192, 4); else SLR_LEAN8(6144, 6);
+#undef SLR_LEAN8
+                return hipGetLastError();
+            }
+            if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
+                if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<1024, true, true>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
+                                          W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);
+                else SLR_LAUNCH((mf_match_lean_kernel<1024, false, true>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
+                                W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);
+                return hipGetLastError();
+            }
             if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);
 #undef SLR_LEAN
             return hipGetLastError();
@@ -1290,8 +1621,12 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
     constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, kPer = TC / BLOCK, kMaxList = 32;
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    __shared__ unsigned start[TC + BLOCK + 1];             // counters, then list starts (start[TC] = total); [TC + 1 + tid]: atomics' sinks
-    __shared__ unsigned short S[N];                        // the lists: columns grouped by code, ascending inside a code
+    __shared__ union {
+        struct { unsigned start[TC + BLOCK + 1]; unsigned short S[N]; } l;
+        f32x4 x4[3 * BLOCK];                               // the row's XYZ on its way out (round 4: whole kilobytes per store instruction)
+    } sh;
+    unsigned *const start = sh.l.start;                    // counters, then list starts (start[TC] = total); [TC + 1 + tid]: atomics' sinks
+    unsigned short *const S = sh.l.S;                      // the lists: columns grouped by code, ascending inside a code
     __shared__ union { unsigned u[BLOCK / 64]; int i[BLOCK / 64]; } scan_tmp;
 
     const int row = blockIdx.x, tid = threadIdx.x;
@@ -1412,13 +1747,13 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
         ks_in = new_in > ks_in ? new_in : ks_in;
         if (!__syncthreads_or(dirty ? 1 : 0)) break;
     }
-    if (!inrow) return;
+    // (the loop's last barrier: every thread is done with the lists; threads beyond the row stay for the exchange's barrier)
 
     // triangulation of the thread's 4 pixels (reconstruct.cpp:570-603), branch-free
     float out[12];
     unsigned hw = 0, cw = 0, bad = 0;
     unsigned wl4 = 0;
-    if (color) wl4 = *reinterpret_cast<const unsigned *>(whiteL + base + k0);
+    if (color && inrow) wl4 = *reinterpret_cast<const unsigned *>(whiteL + base + k0);
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         const int j = k0 + i, mm = m[i] >= 0 ? m[i] : 0;
@@ -1472,9 +1807,17 @@ __global__ __launch_bounds__(1024, 8) void ge_match_lean_kernel(const int32_t *_
     const size_t o = base + k0;
     f32x4 *d4 = reinterpret_cast<f32x4 *>(xyz + 3 * o);
     const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
-    __builtin_nontemporal_store(v0, d4);
-    __builtin_nontemporal_store(v1, d4 + 1);
-    __builtin_nontemporal_store(v2, d4 + 2);
+    (void)d4;
+    sh.x4[3 * tid] = v0; sh.x4[3 * tid + 1] = v1; sh.x4[3 * tid + 2] = v2;
+    __syncthreads();
+    {
+        f32x4 *const r4 = reinterpret_cast<f32x4 *>(xyz + 3 * base);
+        const int n4 = 3 * W / 4;                          // 16-byte words of the row
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (tid + q * BLOCK < n4) __builtin_nontemporal_store(sh.x4[tid + q * BLOCK], r4 + tid + q * BLOCK);
+    }
+    if (!inrow) return;
     __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
     if (color) __builtin_nontemporal_store(cw, reinterpret_cast<unsigned *>(color + o));
     if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(m[0], m[1], m[2], m[3]);

@@ -1773,7 +1773,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
     if (!c) return SLR_ERR_INVALID_ARG;
     switch (option) {
         case SLR_OPT_MF_MATCH_ALGO:
-            if (value < 0 || value > 3) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..3");
+            if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..6");
 #ifndef SLR_ALL_FORMS
             if (value == 2) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 2 (sorted form) is compiled with -DSLR_ALL_FORMS only");
 #endif
