@@ -542,6 +542,370 @@ __global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The LDS-DMA form of the rectifying 4 x 8 decode (round 4; BASELINE config 5's shipped kernel).  The register-staged tile kernel
+// above waits out one fetch latency per plane group (2.0 ms per 8192 x 6000 camera, hardly faster than the gather form): its
+// groups are short (0.15 us of arithmetic against ~2 us of latency) and only two are in flight.  Here
+//   * the source box goes HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 bytes per lane, no VGPR staging, no commit pass)
+//     into a RING of R slots of one 4-plane group each (15 KB; rows / columns beyond the tile's real box and everything outside the
+//     image or the source window are out-of-range lanes: zeros, no traffic -- BORDER_CONSTANT);
+//   * the stream of groups runs ACROSS tiles: a persistent workgroup keeps R - 1 groups in flight while it decodes one, also over
+//     a tile boundary -- the next tile's map entries (6 bytes per pixel) arrive by DMA as well during the current tile, its box is
+//     reduced from them (wave reductions + one LDS round, riding on the group barriers) four groups before its first DMA is due;
+//   * every wave issues the same static sequence of DMAs (2 per group, 1 per tile for the map), so the wait at the top of a group
+//     is COUNTED (s_waitcnt vmcnt(2 (R - 2)): everything younger than the group stays in flight) and one s_barrier per group orders
+//     both the arrival of a group and the release of the slot it overwrites.  LDS-DMA and ordinary vector memory operations do
+//     not retire in order relative to each other (kernels_rectdma.hip): the only other vector memory operations are the output
+//     stores, which are never waited for (an outstanding one merely makes a wait longer);
+//   * R = 3: 52 KB of LDS, three workgroups per CU (80 VGPRs).
+// Arithmetic, order and therefore results are the gather form's, bit for bit (tests/test_mfn_extension.py); a tile whose box
+// exceeds 80 x 24 elements is marked (valid bytes 0xFE) and decoded by mfn_rect_fix_kernel's gather code in a second launch.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kDmaGroupChunks = kTileG * kBoxChunks;                       // 960 16-byte chunks per group
+constexpr int kDmaGroupBytes = kDmaGroupChunks * 16;
+constexpr int kDmaMapXyBytes = kTileW * kTileH * 4, kDmaMapFrBytes = kTileW * kTileH * 2;
+constexpr unsigned kMfnDmaInvalid = 0xFFFFFFF0u;                           // beyond every descriptor's range: loads 0
+static_assert(kTileNT == 512 && kDmaGroupChunks > 512 && kDmaGroupChunks <= 1024 - 64, "two DMAs per wave and group, the last wave's second one is a dummy");
+static_assert(kDmaMapXyBytes == 4 * 1024 && kDmaMapFrBytes == 2 * 1024, "map DMAs: waves 0-3 the xy entries, 4-5 the fractions, 6-7 dummies");
+
+__device__ __forceinline__ void mfn_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned soff)
+{
+    unsigned keep;       // (M0 carries the LDS base and is compiler-reserved: saved and restored inside the one statement that uses it)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst)), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+template <int N> __device__ __forceinline__ void mfn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+constexpr unsigned kMfnDeferred = 0x80000000u;                             // okm of a tile the DMA kernel leaves to mfn_rect_fix_kernel
+constexpr unsigned kMfnDeferredByte = 0xFEu;                               // ... and the valid byte its live pixels carry until then (never a result)
+
+struct MfnDmaArgs {
+    const uint16_t *base; unsigned stride_bytes, total_bytes;               // the contiguous stack (MfnStridedArg)
+    const int16_t *map_xy; const uint16_t *map_frac; unsigned map_px;       // the maps and their pixel count (descriptor ranges)
+};
+
+template <int R>
+__global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel(MfnDmaArgs arg, MfnTrigN<8> tr, int pitch, int W, int H, float black_thr,
+                                                                                 int row0, int rows, int src_row0, int src_rows, int tiles_x,
+                                                                                 float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    constexpr int kRing = R * kDmaGroupBytes, kOffXy = kRing, kOffFr = kOffXy + kDmaMapXyBytes, kOffDump = kOffFr + kDmaMapFrBytes;
+    constexpr int kWait = 2 * (R - 2);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kOffDump + 1024];
+    __shared__ int red[kTileNW][4];
+    const MfnStridedPlanes src{__builtin_amdgcn_make_buffer_rsrc((void *)arg.base, 0, (int)arg.total_bytes, 0x00020000), arg.stride_bytes};
+    const __amdgpu_buffer_rsrc_t rs_xy = __builtin_amdgcn_make_buffer_rsrc((void *)arg.map_xy, 0, (int)(arg.map_px * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_fr = __builtin_amdgcn_make_buffer_rsrc((void *)arg.map_frac, 0, (int)(arg.map_px * 2u), 0x00020000);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tiles_y = (rows + kTileH - 1) / kTileH, ntiles = tiles_x * tiles_y;
+    const unsigned nb = gridDim.x, per = (nb + 7) / 8;
+    unsigned vb = (blockIdx.x % 8) * per + blockIdx.x / 8;   // XCD-banded tile order (workgroup b runs on XCD b % 8)
+    if (nb % 8 != 0) vb = blockIdx.x;
+
+    // this thread's two chunks of a group: id = threadIdx (+ 512) -> (plane of the group, box row, 16-byte column); ids >= 960: the dump
+    int cpg[2], crow[2], ccol[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int id = (int)threadIdx.x + kTileNT * i, pg = id / kBoxChunks, w = id - pg * kBoxChunks;
+        cpg[i] = pg; crow[i] = w / (kBoxW / 8); ccol[i] = w - crow[i] * (kBoxW / 8);
+    }
+    const unsigned dstA = (unsigned)(wv * 1024), dstB = wv == kTileNW - 1 ? ~0u : (unsigned)(kTileNT * 16 + wv * 1024);   // slot-relative (~0: dump)
+
+    struct Box { int x0, y0, bw, bh; bool dma; bool fits; };   // bw / bh: the box in elements (0: nothing to fetch); dma: fetch it; fits: decode from LDS
+    // vector offsets of the thread's two chunks of a group of `box` (plane 0 of the group; the plane group is the scalar offset)
+    auto chunk_offsets = [&](const Box &b, unsigned vo[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int gy = b.y0 + crow[i], gx = b.x0 + 8 * ccol[i];
+            const bool in = b.dma && cpg[i] < kTileG && crow[i] < b.bh && 8 * ccol[i] < b.bw && (unsigned)gy < (unsigned)H &&
+                            (unsigned)(gy - src_row0) < (unsigned)src_rows && (unsigned)gx < (unsigned)W;
+            vo[i] = in ? (unsigned)(((gy - src_row0) * pitch + gx) * 2) + (unsigned)cpg[i] * src.stride_bytes : kMfnDmaInvalid;
+        }
+    };
+    // the two DMAs of one group: planes first .. first + count - 1 into ring slot `slot`
+    auto issue_group = [&](const unsigned vo[2], int first, int count, int slot) {
+        const unsigned sb = lds0 + (unsigned)(slot * kDmaGroupBytes);
+        const unsigned a = cpg[0] < count ? vo[0] : kMfnDmaInvalid, b = cpg[1] < count ? vo[1] : kMfnDmaInvalid;
+        mfn_dma16(a, src.rsrc, sb + dstA, (unsigned)first * src.stride_bytes);
+        mfn_dma16(b, src.rsrc, dstB == ~0u ? lds0 + (unsigned)kOffDump : sb + dstB, (unsigned)first * src.stride_bytes);
+    };
+    // the map entries of tile t (none beyond the last tile): one DMA per wave
+    auto issue_map = [&](int t) {
+        const bool on = t < ntiles;
+        const int ty = on ? t / tiles_x : 0, tx = on ? t - ty * tiles_x : 0;
+        if (wv < 4) {                                     // xy: 16 rows x 16 chunks of 4 pixels; this lane: chunk wv * 64 + lane
+            const int id = wv * 64 + lane, r = id >> 4, c = id & 15, brow = ty * kTileH + r, col = tx * kTileW + 4 * c;
+            const bool in = on && brow < rows && col < W;
+            mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 4) : kMfnDmaInvalid, rs_xy, lds0 + (unsigned)(kOffXy + wv * 1024), 0u);
+        } else if (wv < 6) {                              // fractions: 16 rows x 8 chunks of 8 pixels
+            const int id = (wv - 4) * 64 + lane, r = id >> 3, c = id & 7, brow = ty * kTileH + r, col = tx * kTileW + 8 * c;
+            const bool in = on && brow < rows && col < W;
+            mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 2) : kMfnDmaInvalid, rs_fr, lds0 + (unsigned)(kOffFr + (wv - 4) * 1024), 0u);
+        } else
+            mfn_dma16(kMfnDmaInvalid, rs_fr, lds0 + (unsigned)kOffDump, 0u);
+    };
+    // this thread's pixel j of the staged tile: column lane, tile row wv + 8 j
+    auto staged_px = [&](int j, int &sx, int &sy, unsigned &fr) {
+        const int e = (wv + kTileNW * j) * kTileW + lane;
+        const unsigned xy = *reinterpret_cast<const unsigned *>(smem + kOffXy + 4 * e);
+        sx = (int)(short)(xy & 0xFFFFu); sy = (int)xy >> 16;
+        fr = (unsigned)*reinterpret_cast<const unsigned short *>(smem + kOffFr + 2 * e) & 1023u;
+    };
+    // the wave's share of the staged tile's bounding box -> red[wv]
+    auto reduce_staged = [&](int t) {
+        const bool on = t < ntiles;
+        const int ty = on ? t / tiles_x : 0, tx = on ? t - ty * tiles_x : 0, col = tx * kTileW + lane;
+        int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) {
+            int sx, sy; unsigned fr;
+            staged_px(j, sx, sy, fr);
+            const bool live = on && ty * kTileH + wv + kTileNW * j < rows && col < W;
+            if (live && !(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {       // footprints completely outside read 0
+                mnx = sx < mnx ? sx : mnx; mxx = sx > mxx ? sx : mxx; mny = sy < mny ? sy : mny; mxy = sy > mxy ? sy : mxy;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            int v;
+            v = __shfl_xor(mnx, d); mnx = v < mnx ? v : mnx;
+            v = __shfl_xor(mxx, d); mxx = v > mxx ? v : mxx;
+            v = __shfl_xor(mny, d); mny = v < mny ? v : mny;
+            v = __shfl_xor(mxy, d); mxy = v > mxy ? v : mxy;
+        }
+        if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
+    };
+    auto box_from_red = [&]() -> Box {
+        int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
+#pragma unroll
+        for (int w = 0; w < kTileNW; w++) {
+            mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
+            mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
+        }
+        mnx = __builtin_amdgcn_readfirstlane(mnx); mxx = __builtin_amdgcn_readfirstlane(mxx);      // (wave-uniform: scalar registers)
+        mny = __builtin_amdgcn_readfirstlane(mny); mxy = __builtin_amdgcn_readfirstlane(mxy);
+        Box b;
+        const bool empty = mnx > mxx;                     // the tile samples nothing
+        b.x0 = empty ? 0 : (mnx & ~7); b.y0 = empty ? 0 : mny;
+        b.bw = empty ? 0 : (mxx + 2) - b.x0; b.bh = empty ? 0 : (mxy + 2) - b.y0;
+        b.fits = empty || ((mxx + 1) - b.x0 < kBoxW && (mxy + 1) - b.y0 < kBoxH);
+        b.dma = !empty && b.fits;
+        return b;
+    };
+
+    // prologue: the first tile's map, its box, its first R - 1 groups
+    int t = (int)vb;
+    issue_map(t);
+    mfn_wait_vm<0>();
+    __syncthreads();
+    reduce_staged(t);
+    __syncthreads();
+    Box cur = box_from_red(), nxt = cur;
+    unsigned cvo[2], nvo[2];
+    chunk_offsets(cur, cvo);
+    nvo[0] = nvo[1] = kMfnDmaInvalid;
+    issue_group(cvo, 0, 2, 0);
+#pragma unroll
+    for (int g = 1; g < R - 1; g++) issue_group(cvo, 2 + 4 * (g - 1), 4, g);
+    int s0 = 0;                                           // ring slot of this tile's group 0
+    // a tile's results are stored at the top of the NEXT tile's first step, behind that step's DMAs: vmcnt counts stores too, and
+    // the counted wait that follows them is a whole group away
+    float pend_out[kTilePx] = {};
+    unsigned pend_okm = 0;
+    int pend_t = -1;
+    auto flush = [&]() {
+        if (pend_t < 0) return;
+        const int py = pend_t / tiles_x, px = pend_t - py * tiles_x, pcol = px * kTileW + lane;
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) {
+            const int brow = py * kTileH + wv + kTileNW * j;
+            if (!(brow < rows && pcol < W)) continue;
+            const size_t oo = (size_t)brow * W + pcol;
+            phase[oo] = pend_out[j];
+            valid[oo] = pend_okm == kMfnDeferred ? (uint8_t)kMfnDeferredByte : (uint8_t)((pend_okm >> j) & 1u);
+        }
+        pend_t = -1;
+    };
+
+    const float mod2 = 4.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2
+#pragma unroll 1
+    for (; t < ntiles; t += (int)nb) {
+        const int tn = t + (int)nb;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x, col = tx * kTileW + lane;
+        // this thread's pixels from the staged map entries
+        int sx[kTilePx], sy[kTilePx];
+        unsigned fr[kTilePx];
+        bool live[kTilePx];
+        unsigned ta[kTilePx], tsh[kTilePx];
+        h16x2 w0[kTilePx], w1[kTilePx];
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) {
+            staged_px(j, sx[j], sy[j], fr[j]);
+            live[j] = ty * kTileH + wv + kTileNW * j < rows && col < W;
+            const unsigned fx = fr[j] & 31u, fy = fr[j] >> 5;
+            w0[j] = h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))};
+            w1[j] = h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)};
+            const bool touch = live[j] && !(sx[j] >= W || sx[j] + 1 < 0 || sy[j] >= H || sy[j] + 1 < 0);
+            const unsigned b = touch && cur.fits ? (unsigned)((sy[j] - cur.y0) * kBoxRowBytes + (sx[j] - cur.x0) * 2) : 0u;
+            ta[j] = b & ~3u; tsh[j] = (b & 2u) * 8u;
+            if (!touch) { w0[j] = h16x2{(_Float16)0.0f, (_Float16)0.0f}; w1[j] = w0[j]; }       // every sample 0
+        }
+        float out[kTilePx];
+        unsigned okm = 0;                                 // bit j: pixel j valid
+        if (!cur.fits) {                                  // (block-uniform) a box beyond the LDS image: the tile is left to the fix-up pass
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) out[j] = 0.0f;
+            okm = kMfnDeferred;                               // (every live pixel's valid byte becomes the marker)
+        }
+        float wh[kTilePx], bk[kTilePx], L0[kTilePx], L1[kTilePx], L2[kTilePx], fin[kTilePx], S[kTilePx], C[kTilePx];
+        bool ok[kTilePx];
+        // the rectified samples (x 1024) of plane image `img` for the thread's pixels
+        auto samples = [&](const unsigned char *img, float smp[kTilePx]) {
+            asm volatile("" ::: "memory");                // (one plane's tap reads at a time)
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) {
+                const unsigned *r0 = reinterpret_cast<const unsigned *>(img + ta[j]);
+                const unsigned *r1 = reinterpret_cast<const unsigned *>(img + ta[j] + kBoxRowBytes);
+                const unsigned u0 = __builtin_amdgcn_alignbit(r0[1], r0[0], tsh[j]);
+                const unsigned u1 = __builtin_amdgcn_alignbit(r1[1], r1[0], tsh[j]);
+                const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[j], 0.0f, false);
+                smp[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[j], a, false);
+            }
+        };
+        // one step of the group stream: group g of this tile has landed and is decoded; group g + R - 1 (of this tile or the next) is issued
+        auto step_top = [&](int g) {
+            mfn_wait_vm<kWait>();
+            __syncthreads();
+            if (g == 1) issue_map(tn);                    // (before the step's group DMAs: the counted wait stays exact)
+            if (g == 5) { nxt = box_from_red(); chunk_offsets(nxt, nvo); }
+            const int gi = g + R - 1;                     // the group to issue
+            int slot = s0 + gi; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0;
+            if (gi < 9) issue_group(cvo, gi == 0 ? 0 : 2 + 4 * (gi - 1), gi == 0 ? 2 : 4, slot);
+            else issue_group(nvo, gi == 9 ? 0 : 2 + 4 * (gi - 10), gi == 9 ? 2 : 4, slot);
+            if (g == 0) flush();
+            if (g == 4) reduce_staged(tn);
+        };
+        auto slot_of = [&](int g) -> const unsigned char * {
+            int slot = s0 + g; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0;
+            return smem + slot * kDmaGroupBytes;
+        };
+        step_top(0);
+        if (cur.fits) {
+            const unsigned char *img = slot_of(0);
+            float smp[kTilePx];
+            samples(img, smp);
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) wh[j] = smp[j];
+            samples(img + kBoxPlaneBytes, smp);
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) { bk[j] = smp[j]; ok[j] = wh[j] - bk[j] > thr1024; L0[j] = L1[j] = L2[j] = fin[j] = 0.0f; }
+        }
+#pragma unroll 1
+        for (int f = 0; f < 4; f++) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                const int g = 1 + 2 * f + hf;
+                step_top(g);
+                if (cur.fits) {
+                    const unsigned char *img = slot_of(g);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float smp[kTilePx];
+                        samples(img + k * kBoxPlaneBytes, smp);
+#pragma unroll
+                        for (int j = 0; j < kTilePx; j++) {
+                            if (hf == 0 && k == 0) S[j] = C[j] = 0.0f;
+                            S[j] += smp[j] * tr.sn[4 * hf + k]; C[j] += smp[j] * tr.cs[4 * hf + k];
+                        }
+                    }
+                }
+            }
+            if (cur.fits) {
+#pragma unroll
+                for (int j = 0; j < kTilePx; j++) {
+                    float p = atan2f(-S[j], C[j]);
+                    if (p < 0.0f) p += kTrue2PI;
+                    ok[j] = ok[j] && (S[j] * S[j] + C[j] * C[j] > mod2);
+                    // the cascade of neighbouring differences, streamed (mfn_rect_tile_kernel)
+                    auto wrapd = [](float a, float b) { return (a > b) ? (a - b) : (a - b + kTrue2PI); };
+                    const float d1 = wrapd(L0[j], p);                    // (f >= 1)
+                    const float d2 = wrapd(L1[j], d1);                   // (f >= 2)
+                    const float d3 = wrapd(L2[j], d2);                   // (f == 3)
+                    fin[j] = f == 3 ? d3 : fin[j];
+                    L2[j] = f >= 2 ? d2 : L2[j];
+                    L1[j] = f >= 1 ? d1 : L1[j];
+                    L0[j] = p;
+                }
+            }
+        }
+        if (cur.fits) {
+#pragma unroll
+            for (int j = 0; j < kTilePx; j++) {
+                out[j] = (wh[j] - bk[j] > thr1024) ? fin[j] / kTrue2PI * 255 : 0.0f;
+                okm |= (ok[j] ? 1u : 0u) << j;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kTilePx; j++) pend_out[j] = out[j];
+        pend_okm = okm; pend_t = t;
+        cur = nxt; cvo[0] = nvo[0]; cvo[1] = nvo[1];
+        s0 += 9 % R; s0 -= s0 >= R ? R : 0;
+    }
+    flush();
+    mfn_wait_vm<0>();                                     // the dummy DMAs behind the last tile must land before the LDS is released
+}
+
+// second pass of the LDS-DMA form: the tiles it marked (boxes beyond the LDS image; none on BASELINE's rigs), by the gather code.
+// A workgroup looks at 64 tiles' marker bytes (the first live pixel of a tile is its upper left one) and decodes the marked ones.
+__global__ __launch_bounds__(256) void mfn_rect_fix_kernel(MfnStridedArg arg, MfnTrigN<8> tr, int pitch, int W, int H, float black_thr,
+                                                           const int16_t *__restrict__ map_xy, const uint16_t *__restrict__ map_frac,
+                                                           int row0, int rows, int src_row0, int src_rows, int tiles_x, int ntiles,
+                                                           float *__restrict__ phase, uint8_t *__restrict__ valid)
+{
+    const MfnStridedPlanes src{__builtin_amdgcn_make_buffer_rsrc((void *)arg.base, 0, (int)arg.total_bytes, 0x00020000), arg.stride_bytes};
+    __shared__ unsigned long long marked;
+    const int t0 = blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int t = t0 + (int)threadIdx.x;
+        bool m = false;
+        if (t < ntiles) {
+            const int ty = t / tiles_x, tx = t - ty * tiles_x;
+            m = valid[(size_t)(ty * kTileH) * W + tx * kTileW] == (uint8_t)kMfnDeferredByte;
+        }
+        const unsigned long long b = __ballot(m);
+        if (threadIdx.x == 0) marked = b;
+    }
+    __syncthreads();
+    unsigned long long todo = marked;
+    while (todo) {
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int t = t0 + i, ty = t / tiles_x, tx = t - ty * tiles_x;
+#pragma unroll 1
+        for (int e = (int)threadIdx.x; e < kTileW * kTileH; e += 256) {
+            const int brow = ty * kTileH + e / kTileW, col = tx * kTileW + e % kTileW;
+            if (!(brow < rows && col < W)) continue;
+            const size_t m = (size_t)(brow + row0) * W + col;
+            const int sx = map_xy[2 * m], sy = map_xy[2 * m + 1];
+            const unsigned fr = map_frac[m] & 1023u, fx = fr & 31u, fy = fr >> 5;
+            const h16x2 gw0[1] = {h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))}};
+            const h16x2 gw1[1] = {h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)}};
+            const bool bx0 = (unsigned)sx < (unsigned)W, bx1 = (unsigned)(sx + 1) < (unsigned)W;
+            const bool by0 = (unsigned)sy < (unsigned)H && (unsigned)(sy - src_row0) < (unsigned)src_rows;
+            const bool by1 = (unsigned)(sy + 1) < (unsigned)H && (unsigned)(sy + 1 - src_row0) < (unsigned)src_rows;
+            const unsigned inb[1] = {(bx0 && by0 ? 1u : 0u) | (bx1 && by0 ? 2u : 0u) | (bx0 && by1 ? 4u : 0u) | (bx1 && by1 ? 8u : 0u)};
+            const unsigned off[1] = {(unsigned)((sy - src_row0) * pitch + sx)};
+            float o1[1] = {0.0f};
+            unsigned vw1 = 0;
+            if (src_rows > 0) mfn_rect_quad<1, 4, 8, false>(src, tr, 4, 8, (unsigned)pitch, black_thr, off, inb, gw0, gw1, o1, vw1);
+            const size_t oo = (size_t)brow * W + col;
+            phase[oo] = o1[0];
+            valid[oo] = (uint8_t)(vw1 & 1u);
+        }
+    }
+}
+
 // source rows [lo, hi] that destination rows [row0, row0 + rows) read through a map (taps sy and sy + 1, clipped to the image);
 // out[0] = min sy, out[1] = max sy + 1 over the pixels whose footprint touches the image (initialised by the launcher)
 __global__ __launch_bounds__(256) void map_source_rows_kernel(const int16_t *__restrict__ map_xy, int W, int H, int row0, int rows,
@@ -608,7 +972,24 @@ hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int
     SLR_LAUNCH((mfn_rect_decode_kernel<V, FS, NS, decltype(SRC)>), dim3(blocks ? blocks : 8), dim3(256), 0, s, SRC, TR, n_freq, n_step, \
                pitch, W, H, black_thr, map_xy, map_frac, row0, rows, src_row0, src_rows, phase, valid)
     if (spec && strided && W % 8 == 0 && ((uintptr_t)planes[0] % 16) == 0 && ((size_t)pitch * 2) % 16 == 0 && (stride * 2) % 16 == 0 &&
-        !tl_debug.no_tiled_map) {                            // the LDS-tiled form (SLR_OPT_DEBUG_FLAGS bit 0 keeps the gather form: tests)
+        !tl_debug.no_tiled_map && !tl_debug.no_buffer_form && (uintptr_t)map_xy % 16 == 0 && (uintptr_t)map_frac % 16 == 0 &&
+        (size_t)W * H * 4 < (1ull << 31)) {                  // the LDS-DMA form (SLR_OPT_DEBUG_FLAGS bit 1: the register-staged tile form)
+        const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
+        const bool ring4 = tl_debug.gray_small_tiles;        // (SLR_OPT_DEBUG_FLAGS bit 4: a ring of 4 groups, two workgroups per CU)
+        const int per_cu = ring4 ? 2 : 3;
+        unsigned tb = (unsigned)(tiles_x * tiles_y < 256 * per_cu ? tiles_x * tiles_y : 256 * per_cu);
+        tb = (tb + 7u) & ~7u;
+        const MfnDmaArgs da{planes[0], (unsigned)(stride * 2), (unsigned)span, map_xy, map_frac, (unsigned)((size_t)W * H)};
+        if (ring4) SLR_LAUNCH(mfn_rect_dma_kernel<4>, dim3(tb ? tb : 8), dim3(kTileNT), 0, s, da, tr8, pitch, W, H, black_thr, row0, rows,
+                              src_row0, src_rows, tiles_x, phase, valid);
+        else SLR_LAUNCH(mfn_rect_dma_kernel<3>, dim3(tb ? tb : 8), dim3(kTileNT), 0, s, da, tr8, pitch, W, H, black_thr, row0, rows,
+                        src_row0, src_rows, tiles_x, phase, valid);
+        const int ntiles = tiles_x * tiles_y;
+        SLR_LAUNCH(mfn_rect_fix_kernel, dim3((ntiles + 63) / 64), dim3(256), 0, s, sp, tr8, pitch, W, H, black_thr, map_xy, map_frac, row0, rows,
+                   src_row0, src_rows, tiles_x, ntiles, phase, valid);
+    }
+    else if (spec && strided && W % 8 == 0 && ((uintptr_t)planes[0] % 16) == 0 && ((size_t)pitch * 2) % 16 == 0 && (stride * 2) % 16 == 0 &&
+        !tl_debug.no_tiled_map) {                            // the register-staged LDS-tiled form (bit 0 keeps the gather form: tests)
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
         unsigned tb = (unsigned)(tiles_x * tiles_y < 8 * 256 * 4 ? tiles_x * tiles_y : 8 * 256 * 4);
         tb = (tb + 7u) & ~7u;
