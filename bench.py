@@ -491,7 +491,7 @@ def main_mfn(args):
         roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": k0["frac_hbm_peak"], "traffic": None, "avg_launch_us": k0["avg_us"],
                     "alg_bytes_per_launch": ALG_BYTES[k0["name"]] * W * rows,
-                    "form": "per-pixel gather (L1 / L2 serve the taps); the LDS-tiled form of the u8 path is not built for fp16"}
+                    "form": "LDS-DMA form (round 4): 64 x 16 tiles, source boxes by buffer_load ... lds into a ring of 3 four-plane groups streamed across tiles, counted vmcnt waits; bit-identical to the per-pixel gather form"}
     if rank == 0:
         print(json.dumps({
             "metric": "Mpixels/s decode+unwrap+triangulate, 4096x3000 stereo, 1/2/4/8 GPU", "value": round(value, 2), "unit": "Mpix/s",

@@ -24,10 +24,11 @@ for name, path in variants:
     capi.load_library()
     ctx = slr.Context(0)
     ctx.set_calibration(rig["calib"]); synth.install_verged_maps(ctx, rig, W, H)
-    for rep in range(8):
-        fl = (0, 16, 2, 1)[rep & 3]                            # LDS-DMA ring of 3 / of 4, register-staged tiles, per-pixel gather
+    forms = [int(x) for x in os.environ.get("MFN_FORMS", "0,16,2,1").split(",")]
+    for rep in range(2 * len(forms)):
+        fl = forms[rep % len(forms)]                           # 0 / 16: LDS-DMA ring of 3 / of 4, 2: register-staged tiles, 1: per-pixel gather
         ctx.set_option(capi.OPT_DEBUG_FLAGS, fl)
-        line = [{0: "dma-3 ", 16: "dma-4 ", 2: "tiled ", 1: "gather"}[fl]]
+        line = [{0: "dma-3 ", 16: "dma-4 ", 8: "dma-3/256", 24: "dma-4/256", 2: "tiled ", 1: "gather"}[fl]]
         for cam in range(2):
             ctx.mfn_rectify_decode(cam, st[cam], 4, 8, 40.0, phase=ph, valid=vd)
             ctx.synchronize(); ctx.timer_begin()

@@ -18,6 +18,10 @@
 
 #pragma clang diagnostic ignored "-Wpass-failed"   // the run-time (FS = NS = 0) variant cannot fully unroll its plane loops
 
+#if !defined(SLR_EXPERIMENTS) && defined(SLR_MFN_ABL)
+#error "SLR_MFN_ABL is an experiment switch: build with -DSLR_EXPERIMENTS"
+#endif
+
 namespace slr {
 
 constexpr float kTruePI = 3.14159265358979323846f;
@@ -557,7 +561,9 @@ __global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg
 //     both the arrival of a group and the release of the slot it overwrites.  LDS-DMA and ordinary vector memory operations do
 //     not retire in order relative to each other (kernels_rectdma.hip): the only other vector memory operations are the output
 //     stores, which are never waited for (an outstanding one merely makes a wait longer);
-//   * R = 3: 52 KB of LDS, three workgroups per CU (80 VGPRs).
+//   * R = 3: 52 KB of LDS, three workgroups per CU; 256 threads x 4 pixels (a wave's rows wv, wv + 4, ..) beat 512 x 2 by 4 %: half the
+//     barriers and per-tile set-up per pixel.  Ablations (profiles/exp/r04): no source traffic 1.22 ms, no tap reads / blend 1.12-1.2,
+//     neither 0.90, also without the group barriers 0.55 -- the DFT + four atan2f + per-tile set-up alone are 40 % of the kernel.
 // Arithmetic, order and therefore results are the gather form's, bit for bit (tests/test_mfn_extension.py); a tile whose box
 // exceeds 80 x 24 elements is marked (valid bytes 0xFE) and decoded by mfn_rect_fix_kernel's gather code in a second launch.
 // ------------------------------------------------------------------------------------------------------
@@ -565,7 +571,7 @@ constexpr int kDmaGroupChunks = kTileG * kBoxChunks;                       // 96
 constexpr int kDmaGroupBytes = kDmaGroupChunks * 16;
 constexpr int kDmaMapXyBytes = kTileW * kTileH * 4, kDmaMapFrBytes = kTileW * kTileH * 2;
 constexpr unsigned kMfnDmaInvalid = 0xFFFFFFF0u;                           // beyond every descriptor's range: loads 0
-static_assert(kTileNT == 512 && kDmaGroupChunks > 512 && kDmaGroupChunks <= 1024 - 64, "two DMAs per wave and group, the last wave's second one is a dummy");
+static_assert(kDmaGroupChunks % 64 == 0 && kDmaGroupChunks <= 1024 - 64, "whole waves of chunks; the DMAs beyond them go to the dump");
 static_assert(kDmaMapXyBytes == 4 * 1024 && kDmaMapFrBytes == 2 * 1024, "map DMAs: waves 0-3 the xy entries, 4-5 the fractions, 6-7 dummies");
 
 __device__ __forceinline__ void mfn_dma16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned lds_dst, unsigned soff)
@@ -584,15 +590,19 @@ struct MfnDmaArgs {
     const int16_t *map_xy; const uint16_t *map_frac; unsigned map_px;       // the maps and their pixel count (descriptor ranges)
 };
 
-template <int R>
-__global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel(MfnDmaArgs arg, MfnTrigN<8> tr, int pitch, int W, int H, float black_thr,
+template <int R, int NT>
+__global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect_dma_kernel(MfnDmaArgs arg, MfnTrigN<8> tr, int pitch, int W, int H, float black_thr,
                                                                                  int row0, int rows, int src_row0, int src_rows, int tiles_x,
                                                                                  float *__restrict__ phase, uint8_t *__restrict__ valid)
 {
     constexpr int kRing = R * kDmaGroupBytes, kOffXy = kRing, kOffFr = kOffXy + kDmaMapXyBytes, kOffDump = kOffFr + kDmaMapFrBytes;
-    constexpr int kWait = 2 * (R - 2);
+    constexpr int kNW = NT / 64, kPX = kTileW * kTileH / NT;          // waves; pixels per thread (tile rows wv + kNW j)
+    constexpr int kDPG = (kDmaGroupChunks + NT - 1) / NT;              // DMAs per wave and group (chunk ids >= 960 go to the dump)
+    constexpr int kMPW = 8 / kNW;                                      // map DMAs per wave and tile (8 in all: 4 xy, 2 fractions, 2 dummies)
+    constexpr int kWait = kDPG * (R - 2);
+    static_assert(NT == 512 || NT == 256, "8 or 4 waves");
     __shared__ __attribute__((aligned(16))) unsigned char smem[kOffDump + 1024];
-    __shared__ int red[kTileNW][4];
+    __shared__ int red[kNW][4];
     const MfnStridedPlanes src{__builtin_amdgcn_make_buffer_rsrc((void *)arg.base, 0, (int)arg.total_bytes, 0x00020000), arg.stride_bytes};
     const __amdgpu_buffer_rsrc_t rs_xy = __builtin_amdgcn_make_buffer_rsrc((void *)arg.map_xy, 0, (int)(arg.map_px * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_fr = __builtin_amdgcn_make_buffer_rsrc((void *)arg.map_frac, 0, (int)(arg.map_px * 2u), 0x00020000);
@@ -604,50 +614,60 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
     if (nb % 8 != 0) vb = blockIdx.x;
 
     // this thread's two chunks of a group: id = threadIdx (+ 512) -> (plane of the group, box row, 16-byte column); ids >= 960: the dump
-    int cpg[2], crow[2], ccol[2];
+    int cpg[kDPG], crow[kDPG], ccol[kDPG];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int id = (int)threadIdx.x + kTileNT * i, pg = id / kBoxChunks, w = id - pg * kBoxChunks;
+    for (int i = 0; i < kDPG; i++) {
+        const int id = (int)threadIdx.x + NT * i, pg = id / kBoxChunks, w = id - pg * kBoxChunks;
         cpg[i] = pg; crow[i] = w / (kBoxW / 8); ccol[i] = w - crow[i] * (kBoxW / 8);
     }
-    const unsigned dstA = (unsigned)(wv * 1024), dstB = wv == kTileNW - 1 ? ~0u : (unsigned)(kTileNT * 16 + wv * 1024);   // slot-relative (~0: dump)
 
     struct Box { int x0, y0, bw, bh; bool dma; bool fits; };   // bw / bh: the box in elements (0: nothing to fetch); dma: fetch it; fits: decode from LDS
     // vector offsets of the thread's two chunks of a group of `box` (plane 0 of the group; the plane group is the scalar offset)
-    auto chunk_offsets = [&](const Box &b, unsigned vo[2]) {
+    auto chunk_offsets = [&](const Box &b, unsigned vo[kDPG]) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < kDPG; i++) {
             const int gy = b.y0 + crow[i], gx = b.x0 + 8 * ccol[i];
             const bool in = b.dma && cpg[i] < kTileG && crow[i] < b.bh && 8 * ccol[i] < b.bw && (unsigned)gy < (unsigned)H &&
                             (unsigned)(gy - src_row0) < (unsigned)src_rows && (unsigned)gx < (unsigned)W;
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 1)
+            vo[i] = in && gy == -12345 ? 0u : kMfnDmaInvalid;        // (ablation: no source traffic, the DMAs write zeros)
+#else
             vo[i] = in ? (unsigned)(((gy - src_row0) * pitch + gx) * 2) + (unsigned)cpg[i] * src.stride_bytes : kMfnDmaInvalid;
+#endif
         }
     };
     // the two DMAs of one group: planes first .. first + count - 1 into ring slot `slot`
-    auto issue_group = [&](const unsigned vo[2], int first, int count, int slot) {
+    auto issue_group = [&](const unsigned vo[kDPG], int first, int count, int slot) {
         const unsigned sb = lds0 + (unsigned)(slot * kDmaGroupBytes);
-        const unsigned a = cpg[0] < count ? vo[0] : kMfnDmaInvalid, b = cpg[1] < count ? vo[1] : kMfnDmaInvalid;
-        mfn_dma16(a, src.rsrc, sb + dstA, (unsigned)first * src.stride_bytes);
-        mfn_dma16(b, src.rsrc, dstB == ~0u ? lds0 + (unsigned)kOffDump : sb + dstB, (unsigned)first * src.stride_bytes);
+#pragma unroll
+        for (int i = 0; i < kDPG; i++) {
+            const int cb = i * NT + wv * 64;              // the wave's first chunk of this DMA (wave-uniform)
+            mfn_dma16(cpg[i] < count ? vo[i] : kMfnDmaInvalid, src.rsrc, cb >= kDmaGroupChunks ? lds0 + (unsigned)kOffDump : sb + (unsigned)(cb * 16),
+                      (unsigned)first * src.stride_bytes);
+        }
     };
     // the map entries of tile t (none beyond the last tile): one DMA per wave
     auto issue_map = [&](int t) {
         const bool on = t < ntiles;
         const int ty = on ? t / tiles_x : 0, tx = on ? t - ty * tiles_x : 0;
-        if (wv < 4) {                                     // xy: 16 rows x 16 chunks of 4 pixels; this lane: chunk wv * 64 + lane
-            const int id = wv * 64 + lane, r = id >> 4, c = id & 15, brow = ty * kTileH + r, col = tx * kTileW + 4 * c;
-            const bool in = on && brow < rows && col < W;
-            mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 4) : kMfnDmaInvalid, rs_xy, lds0 + (unsigned)(kOffXy + wv * 1024), 0u);
-        } else if (wv < 6) {                              // fractions: 16 rows x 8 chunks of 8 pixels
-            const int id = (wv - 4) * 64 + lane, r = id >> 3, c = id & 7, brow = ty * kTileH + r, col = tx * kTileW + 8 * c;
-            const bool in = on && brow < rows && col < W;
-            mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 2) : kMfnDmaInvalid, rs_fr, lds0 + (unsigned)(kOffFr + (wv - 4) * 1024), 0u);
-        } else
-            mfn_dma16(kMfnDmaInvalid, rs_fr, lds0 + (unsigned)kOffDump, 0u);
+#pragma unroll
+        for (int i = 0; i < kMPW; i++) {
+            const int m = wv * kMPW + i;                  // 0-3: the xy entries (16 rows x 16 chunks of 4 pixels), 4-5: the fractions (16 rows x 8 chunks of 8 pixels), 6-7: dummies
+            if (m < 4) {
+                const int id = m * 64 + lane, r = id >> 4, c = id & 15, brow = ty * kTileH + r, col = tx * kTileW + 4 * c;
+                const bool in = on && brow < rows && col < W;
+                mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 4) : kMfnDmaInvalid, rs_xy, lds0 + (unsigned)(kOffXy + m * 1024), 0u);
+            } else if (m < 6) {
+                const int id = (m - 4) * 64 + lane, r = id >> 3, c = id & 7, brow = ty * kTileH + r, col = tx * kTileW + 8 * c;
+                const bool in = on && brow < rows && col < W;
+                mfn_dma16(in ? (unsigned)(((size_t)(brow + row0) * W + col) * 2) : kMfnDmaInvalid, rs_fr, lds0 + (unsigned)(kOffFr + (m - 4) * 1024), 0u);
+            } else
+                mfn_dma16(kMfnDmaInvalid, rs_fr, lds0 + (unsigned)kOffDump, 0u);
+        }
     };
     // this thread's pixel j of the staged tile: column lane, tile row wv + 8 j
     auto staged_px = [&](int j, int &sx, int &sy, unsigned &fr) {
-        const int e = (wv + kTileNW * j) * kTileW + lane;
+        const int e = (wv + kNW * j) * kTileW + lane;
         const unsigned xy = *reinterpret_cast<const unsigned *>(smem + kOffXy + 4 * e);
         sx = (int)(short)(xy & 0xFFFFu); sy = (int)xy >> 16;
         fr = (unsigned)*reinterpret_cast<const unsigned short *>(smem + kOffFr + 2 * e) & 1023u;
@@ -658,10 +678,10 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
         const int ty = on ? t / tiles_x : 0, tx = on ? t - ty * tiles_x : 0, col = tx * kTileW + lane;
         int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
 #pragma unroll
-        for (int j = 0; j < kTilePx; j++) {
+        for (int j = 0; j < kPX; j++) {
             int sx, sy; unsigned fr;
             staged_px(j, sx, sy, fr);
-            const bool live = on && ty * kTileH + wv + kTileNW * j < rows && col < W;
+            const bool live = on && ty * kTileH + wv + kNW * j < rows && col < W;
             if (live && !(sx >= W || sx + 1 < 0 || sy >= H || sy + 1 < 0)) {       // footprints completely outside read 0
                 mnx = sx < mnx ? sx : mnx; mxx = sx > mxx ? sx : mxx; mny = sy < mny ? sy : mny; mxy = sy > mxy ? sy : mxy;
             }
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
     auto box_from_red = [&]() -> Box {
         int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
 #pragma unroll
-        for (int w = 0; w < kTileNW; w++) {
+        for (int w = 0; w < kNW; w++) {
             mnx = red[w][0] < mnx ? red[w][0] : mnx; mxx = red[w][1] > mxx ? red[w][1] : mxx;
             mny = red[w][2] < mny ? red[w][2] : mny; mxy = red[w][3] > mxy ? red[w][3] : mxy;
         }
@@ -702,26 +722,30 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
     reduce_staged(t);
     __syncthreads();
     Box cur = box_from_red(), nxt = cur;
-    unsigned cvo[2], nvo[2];
+    unsigned cvo[kDPG], nvo[kDPG];
     chunk_offsets(cur, cvo);
-    nvo[0] = nvo[1] = kMfnDmaInvalid;
+#pragma unroll
+    for (int i = 0; i < kDPG; i++) nvo[i] = kMfnDmaInvalid;
     issue_group(cvo, 0, 2, 0);
 #pragma unroll
     for (int g = 1; g < R - 1; g++) issue_group(cvo, 2 + 4 * (g - 1), 4, g);
     int s0 = 0;                                           // ring slot of this tile's group 0
     // a tile's results are stored at the top of the NEXT tile's first step, behind that step's DMAs: vmcnt counts stores too, and
     // the counted wait that follows them is a whole group away
-    float pend_out[kTilePx] = {};
+    float pend_out[kPX] = {};
     unsigned pend_okm = 0;
     int pend_t = -1;
     auto flush = [&]() {
         if (pend_t < 0) return;
         const int py = pend_t / tiles_x, px = pend_t - py * tiles_x, pcol = px * kTileW + lane;
 #pragma unroll
-        for (int j = 0; j < kTilePx; j++) {
-            const int brow = py * kTileH + wv + kTileNW * j;
+        for (int j = 0; j < kPX; j++) {
+            const int brow = py * kTileH + wv + kNW * j;
             if (!(brow < rows && pcol < W)) continue;
             const size_t oo = (size_t)brow * W + pcol;
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 4)
+            if (pend_out[j] != 1.2345e-30f) continue;              // (ablation: no output stores)
+#endif
             phase[oo] = pend_out[j];
             valid[oo] = pend_okm == kMfnDeferred ? (uint8_t)kMfnDeferredByte : (uint8_t)((pend_okm >> j) & 1u);
         }
@@ -734,15 +758,15 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
         const int tn = t + (int)nb;
         const int ty = t / tiles_x, tx = t - ty * tiles_x, col = tx * kTileW + lane;
         // this thread's pixels from the staged map entries
-        int sx[kTilePx], sy[kTilePx];
-        unsigned fr[kTilePx];
-        bool live[kTilePx];
-        unsigned ta[kTilePx], tsh[kTilePx];
-        h16x2 w0[kTilePx], w1[kTilePx];
+        int sx[kPX], sy[kPX];
+        unsigned fr[kPX];
+        bool live[kPX];
+        unsigned ta[kPX], tsh[kPX];
+        h16x2 w0[kPX], w1[kPX];
 #pragma unroll
-        for (int j = 0; j < kTilePx; j++) {
+        for (int j = 0; j < kPX; j++) {
             staged_px(j, sx[j], sy[j], fr[j]);
-            live[j] = ty * kTileH + wv + kTileNW * j < rows && col < W;
+            live[j] = ty * kTileH + wv + kNW * j < rows && col < W;
             const unsigned fx = fr[j] & 31u, fy = fr[j] >> 5;
             w0[j] = h16x2{(_Float16)(float)((32u - fx) * (32u - fy)), (_Float16)(float)(fx * (32u - fy))};
             w1[j] = h16x2{(_Float16)(float)((32u - fx) * fy), (_Float16)(float)(fx * fy)};
@@ -751,20 +775,27 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
             ta[j] = b & ~3u; tsh[j] = (b & 2u) * 8u;
             if (!touch) { w0[j] = h16x2{(_Float16)0.0f, (_Float16)0.0f}; w1[j] = w0[j]; }       // every sample 0
         }
-        float out[kTilePx];
+        float out[kPX];
         unsigned okm = 0;                                 // bit j: pixel j valid
         if (!cur.fits) {                                  // (block-uniform) a box beyond the LDS image: the tile is left to the fix-up pass
 #pragma unroll
-            for (int j = 0; j < kTilePx; j++) out[j] = 0.0f;
+            for (int j = 0; j < kPX; j++) out[j] = 0.0f;
             okm = kMfnDeferred;                               // (every live pixel's valid byte becomes the marker)
         }
-        float wh[kTilePx], bk[kTilePx], L0[kTilePx], L1[kTilePx], L2[kTilePx], fin[kTilePx], S[kTilePx], C[kTilePx];
-        bool ok[kTilePx];
+        float wh[kPX], bk[kPX], L0[kPX], L1[kPX], L2[kPX], fin[kPX], S[kPX], C[kPX];
+        bool ok[kPX];
         // the rectified samples (x 1024) of plane image `img` for the thread's pixels
-        auto samples = [&](const unsigned char *img, float smp[kTilePx]) {
+        auto samples = [&](const unsigned char *img, float smp[kPX]) {
+#if !defined(SLR_MFN_NOFENCE)
             asm volatile("" ::: "memory");                // (one plane's tap reads at a time)
+#endif
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 2)
 #pragma unroll
-            for (int j = 0; j < kTilePx; j++) {
+            for (int j = 0; j < kPX; j++) smp[j] = __uint_as_float(ta[j] + (unsigned)(uintptr_t)img);    // (ablation: no tap reads, no blend)
+            return;
+#endif
+#pragma unroll
+            for (int j = 0; j < kPX; j++) {
                 const unsigned *r0 = reinterpret_cast<const unsigned *>(img + ta[j]);
                 const unsigned *r1 = reinterpret_cast<const unsigned *>(img + ta[j] + kBoxRowBytes);
                 const unsigned u0 = __builtin_amdgcn_alignbit(r0[1], r0[0], tsh[j]);
@@ -776,7 +807,9 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
         // one step of the group stream: group g of this tile has landed and is decoded; group g + R - 1 (of this tile or the next) is issued
         auto step_top = [&](int g) {
             mfn_wait_vm<kWait>();
-            __syncthreads();
+#if !(defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 8))
+            __syncthreads();                              // (ablation 8: no group barriers -- wrong results, timing only)
+#endif
             if (g == 1) issue_map(tn);                    // (before the step's group DMAs: the counted wait stays exact)
             if (g == 5) { nxt = box_from_red(); chunk_offsets(nxt, nvo); }
             const int gi = g + R - 1;                     // the group to issue
@@ -793,13 +826,13 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
         step_top(0);
         if (cur.fits) {
             const unsigned char *img = slot_of(0);
-            float smp[kTilePx];
+            float smp[kPX];
             samples(img, smp);
 #pragma unroll
-            for (int j = 0; j < kTilePx; j++) wh[j] = smp[j];
+            for (int j = 0; j < kPX; j++) wh[j] = smp[j];
             samples(img + kBoxPlaneBytes, smp);
 #pragma unroll
-            for (int j = 0; j < kTilePx; j++) { bk[j] = smp[j]; ok[j] = wh[j] - bk[j] > thr1024; L0[j] = L1[j] = L2[j] = fin[j] = 0.0f; }
+            for (int j = 0; j < kPX; j++) { bk[j] = smp[j]; ok[j] = wh[j] - bk[j] > thr1024; L0[j] = L1[j] = L2[j] = fin[j] = 0.0f; }
         }
 #pragma unroll 1
         for (int f = 0; f < 4; f++) {
@@ -811,10 +844,10 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
                     const unsigned char *img = slot_of(g);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        float smp[kTilePx];
+                        float smp[kPX];
                         samples(img + k * kBoxPlaneBytes, smp);
 #pragma unroll
-                        for (int j = 0; j < kTilePx; j++) {
+                        for (int j = 0; j < kPX; j++) {
                             if (hf == 0 && k == 0) S[j] = C[j] = 0.0f;
                             S[j] += smp[j] * tr.sn[4 * hf + k]; C[j] += smp[j] * tr.cs[4 * hf + k];
                         }
@@ -823,7 +856,7 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
             }
             if (cur.fits) {
 #pragma unroll
-                for (int j = 0; j < kTilePx; j++) {
+                for (int j = 0; j < kPX; j++) {
                     float p = atan2f(-S[j], C[j]);
                     if (p < 0.0f) p += kTrue2PI;
                     ok[j] = ok[j] && (S[j] * S[j] + C[j] * C[j] > mod2);
@@ -841,15 +874,17 @@ __global__ __launch_bounds__(kTileNT, (R == 3 ? 6 : 4)) void mfn_rect_dma_kernel
         }
         if (cur.fits) {
 #pragma unroll
-            for (int j = 0; j < kTilePx; j++) {
+            for (int j = 0; j < kPX; j++) {
                 out[j] = (wh[j] - bk[j] > thr1024) ? fin[j] / kTrue2PI * 255 : 0.0f;
                 okm |= (ok[j] ? 1u : 0u) << j;
             }
         }
 #pragma unroll
-        for (int j = 0; j < kTilePx; j++) pend_out[j] = out[j];
+        for (int j = 0; j < kPX; j++) pend_out[j] = out[j];
         pend_okm = okm; pend_t = t;
-        cur = nxt; cvo[0] = nvo[0]; cvo[1] = nvo[1];
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < kDPG; i++) cvo[i] = nvo[i];
         s0 += 9 % R; s0 -= s0 >= R ? R : 0;
     }
     flush();
@@ -975,15 +1010,17 @@ hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int
         !tl_debug.no_tiled_map && !tl_debug.no_buffer_form && (uintptr_t)map_xy % 16 == 0 && (uintptr_t)map_frac % 16 == 0 &&
         (size_t)W * H * 4 < (1ull << 31)) {                  // the LDS-DMA form (SLR_OPT_DEBUG_FLAGS bit 1: the register-staged tile form)
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
-        const bool ring4 = tl_debug.gray_small_tiles;        // (SLR_OPT_DEBUG_FLAGS bit 4: a ring of 4 groups, two workgroups per CU)
+        // shipped: 256 threads x 4 pixels, ring of 3 (1.32 ms per 8192 x 6000 camera; 512 x 2: 1.39; ring of 4: 1.45 / 1.51).
+        // SLR_OPT_DEBUG_FLAGS bit 4: a ring of 4 groups, two workgroups per CU; bit 3: 512 threads x 2 pixels
+        const bool ring4 = tl_debug.gray_small_tiles, nt256 = !tl_debug.no_decode_count;
         const int per_cu = ring4 ? 2 : 3;
         unsigned tb = (unsigned)(tiles_x * tiles_y < 256 * per_cu ? tiles_x * tiles_y : 256 * per_cu);
         tb = (tb + 7u) & ~7u;
         const MfnDmaArgs da{planes[0], (unsigned)(stride * 2), (unsigned)span, map_xy, map_frac, (unsigned)((size_t)W * H)};
-        if (ring4) SLR_LAUNCH(mfn_rect_dma_kernel<4>, dim3(tb ? tb : 8), dim3(kTileNT), 0, s, da, tr8, pitch, W, H, black_thr, row0, rows,
-                              src_row0, src_rows, tiles_x, phase, valid);
-        else SLR_LAUNCH(mfn_rect_dma_kernel<3>, dim3(tb ? tb : 8), dim3(kTileNT), 0, s, da, tr8, pitch, W, H, black_thr, row0, rows,
-                        src_row0, src_rows, tiles_x, phase, valid);
+#define SLR_MFND(RR, NTT) SLR_LAUNCH((mfn_rect_dma_kernel<RR, NTT>), dim3(tb ? tb : 8), dim3(NTT), 0, s, da, tr8, pitch, W, H, black_thr, row0, rows, \
+                                     src_row0, src_rows, tiles_x, phase, valid)
+        if (ring4 && nt256) SLR_MFND(4, 256); else if (ring4) SLR_MFND(4, 512); else if (nt256) SLR_MFND(3, 256); else SLR_MFND(3, 512);
+#undef SLR_MFND
         const int ntiles = tiles_x * tiles_y;
         SLR_LAUNCH(mfn_rect_fix_kernel, dim3((ntiles + 63) / 64), dim3(256), 0, s, sp, tr8, pitch, W, H, black_thr, map_xy, map_frac, row0, rows,
                    src_row0, src_rows, tiles_x, ntiles, phase, valid);
