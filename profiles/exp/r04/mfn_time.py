@@ -25,10 +25,10 @@ for name, path in variants:
     ctx = slr.Context(0)
     ctx.set_calibration(rig["calib"]); synth.install_verged_maps(ctx, rig, W, H)
     forms = [int(x) for x in os.environ.get("MFN_FORMS", "0,16,2,1").split(",")]
-    for rep in range(2 * len(forms)):
+    for rep in range(int(os.environ.get("MFN_REPS", "2")) * len(forms)):
         fl = forms[rep % len(forms)]                           # 0 / 16: LDS-DMA ring of 3 / of 4, 2: register-staged tiles, 1: per-pixel gather
         ctx.set_option(capi.OPT_DEBUG_FLAGS, fl)
-        line = [{0: "dma-3 ", 16: "dma-4 ", 8: "dma-3/256", 24: "dma-4/256", 2: "tiled ", 1: "gather"}[fl]]
+        line = [{0: "dma3/256x4", 16: "dma4/256x4", 8: "dma3/512x2", 24: "dma4/512x2", 2: "tiled ", 1: "gather"}[fl]]
         for cam in range(2):
             ctx.mfn_rectify_decode(cam, st[cam], 4, 8, 40.0, phase=ph, valid=vd)
             ctx.synchronize(); ctx.timer_begin()

@@ -27,11 +27,63 @@ namespace slr {
 constexpr float kTruePI = 3.14159265358979323846f;
 constexpr float kTrue2PI = 2 * kTruePI;
 
+// The wrapped phase atan2(y, x) brought into [0, 2 pi) -- what every config-5 kernel computes four times per pixel.  The library
+// atan2f costs ~40 instructions (argument scaling against overflow, infinities, NaNs) + 3 for the range; the DFT bins of a decode
+// are finite and far from both ends of the exponent range, so: t = min / max by v_rcp_f32 (1 ulp), atan t on [0, 1] as t times a
+// degree-7 polynomial in t^2 (weighted least-squares minimax fit, |error| < 1.4e-7 in f32 arithmetic, i.e. the library's 2 ulp
+// at pi), three selects for the octant, the half plane and the sign: 22 instructions.  Config 5 is a build extension validated
+// against an fp64 model within 1e-4 relative + an f32 floor (tests/test_mfn_extension.py); every kernel form uses THIS function, so
+// the forms still agree bit for bit.  x = y = 0 gives 0 (the pixel fails the modulation test anyway).
+__device__ __forceinline__ float mfn_phase_of(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), 1e-30f), mn = __builtin_fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float u = t * t;
+    float q = -4.054523073e-03f;
+    q = __builtin_fmaf(q, u, 2.186279185e-02f);
+    q = __builtin_fmaf(q, u, -5.591207743e-02f);
+    q = __builtin_fmaf(q, u, 9.642177820e-02f);
+    q = __builtin_fmaf(q, u, -1.390862167e-01f);
+    q = __builtin_fmaf(q, u, 1.994656473e-01f);
+    q = __builtin_fmaf(q, u, -3.332985938e-01f);
+    q = __builtin_fmaf(q, u, 9.999993443e-01f);
+    float a = q * t;                                     // atan t, 0 <= t <= 1
+    a = ay > ax ? 0.5f * kTruePI - a : a;                // [0, pi / 2]
+    a = x < 0.0f ? kTruePI - a : a;                      // [0, pi]
+    return y < 0.0f ? kTrue2PI - a : a;                  // [0, 2 pi)
+}
+// One frequency's DFT bin of EIGHT equally spaced steps by its butterflies: with a_k = s_k - s_(k+4),
+//   C = sum s_k cos(2 pi k / 8) = a_0 + sqrt(1/2) (a_1 - a_3),   S = sum s_k sin(2 pi k / 8) = a_2 + sqrt(1/2) (a_1 + a_3)
+// -- 8 instructions per pixel and frequency where the table form spends 32 (16 multiplies and 16 adds: the library is built without
+// contraction).  Any common power-of-two scale of the samples scales S and C exactly (the rectifying forms' samples are x 1024).
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+// The rectified sample (x 1024) of a tap pair pair (u0: row sy, u1: row sy + 1) and its weights, and the same SUBTRACTED from a
+// running value -- steps 4..7 of an 8-step frequency fold into a_k = s_k - s_(k+4) through the dot products' own accumulator
+// (negated weights, exact in binary16): a - t00 w00 - t01 w01 - t10 w10 - t11 w11, one rounding per v_dot2, no separate subtract.
+// Every rectifying form uses these two, in this order.
+__device__ __forceinline__ float mfn_sample(unsigned u0, unsigned u1, h16x2 w0, h16x2 w1)
+{
+    float a;
+    asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(a) : "v"(u0), "v"(w0));       // (VOP3P with an inline 0: the VOP2 form needs a v_mov first)
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1, a, false);
+}
+__device__ __forceinline__ float mfn_sample_sub(float acc, unsigned u0, unsigned u1, h16x2 nw0, h16x2 nw1)   // nw = -w
+{
+    const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), nw0, acc, false);
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), nw1, a, false);
+}
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+__device__ __forceinline__ void mfn_bin8(float a0, float a1, float a2, float a3, float &S, float &C)
+{
+    C = __builtin_fmaf(kSqrtHalf, a1 - a3, a0);
+    S = __builtin_fmaf(kSqrtHalf, a1 + a3, a2);
+}
+
 struct MfnPlanes { const uint16_t *p[SLR_MFN_MAX_PLANES]; };
 struct MfnTrig { float cs[SLR_MFN_MAX_STEPS], sn[SLR_MFN_MAX_STEPS]; };
 
 __device__ __forceinline__ float h2f(unsigned short b) { return __half2float(__ushort_as_half(b)); }
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32a2 __attribute__((aligned(2)));      // a dword at a 2-byte aligned address (two adjacent binary16 taps)
 
 // V pixels per thread: 4 (8-byte loads; W % 4 == 0, aligned planes) or 1.  FS x NS != 0: compile-time frequency and
@@ -68,19 +120,31 @@ __global__ __launch_bounds__(256) void mfn_decode_kernel(MfnPlanes pl, MfnTrig t
 #pragma unroll
         for (int f = 0; f < n_freq; f++) {
             float S[V], C[V];
+            if constexpr (NS == 8) {
+                float a[4][V];
 #pragma unroll
-            for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
+                for (int k = 0; k < 8; k++) {
+                    float I[V];
+                    load(2 + f * 8 + k, I);
 #pragma unroll
-            for (int k = 0; k < n_step; k++) {
-                float I[V];
-                load(2 + f * n_step + k, I);
+                    for (int v = 0; v < V; v++) a[k & 3][v] = k < 4 ? I[v] : a[k & 3][v] - I[v];
+                }
 #pragma unroll
-                for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+                for (int v = 0; v < V; v++) mfn_bin8(a[0][v], a[1][v], a[2][v], a[3][v], S[v], C[v]);
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < n_step; k++) {
+                    float I[V];
+                    load(2 + f * n_step + k, I);
+#pragma unroll
+                    for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+                }
             }
 #pragma unroll
             for (int v = 0; v < V; v++) {
-                float p = atan2f(-S[v], C[v]);
-                if (p < 0.0f) p += kTrue2PI;
+                const float p = mfn_phase_of(-S[v], C[v]);
                 // modulation B = 2/N * |DFT bin| below half a grey level: the phase is noise (cf. Q5) -> invalid
                 ok[v] = ok[v] && (S[v] * S[v] + C[v] * C[v] > mod2);
 #pragma unroll
@@ -171,17 +235,27 @@ __device__ __forceinline__ void mfn_rect_quad(const Src &src, const Trig &tr, in
         }
     }
     // smp[v] = 1024 x the rectified sample: the four exact products summed by two v_dot2_f32_f16 -- row sy first, then row sy + 1
+    auto taps = [&](int p, int v, unsigned &u0, unsigned &u1) {
+        if constexpr (INSIDE) { u0 = src.pair(p, off[v]); u1 = src.pair(p, off[v] + pitch); }
+        else {
+            u0 = (src.half(p, o00[v]) | src.half(p, o01[v]) << 16) & k0[v];
+            u1 = (src.half(p, o10[v]) | src.half(p, o11[v]) << 16) & k1[v];
+        }
+    };
     auto load = [&](int p, float smp[V]) {
 #pragma unroll
         for (int v = 0; v < V; v++) {
             unsigned u0, u1;
-            if constexpr (INSIDE) { u0 = src.pair(p, off[v]); u1 = src.pair(p, off[v] + pitch); }
-            else {
-                u0 = (src.half(p, o00[v]) | src.half(p, o01[v]) << 16) & k0[v];
-                u1 = (src.half(p, o10[v]) | src.half(p, o11[v]) << 16) & k1[v];
-            }
-            const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[v], 0.0f, false);
-            smp[v] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[v], a, false);
+            taps(p, v, u0, u1);
+            smp[v] = mfn_sample(u0, u1, w0[v], w1[v]);
+        }
+    };
+    auto load_sub = [&](int p, float acc[V]) {           // acc -= the sample, through the dot products' accumulator (mfn_sample_sub)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            unsigned u0, u1;
+            taps(p, v, u0, u1);
+            acc[v] = mfn_sample_sub(acc[v], u0, u1, -w0[v], -w1[v]);
         }
     };
     // (the samples stay scaled by 1024 -- an exact power of two: the shadow test compares against 1024 x the threshold and the
@@ -192,7 +266,8 @@ __device__ __forceinline__ void mfn_rect_quad(const Src &src, const Trig &tr, in
     load(1, bk);
     float D[V][SLR_MFN_MAX_FREQ];
     bool ok[V];
-    const float mod2 = (0.25f * n_step) * (0.25f * n_step);
+    // (NS == 8: the butterflies work on the x 1024 samples themselves, S and C come out x 1024)
+    const float mod2 = (0.25f * n_step) * (0.25f * n_step) * (NS == 8 ? 1048576.0f : 1.0f);
     const float thr1024 = black_thr * 1024.0f;
 #pragma unroll
     for (int v = 0; v < V; v++) ok[v] = wh[v] - bk[v] > thr1024;
@@ -200,15 +275,20 @@ __device__ __forceinline__ void mfn_rect_quad(const Src &src, const Trig &tr, in
     for (int f = 0; f < (FS ? FS : SLR_MFN_MAX_FREQ); f++) {
         if (f < n_freq) {
             float S[V], C[V];
+            float a[4][V];
 #pragma unroll
             for (int v = 0; v < V; v++) S[v] = C[v] = 0.0f;
 #pragma unroll
             for (int k = 0; k < (NS ? NS : SLR_MFN_MAX_STEPS); k++) {
                 if (k < n_step) {
-                    float I[V];
-                    load(2 + f * n_step + k, I);
+                    if constexpr (NS == 8) {
+                        if (k < 4) load(2 + f * 8 + k, a[k & 3]); else load_sub(2 + f * 8 + k, a[k & 3]);
+                    } else {
+                        float I[V];
+                        load(2 + f * n_step + k, I);
 #pragma unroll
-                    for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+                        for (int v = 0; v < V; v++) { S[v] += I[v] * tr.sn[k]; C[v] += I[v] * tr.cs[k]; }
+                    }
                     // four planes' tap loads (2 x 4 x V dwords) are in flight together; later ones must not be hoisted above this
                     // point (all 272 of a 4 x 8 stack at once need 300 registers -- one wave per SIMD --, a whole frequency's 64
                     // still spill at the 128 registers of four waves per SIMD)
@@ -216,10 +296,13 @@ __device__ __forceinline__ void mfn_rect_quad(const Src &src, const Trig &tr, in
                 }
             }
             asm volatile("" ::: "memory");
+            if constexpr (NS == 8) {
+#pragma unroll
+                for (int v = 0; v < V; v++) mfn_bin8(a[0][v], a[1][v], a[2][v], a[3][v], S[v], C[v]);
+            }
 #pragma unroll
             for (int v = 0; v < V; v++) {
-                float p = atan2f(-S[v], C[v]);
-                if (p < 0.0f) p += kTrue2PI;
+                const float p = mfn_phase_of(-S[v], C[v]);
                 // modulation B = 2/N * |DFT bin| below half a grey level: the phase is noise (cf. Q5) -> invalid
                 ok[v] = ok[v] && (S[v] * S[v] + C[v] * C[v] > mod2);
 #pragma unroll
@@ -455,9 +538,9 @@ __global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg
             };
             float wh[kTilePx], bk[kTilePx], L0[kTilePx], L1[kTilePx], L2[kTilePx], fin[kTilePx];
             bool ok[kTilePx];
-            const float mod2 = 4.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2
+            const float mod2 = 4.0f * 1048576.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2, on S and C of the x 1024 samples
             // the rectified samples (x 1024) of plane image `img` for the thread's 4 pixels
-            auto samples = [&](const unsigned char *img, float smp[kTilePx]) {
+            auto samples = [&](const unsigned char *img, float smp[kTilePx], bool sub = false) {   // sub: smp -= the samples
                 asm volatile("" ::: "memory");                // (one plane's tap reads at a time: hoisting four planes' reads spills)
 #pragma unroll
                 for (int j = 0; j < kTilePx; j++) {
@@ -465,8 +548,7 @@ __global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg
                     const unsigned *r1 = reinterpret_cast<const unsigned *>(img + ta[j] + kBoxRowBytes);
                     const unsigned u0 = __builtin_amdgcn_alignbit(r0[1], r0[0], tsh[j]);
                     const unsigned u1 = __builtin_amdgcn_alignbit(r1[1], r1[0], tsh[j]);
-                    const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[j], 0.0f, false);
-                    smp[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[j], a, false);
+                    smp[j] = sub ? mfn_sample_sub(smp[j], u0, u1, -w0[j], -w1[j]) : mfn_sample(u0, u1, w0[j], w1[j]);
                 }
             };
             // groups: (white, black) in buffer 0, then per frequency its steps 0-3 in buffer 1 (register set A) and 4-7 in buffer 0 (set
@@ -489,32 +571,19 @@ __global__ __launch_bounds__(kTileNT, 4) void mfn_rect_tile_kernel(MfnStridedArg
             __syncthreads();
 #pragma unroll 1
             for (int f = 0; f < 4; f++) {
-                float S[kTilePx], C[kTilePx];
+                float S[kTilePx], C[kTilePx], a[4][kTilePx];
                 if (f < 3) fetch(preA, 2 + 8 * (f + 1), 4);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float smp[kTilePx];
-                    samples(&box[1][k][0], smp);
-#pragma unroll
-                    for (int j = 0; j < kTilePx; j++) {
-                        if (k == 0) S[j] = C[j] = 0.0f;
-                        S[j] += smp[j] * tr.sn[k]; C[j] += smp[j] * tr.cs[k];
-                    }
-                }
+                for (int k = 0; k < 4; k++) samples(&box[1][k][0], a[k]);
                 commit(preB, 0);
                 __syncthreads();
                 if (f < 3) fetch(preB, 2 + 8 * (f + 1) + 4, 4);
 #pragma unroll
-                for (int k = 4; k < 8; k++) {
-                    float smp[kTilePx];
-                    samples(&box[0][k - 4][0], smp);
-#pragma unroll
-                    for (int j = 0; j < kTilePx; j++) { S[j] += smp[j] * tr.sn[k]; C[j] += smp[j] * tr.cs[k]; }
-                }
+                for (int k = 4; k < 8; k++) samples(&box[0][k - 4][0], a[k - 4], true);
 #pragma unroll
                 for (int j = 0; j < kTilePx; j++) {
-                    float p = atan2f(-S[j], C[j]);
-                    if (p < 0.0f) p += kTrue2PI;
+                    mfn_bin8(a[0][j], a[1][j], a[2][j], a[3][j], S[j], C[j]);
+                    const float p = mfn_phase_of(-S[j], C[j]);
                     ok[j] = ok[j] && (S[j] * S[j] + C[j] * C[j] > mod2);
                     // the cascade of neighbouring differences, streamed: level 1 from (P_{f-1}, P_f), level 2 from the last two level-1
                     // values, level 3 from the two level-2 values -- the same operations in the same order as the array form
@@ -642,7 +711,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
 #pragma unroll
         for (int i = 0; i < kDPG; i++) {
             const int cb = i * NT + wv * 64;              // the wave's first chunk of this DMA (wave-uniform)
-            mfn_dma16(cpg[i] < count ? vo[i] : kMfnDmaInvalid, src.rsrc, cb >= kDmaGroupChunks ? lds0 + (unsigned)kOffDump : sb + (unsigned)(cb * 16),
+            mfn_dma16(count == 4 || cpg[i] < count ? vo[i] : kMfnDmaInvalid, src.rsrc, cb >= kDmaGroupChunks ? lds0 + (unsigned)kOffDump : sb + (unsigned)(cb * 16),
                       (unsigned)first * src.stride_bytes);
         }
     };
@@ -752,7 +821,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
         pend_t = -1;
     };
 
-    const float mod2 = 4.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2
+    const float mod2 = 4.0f * 1048576.0f, thr1024 = black_thr * 1024.0f;      // (0.25 * 8)^2, on S and C of the x 1024 samples
 #pragma unroll 1
     for (; t < ntiles; t += (int)nb) {
         const int tn = t + (int)nb;
@@ -782,10 +851,13 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
             for (int j = 0; j < kPX; j++) out[j] = 0.0f;
             okm = kMfnDeferred;                               // (every live pixel's valid byte becomes the marker)
         }
-        float wh[kPX], bk[kPX], L0[kPX], L1[kPX], L2[kPX], fin[kPX], S[kPX], C[kPX];
+        float wh[kPX], bk[kPX], L0[kPX], L1[kPX], L2[kPX], fin[kPX], S[kPX], C[kPX], A[4][kPX];
         bool ok[kPX];
         // the rectified samples (x 1024) of plane image `img` for the thread's pixels
-        auto samples = [&](const unsigned char *img, float smp[kPX]) {
+        h16x2 nw0[kPX], nw1[kPX];
+#pragma unroll
+        for (int j = 0; j < kPX; j++) { nw0[j] = -w0[j]; nw1[j] = -w1[j]; }
+        auto samples = [&](const unsigned char *img, float smp[kPX], bool sub) {       // sub: smp -= the samples (mfn_sample_sub)
 #if !defined(SLR_MFN_NOFENCE)
             asm volatile("" ::: "memory");                // (one plane's tap reads at a time)
 #endif
@@ -800,8 +872,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
                 const unsigned *r1 = reinterpret_cast<const unsigned *>(img + ta[j] + kBoxRowBytes);
                 const unsigned u0 = __builtin_amdgcn_alignbit(r0[1], r0[0], tsh[j]);
                 const unsigned u1 = __builtin_amdgcn_alignbit(r1[1], r1[0], tsh[j]);
-                const float a = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u0), w0[j], 0.0f, false);
-                smp[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, u1), w1[j], a, false);
+                smp[j] = sub ? mfn_sample_sub(smp[j], u0, u1, nw0[j], nw1[j]) : mfn_sample(u0, u1, w0[j], w1[j]);
             }
         };
         // one step of the group stream: group g of this tile has landed and is decoded; group g + R - 1 (of this tile or the next) is issued
@@ -827,10 +898,10 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
         if (cur.fits) {
             const unsigned char *img = slot_of(0);
             float smp[kPX];
-            samples(img, smp);
+            samples(img, smp, false);
 #pragma unroll
             for (int j = 0; j < kPX; j++) wh[j] = smp[j];
-            samples(img + kBoxPlaneBytes, smp);
+            samples(img + kBoxPlaneBytes, smp, false);
 #pragma unroll
             for (int j = 0; j < kPX; j++) { bk[j] = smp[j]; ok[j] = wh[j] - bk[j] > thr1024; L0[j] = L1[j] = L2[j] = fin[j] = 0.0f; }
         }
@@ -843,22 +914,14 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
                 if (cur.fits) {
                     const unsigned char *img = slot_of(g);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        float smp[kPX];
-                        samples(img + k * kBoxPlaneBytes, smp);
-#pragma unroll
-                        for (int j = 0; j < kPX; j++) {
-                            if (hf == 0 && k == 0) S[j] = C[j] = 0.0f;
-                            S[j] += smp[j] * tr.sn[4 * hf + k]; C[j] += smp[j] * tr.cs[4 * hf + k];
-                        }
-                    }
+                    for (int k = 0; k < 4; k++) samples(img + k * kBoxPlaneBytes, A[k], hf == 1);
                 }
             }
             if (cur.fits) {
 #pragma unroll
                 for (int j = 0; j < kPX; j++) {
-                    float p = atan2f(-S[j], C[j]);
-                    if (p < 0.0f) p += kTrue2PI;
+                    mfn_bin8(A[0][j], A[1][j], A[2][j], A[3][j], S[j], C[j]);
+                    const float p = mfn_phase_of(-S[j], C[j]);
                     ok[j] = ok[j] && (S[j] * S[j] + C[j] * C[j] > mod2);
                     // the cascade of neighbouring differences, streamed (mfn_rect_tile_kernel)
                     auto wrapd = [](float a, float b) { return (a > b) ? (a - b) : (a - b + kTrue2PI); };
