@@ -124,6 +124,7 @@ def parse_args():
                          "(4096) puts the ~10 source rows of every tile of the rectifying decode on the same HBM channels: the "
                          "fused kernel is 3-6 %% faster with 64..1152 bytes of padding (the unfused one 1-3 %% slower)")
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
+    ap.add_argument("--match-group", type=int, default=0, help="SLR_OPT_MF_BATCH_GROUP (0 = the library's default, 8; 1 = one match launch per frame)")
     ap.add_argument("--match-algo", type=int, default=0, help="SLR_OPT_MF_MATCH_ALGO (tuning: 0 auto, 4 lean K4 with per-thread stores, 5 / 6 512 x 8 shapes)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
@@ -272,7 +273,7 @@ def live_traffic(args, kernel_name):
         d = tempfile.mkdtemp(prefix="slr_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "1", "--mode", args.mode, "--width", str(args.width), "--height", str(args.height),
-               "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--match-algo", str(args.match_algo), "--dma-shape", str(args.dma_shape),
+               "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--match-algo", str(args.match_algo), "--match-group", str(args.match_group), "--dma-shape", str(args.dma_shape),
                "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags),
                "--maps", args.maps]
         try:
@@ -611,6 +612,8 @@ def main():
             c_.set_option(slr.capi.OPT_RECT_DECODE_ALGO, args.rect_algo)
         if args.match_algo:
             c_.set_option(slr.capi.OPT_MF_MATCH_ALGO, args.match_algo)
+        if args.match_group:
+            c_.set_option(slr.capi.OPT_MF_BATCH_GROUP, args.match_group)
         if args.dma_shape >= 0:
             c_.set_option(slr.capi.OPT_RECT_DMA_SHAPE, args.dma_shape)
         if args.dma_depth >= 0:

@@ -152,6 +152,11 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * scratch set each, the second one half a frame behind: a frame's ray-ray triangulation (arithmetic) runs beside the next
  * frame's decode, histogram and scatter (HBM streaming); 1 = one frame after the other on the context's stream.  Same results. */
 #define SLR_OPT_BATCH_STREAMS 12
+/* SLR_OPT_MF_BATCH_GROUP: frames slr_reconstruct_mf_batch hands to ONE match + triangulate launch (default 8; 1 = frame by frame as
+ * in rounds 1-3).  The undistortion tables K4 reads are per calibration (12 of its 35 bytes per pixel): a launch over a group of
+ * frames walks a row of all of them on the same XCD, so the tables cross HBM once per group.  The phases of a group live in the
+ * context's scratch (8 bytes per pixel and frame).  Identical results. */
+#define SLR_OPT_MF_BATCH_GROUP 15
 /* SLR_OPT_DEBUG_POISON_SCRATCH (tests): 1 = every scratch buffer the context hands to a call (phases, codes, buckets, staging --
  * not the cached calibration tables) is filled with 0x7B bytes first, behind a device synchronisation: an intermediate a kernel
  * fails to write cannot pass for the previous call's.  Slow; 0 (default) = off. */

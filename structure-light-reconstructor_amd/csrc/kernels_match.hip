@@ -495,7 +495,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
                                                               int W, int H, int row0, K4Lean kc, int stop,
                                                               const float4 *__restrict__ undL, const float *__restrict__ undRx,
                                                               float *__restrict__ xyz,
-                                                              uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+                                                              uint8_t *__restrict__ has, int32_t *__restrict__ match_k,
+                                                              int nframes, size_t frame_px)
 {
     constexpr int IPT = 4;
     constexpr int N = BLOCK * IPT;
@@ -512,8 +513,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     __shared__ unsigned scan_tmp[BLOCK / 64];
     static_assert(BLOCK != 1024 || sizeof(sh.b) <= sizeof(sh.t), "the index must fit the dead hash table (two workgroups per CU)");
 
-    const int row = blockIdx.x + row0, tid = threadIdx.x;   // absolute image row (row0: first row of a band)
-    const size_t base = (size_t)blockIdx.x * W;
+    // Several frames in one launch (slr_reconstruct_mf_batch): the undistortion tables are per calibration, not per frame -- 12 of the
+    // 35 bytes per pixel K4 moves.  Workgroup b runs on XCD b % 8; the workgroups of one XCD take row r of frames 0 .. nframes - 1 one
+    // after the other, so every frame after the first finds the row's table entries in that XCD's L2.
+    int brow = (int)blockIdx.x, frame = 0;
+    if (nframes > 1) {
+        const int xcd = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+        frame = q % nframes;
+        brow = (q / nframes) * 8 + xcd;
+        if (brow >= H) return;                           // (the grid is padded to whole groups of 8 rows)
+        const size_t fo = (size_t)frame * frame_px;
+        phaseL += fo; phaseR += fo; xyz += 3 * fo; has += fo;
+        if (validL) validL += fo;
+        if (validR) validR += fo;
+        if (match_k) match_k += fo;
+    }
+    const int row = brow + row0, tid = threadIdx.x;      // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)brow * W;
     const int k0 = tid * IPT;
     const bool inrow = k0 < W;                           // W % 4 == 0: a thread's 4 pixels are all inside or all outside
 
@@ -1364,10 +1380,21 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 
 // algo: 0 = auto (lean binned form when it applies, else the general binned form, the chunked form for wide rows, the sweep
 // beyond), 1 = sweep, 2 = sorted indexed form, 3 = general binned indexed form
+// can launch_mf_match take several frames in one launch (the lean 1024-thread kernel on aligned rows of 2049..4096 pixels)?
+bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const float *xyz, const uint8_t *has, int W, const DevCalib &cal,
+                             int algo, const float *undL_xy, const float *undRx, size_t frame_px)
+{
+    return (algo == 0 || algo == 4) && !cal.eval_x87 && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
+           (uintptr_t)undL_xy % 16 == 0 && (uintptr_t)phaseL % 16 == 0 && (uintptr_t)phaseR % 16 == 0 && (uintptr_t)xyz % 16 == 0 &&
+           (uintptr_t)has % 4 == 0 && frame_px % 4 == 0;
+}
+
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, int row0, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
-                           int algo, const float *undL_xy, const float *undRx, hipStream_t s)
+                           int algo, const float *undL_xy, const float *undRx, hipStream_t s, int nframes, size_t frame_px)
 {
+    if (nframes > 1 && (validL || validR || match_k || !mf_match_batches_frames(phaseL, phaseR, xyz, has, W, cal, algo, undL_xy, undRx, frame_px)))
+        return hipErrorInvalidValue;                     // (the caller asks mf_match_batches_frames first)
     const float2 *undL = (const float2 *)undL_xy;
     if (algo != 1 && W <= 256 * 32) {
 #ifdef SLR_DEBUG_HOOKS
@@ -1401,12 +1428,13 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
             for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
             const float4 *undL4 = (const float4 *)undL_xy;
+            const unsigned grid = nframes > 1 ? (unsigned)(((H + 7) / 8) * 8 * nframes) : (unsigned)H;   // (frames batched: whole groups of 8 rows)
 #define SLR_LEAN(BLOCK)                                                                                                          \
     do {                                                                                                                         \
-        if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<BLOCK, true>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
-                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                     \
-        else SLR_LAUNCH((mf_match_lean_kernel<BLOCK, false>), dim3(H), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR,         \
-                        W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);                                               \
+        if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
+                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);                   \
+        else SLR_LAUNCH((mf_match_lean_kernel<BLOCK, false>), dim3(grid), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR,      \
+                        W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);                             \
     } while (0)
             // round 4, rows of 2049..4096 pixels: algo 0 = 1024 threads x 4 pixels with the row's XYZ stored through LDS (whole
             // kilobytes per store instruction: 86 vs 91 us in the batch); 4 = the same without the exchange (round 2); 5 / 6 = 512
@@ -1428,16 +1456,17 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return hipGetLastError();
             }
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
-                if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<1024, true, true>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
-                                          W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);
-                else SLR_LAUNCH((mf_match_lean_kernel<1024, false, true>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
-                                W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k);
+                if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<1024, true, true>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
+                                          W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);
+                else SLR_LAUNCH((mf_match_lean_kernel<1024, false, true>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
+                                W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);
                 return hipGetLastError();
             }
             if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);
 #undef SLR_LEAN
             return hipGetLastError();
         }
+        if (nframes > 1) return hipErrorInvalidValue;
         // wide rows: 1024 threads x few pixels each -> 16 waves per row hide the serial LDS chains of a thread
         if (W <= 256) SLR_SORTED(256, 1);
         else if (W <= 512) SLR_SORTED(256, 2);

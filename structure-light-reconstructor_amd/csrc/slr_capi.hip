@@ -35,7 +35,7 @@ enum Slot {
     S_COUNT
 };
 
-struct ProfRec { hipEvent_t a, b; int id; };
+struct ProfRec { hipEvent_t a, b; int id; int units = 1; };   // units: frames one launch served (the profile reports time per frame)
 
 }  // namespace
 
@@ -69,6 +69,7 @@ struct slr_ctx {
     int opt_async_host = 0;        // SLR_OPT_ASYNC_HOST
     int opt_hybrid_one_pass = 0;   // SLR_OPT_HYBRID_ONE_PASS
     int opt_batch_streams = 2;     // SLR_OPT_BATCH_STREAMS
+    int opt_mf_batch_group = 8;    // SLR_OPT_MF_BATCH_GROUP
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
@@ -287,7 +288,7 @@ int prof_drain(slr_ctx *c)
         float ms = 0;
         SLR_HIP(c, hipEventElapsedTime(&ms, r.a, r.b));
         c->prof_ms[r.id] += ms;
-        c->prof_n[r.id] += 1;
+        c->prof_n[r.id] += r.units;
         c->free_events.push_back(r.a);
         c->free_events.push_back(r.b);
     }
@@ -346,7 +347,8 @@ int core_mf_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl, 
 
 // K4 with the per-(calibration,size) undistortion tables (built lazily, invalidated by slr_set_calibration)
 int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *phR, const uint8_t *vR, int W, int H,
-                  float *xyz, uint8_t *has, int32_t *match_k, int row0 = 0, int rows = -1)
+                  float *xyz, uint8_t *has, int32_t *match_k, int row0 = 0, int rows = -1, int nframes = 1, size_t frame_px = 0,
+                  bool *batched = nullptr /* nframes > 1: *batched = false and nothing launched when one launch cannot take them */)
 {
     // H: height of the IMAGE (tables); the arrays hold `rows` rows starting at image row row0 (default: all of it)
     if (rows < 0) rows = H;
@@ -364,9 +366,15 @@ int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *
         }
         undL = (const float *)a; undR = (const float *)b;
     }
+    if (nframes > 1) {
+        *batched = !vL && !vR && !match_k && row0 == 0 && rows == H &&
+                   mf_match_batches_frames(phL, phR, xyz, has, W, c->cal, c->opt_mf_match_algo, undL, undR, frame_px);
+        if (!*batched) return SLR_OK;
+    }
     ProfScope ps(c, K_MF_MATCH, true);
+    ps.r.units = nframes;
     SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, rows, row0, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
-                               c->stream));
+                               c->stream, nframes, frame_px));
     return SLR_OK;
 }
 
@@ -1219,11 +1227,39 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
     if (!c || !stack || !xyz || !has || n_frames < 0) return fail(c, SLR_ERR_INVALID_ARG, "bad argument");
     SLR_TRY(mf_batch_check(c, pitch, W, H, rectify));
     const size_t plane = (size_t)pitch * H, n = (size_t)W * H;
-    for (int f = 0; f < n_frames; f++) {
-        const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
-        const uint8_t *base = stack + (size_t)f * 2 * SLR_MF_PLANES * plane;
-        for (int i = 0; i < SLR_MF_PLANES; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (SLR_MF_PLANES + i); }
-        SLR_TRY(reconstruct_mf_dev(c, pl, pr, pitch, W, H, black_thr, rectify, xyz + (size_t)f * n * 3, has + (size_t)f * n));
+    // K4 reads 12 bytes of per-CALIBRATION undistortion tables per pixel (a third of its traffic): the frames of a batch are decoded
+    // into a phase scratch of `group` frames and matched by ONE launch whose workgroups take a row of all those frames one after the
+    // other on the same XCD -- the tables come from HBM once per group (SLR_OPT_MF_BATCH_GROUP, default 8; 1 = frame by frame)
+    for (int f0 = 0; f0 < n_frames;) {
+        const int g = n_frames - f0 < c->opt_mf_batch_group ? n_frames - f0 : c->opt_mf_batch_group;
+        void *phL = nullptr, *phR = nullptr;
+        if (g > 1) {
+            SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));
+            SLR_TRY(get_scratch(c, S_PHASE_R, (size_t)g * n * 4, &phR));
+        }
+        bool batched = false;
+        for (int j = 0; j < g && g > 1; j++) {
+            const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
+            const uint8_t *base = stack + (size_t)(f0 + j) * 2 * SLR_MF_PLANES * plane;
+            for (int i = 0; i < SLR_MF_PLANES; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (SLR_MF_PLANES + i); }
+            SLR_TRY(decode_pair_dev(c, pl, pr, pitch, W, H, black_thr, rectify, (float *)phL + (size_t)j * n, nullptr,
+                                    (float *)phR + (size_t)j * n, nullptr));
+        }
+        if (g > 1)
+            SLR_TRY(core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz + (size_t)f0 * n * 3,
+                                  has + (size_t)f0 * n, nullptr, 0, -1, g, n, &batched));
+        for (int j = 0; j < g && !batched; j++) {           // one launch cannot take the group (rows, alignment, match form): frame by frame
+            if (g > 1) {
+                SLR_TRY(core_mf_match(c, (const float *)phL + (size_t)j * n, nullptr, (const float *)phR + (size_t)j * n, nullptr, W, H,
+                                      xyz + (size_t)(f0 + j) * n * 3, has + (size_t)(f0 + j) * n, nullptr));
+                continue;
+            }
+            const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
+            const uint8_t *base = stack + (size_t)(f0 + j) * 2 * SLR_MF_PLANES * plane;
+            for (int i = 0; i < SLR_MF_PLANES; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (SLR_MF_PLANES + i); }
+            SLR_TRY(reconstruct_mf_dev(c, pl, pr, pitch, W, H, black_thr, rectify, xyz + (size_t)(f0 + j) * n * 3, has + (size_t)(f0 + j) * n));
+        }
+        f0 += g;
     }
     return SLR_OK;
 }
@@ -1832,6 +1868,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_RECT_DMA_DEPTH:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_RECT_DMA_DEPTH must be 1 or 2");
             c->opt_dma_depth = value;
+            return SLR_OK;
+        case SLR_OPT_MF_BATCH_GROUP:
+            if (value < 1 || value > 64) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_BATCH_GROUP must be 1..64");
+            c->opt_mf_batch_group = value;
             return SLR_OK;
         case SLR_OPT_BATCH_STREAMS:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_BATCH_STREAMS must be 1 or 2");

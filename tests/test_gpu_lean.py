@@ -159,3 +159,34 @@ def test_gray_dma_form_borders_and_strictness(dma_ctx, slr, oracle, synth):
     cx, _, v = ctx.gray_decode(dev[:4], 1, 0, BLACK, 0, 2, 0, rectify_cam=0)
     ctx.synchronize()
     assert bits_equal(np_of(cx), ex) and bits_equal(np_of(v), ev)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K4 over a group of frames in one launch (slr_reconstruct_mf_batch, SLR_OPT_MF_BATCH_GROUP)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,frames", [(4096, 21, 5), (2052, 9, 3), (1024, 12, 3)])
+def test_mf_batch_frame_groups_equal_frame_by_frame(ctx, slr, synth, W, H, frames):
+    """the batch entry with groups of 1 (every frame on its own: rounds 1-3), 2, 4 and 8 frames per match launch (rows that are not a
+    multiple of the 8 a group of workgroups takes, a last group that is not full, a row width the lean kernel does not take: those
+    fall back to frame-by-frame launches from the group's phase scratch) -- identical clouds, and frame 0 == the single-frame entry"""
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    ctx.set_calibration(calib)
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=2.0)
+        ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
+    stack = torch.stack([synth.render_mf_stack(W, H, seed=300 + f, noise=2) for f in range(frames)]).cuda()
+    res = {}
+    try:
+        for group in (1, 2, 4, 8):
+            ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, group)
+            x, h = ctx.reconstruct_mf_batch(stack, BLACK, True)
+            ctx.synchronize()
+            res[group] = (x.clone(), h.clone())
+    finally:
+        ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, 8)
+    for group in (2, 4, 8):
+        assert torch.equal(res[group][0].view(torch.int32), res[1][0].view(torch.int32)) and torch.equal(res[group][1], res[1][1]), group
+    x0, h0 = ctx.reconstruct_mf(stack[0, 0], stack[0, 1], BLACK, True)
+    ctx.synchronize()
+    assert torch.equal(x0.view(torch.int32), res[8][0][0].view(torch.int32)) and torch.equal(h0, res[8][1][0])
+    assert res[1][1].float().mean().item() > 0.05
