@@ -28,6 +28,7 @@ import csv
 import glob
 import importlib
 import json
+import math
 import os
 import shutil
 import subprocess
@@ -125,6 +126,12 @@ def parse_args():
                          "fused kernel is 3-6 %% faster with 64..1152 bytes of padding (the unfused one 1-3 %% slower)")
     ap.add_argument("--rect-algo", type=int, default=0, help="SLR_OPT_RECT_DECODE_ALGO (tuning: 0 auto, 1 gather, 2 64x16 tiles, 3 ring, 4 128x8/256thr, 5 128x8/512thr, 6 64x8, 7 LDS-DMA form)")
     ap.add_argument("--match-group", type=int, default=0, help="SLR_OPT_MF_BATCH_GROUP (0 = the library's default, 8; 1 = one match launch per frame)")
+    ap.add_argument("--passes", type=int, default=4,
+                    help="batch calls per step: a step is this many passes over the --frames distinct HBM-resident frames (default 4 x 8 = 32 "
+                         "frames, 2.75 GB of input re-read from HBM every pass).  The GPU's clocks ramp for ~60 ms after an idle gap "
+                         "(profiles/exp/r04/ramp.py: 225-250 us per frame in the first batches, 190 after 40): with the driver's --warmup 5 a "
+                         "step of ONE batch starts the timed region 8 ms into that ramp")
+    ap.add_argument("--decode-group", type=int, default=0, help="SLR_OPT_MF_BATCH_DECODE_GROUP (0 = the library's default, 8; 1 = one fused-decode launch per frame)")
     ap.add_argument("--match-algo", type=int, default=0, help="SLR_OPT_MF_MATCH_ALGO (tuning: 0 auto, 4 lean K4 with per-thread stores, 5 / 6 512 x 8 shapes)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
@@ -259,10 +266,26 @@ def literal_cost_baseline(synth, O, W, H, t_remap_frame):
                       "%dx%d; single thread, g++ -O2" % (W, H)}
 
 
-def live_traffic(args, kernel_name):
-    """HBM bytes per launch of `kernel_name` (a profiler name) from two rocprofv3 --pmc passes over a 3-step child run of this
-    script (one frame per step), collected and corrected as MI355X_MICROARCH.md's HBM section prescribes: separate passes for
-    FETCH_SIZE and WRITE_SIZE (KiB), gfx950's FETCH_SIZE doubled.  Returns (bytes, detail) or (None, reason)."""
+def frames_per_launch(args, mode, rectify, F, kernel_name):
+    """frames one launch of `kernel_name` serves inside the timed region: slr_reconstruct_mf_batch hands groups of frames
+    (SLR_OPT_MF_BATCH_GROUP, default 8) to ONE fused-decode launch and ONE match launch (round 4); everything else: 1"""
+    if mode != "mf":
+        return 1.0
+    g = min(args.match_group or 8, F)
+    groups = [g] * (F // g) + ([F % g] if F % g else [])
+    if kernel_name == "slr_mf_match_triangulate" and g >= 2 and args.match_algo in (0, 4):
+        return F / float(len(groups))
+    dg = args.decode_group or 8
+    if kernel_name == "slr_mf_rectify_decode_pair" and g >= 2 and dg >= 2 and rectify and args.rect_algo in (0, 7):
+        launches = sum(x // dg + (1 if x % dg else 0) for x in groups if x > 1) + sum(1 for x in groups if x == 1)
+        return F / float(launches)          # (a last sub-group of one frame is a single-frame launch: mixed, averaged)
+    return 1.0
+
+
+def live_traffic(args, kernel_name, fpl=1.0):
+    """HBM bytes per launch of `kernel_name` (a profiler name) from two rocprofv3 --pmc passes over a short child run of this
+    script (the timed region's batch per step), collected and corrected as MI355X_MICROARCH.md's HBM section prescribes: separate
+    passes for FETCH_SIZE and WRITE_SIZE (KiB), gfx950's FETCH_SIZE doubled.  Returns (bytes, detail) or (None, reason)."""
     exe = shutil.which("rocprofv3")
     prefixes = DEVICE_KERNEL.get(kernel_name)
     if not exe or not prefixes:
@@ -273,9 +296,9 @@ def live_traffic(args, kernel_name):
         d = tempfile.mkdtemp(prefix="slr_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                os.path.abspath(__file__), "--pmc-child", "1", "--mode", args.mode, "--width", str(args.width), "--height", str(args.height),
-               "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--match-algo", str(args.match_algo), "--match-group", str(args.match_group), "--dma-shape", str(args.dma_shape),
+               "--rectify", str(args.rectify), "--rect-algo", str(args.rect_algo), "--match-algo", str(args.match_algo), "--match-group", str(args.match_group), "--decode-group", str(args.decode_group), "--dma-shape", str(args.dma_shape),
                "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags),
-               "--maps", args.maps]
+               "--maps", args.maps, "--frames", str(args.frames)]
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
             got = []
@@ -294,9 +317,10 @@ def live_traffic(args, kernel_name):
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         return None, "rocprofv3 produced no counters for %s (%s)" % (kernel_name, vals)
     rd, wr = 2.0 * vals["FETCH_SIZE"] * 1024.0, vals["WRITE_SIZE"] * 1024.0
-    return int(rd + wr), {"hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
-                          "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, mean per dispatch of a 3-step child run; "
-                                 "FETCH_SIZE KiB x 2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE KiB x 1"}
+    return int(rd + wr), {"hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "frames_per_launch": fpl,
+                          "hbm_bytes_per_frame": int((rd + wr) / fpl),
+                          "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, mean per dispatch of a short child run of the timed "
+                                 "region's batch; FETCH_SIZE KiB x 2 (gfx950 counts 128-B requests at 64 B), WRITE_SIZE KiB x 1"}
 
 
 def copy_ceiling(torch, dev, stream):
@@ -570,8 +594,12 @@ def main():
     W, H = args.width, args.height
     mode = args.mode
     F = args.frames if args.frames > 0 else (4 if mode == "hybrid" else 8)
-    if args.pmc_child:                                   # the rocprofv3 child of live_traffic(): one frame, three steps
-        F, args.steps, args.warmup, args.profile, args.cpu_baseline, args.host_io, args.traffic = 1, 3, 1, 0, 0, 0, "off"
+    PASSES = max(1, args.passes)
+    if args.pmc_child:                                   # the rocprofv3 child of live_traffic(): the timed region's batch, two steps
+        args.steps, args.warmup, args.profile, args.cpu_baseline, args.host_io, args.traffic = 2, 1, 0, 0, 0, "off"
+        PASSES = 1
+        if mode != "mf":
+            F, args.steps = 1, 3
     scan_w, scan_h = (W, 0) if mode in ("ge", "hybrid") else ((1280, 1024) if mode == "gray" else (0, 0))
     ncol = synth.gray_num_bits(scan_w) if mode != "mf" else 0
     nrow = synth.gray_num_bits(scan_h) if mode == "gray" else 0
@@ -614,6 +642,8 @@ def main():
             c_.set_option(slr.capi.OPT_MF_MATCH_ALGO, args.match_algo)
         if args.match_group:
             c_.set_option(slr.capi.OPT_MF_BATCH_GROUP, args.match_group)
+        if args.decode_group:
+            c_.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, args.decode_group)
         if args.dma_shape >= 0:
             c_.set_option(slr.capi.OPT_RECT_DMA_SHAPE, args.dma_shape)
         if args.dma_depth >= 0:
@@ -673,16 +703,17 @@ def main():
         if do_gather:
             streams[i % S].wait_event(done_gather[b])   # buffer b is free again once its gather finished
         c_ = ctxs[i % S]
-        if mode == "mf":
-            c_.reconstruct_mf_batch(stack, BLACK_THR, rectify, W=W, xyz=xyz[b], has=has[b])
-        elif mode == "ge":
-            c_.reconstruct_batch(slr.capi.MODE_GE, stack, BLACK_THR, 0, n_col_bits=ncol, scan_w=scan_w, rectify=rectify, W=W,
-                                 xyz=xyz[b], has=has[b])
-        elif mode == "hybrid":
-            c_.reconstruct_hybrid_batch(stack, ncol, BLACK_THR, 0, scan_w, W=W, xyz=xyz[b], has=has[b])
-        else:
-            c_.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK_THR, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=scan_w,
-                                 scan_h=scan_h, rectify=False, W=W, xyz=xyz[b], has=has[b])
+        for _ in range(PASSES):
+            if mode == "mf":
+                c_.reconstruct_mf_batch(stack, BLACK_THR, rectify, W=W, xyz=xyz[b], has=has[b])
+            elif mode == "ge":
+                c_.reconstruct_batch(slr.capi.MODE_GE, stack, BLACK_THR, 0, n_col_bits=ncol, scan_w=scan_w, rectify=rectify, W=W,
+                                     xyz=xyz[b], has=has[b])
+            elif mode == "hybrid":
+                c_.reconstruct_hybrid_batch(stack, ncol, BLACK_THR, 0, scan_w, W=W, xyz=xyz[b], has=has[b])
+            else:
+                c_.reconstruct_batch(slr.capi.MODE_GRAY, stack, BLACK_THR, 0, n_col_bits=ncol, n_row_bits=nrow, scan_w=scan_w,
+                                     scan_h=scan_h, rectify=False, W=W, xyz=xyz[b], has=has[b])
         if do_gather:
             done_compute[b].record(streams[i % S])
             comm.wait_event(done_compute[b])
@@ -789,12 +820,14 @@ def main():
             c_.close()
         return
     npix = float(W) * H
-    value = world * npix * F * args.steps / elapsed / 1e6
+    value = world * npix * F * PASSES * args.steps / elapsed / 1e6
 
     kernels, roofline = [], None
     for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
-        avg_ms = ms / n
-        entry = {"name": name, "launches": n, "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ms, 3)}
+        avg_ms = ms / n                                  # (the library's profiler counts a launch over g frames as g: time per FRAME)
+        fpl = frames_per_launch(args, mode, rectify, F, name)
+        entry = {"name": name, "launches": int(round(n / fpl)), "frames_per_launch": fpl, "avg_launch_us": round(avg_ms * fpl * 1e3, 2),
+                 "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ms, 3)}
         if name in ALG_BYTES:
             gbs = ALG_BYTES[name] * npix / (avg_ms * 1e-3) / 1e9
             entry.update({"alg_bytes_per_px": ALG_BYTES[name], "achieved_GBs": round(gbs, 1),
@@ -805,7 +838,7 @@ def main():
         traffic, tsrc, tdetail = None, None, None
         want_live = args.traffic == "live" or (args.traffic == "auto" and world == 1 and shutil.which("rocprofv3"))
         if rank == 0 and want_live:
-            traffic, tdetail = live_traffic(args, k0["name"])
+            traffic, tdetail = live_traffic(args, k0["name"], k0["frames_per_launch"])
             tsrc = "live: rocprofv3 --pmc child runs of this command" if traffic else None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # PMC-derived HBM bytes per launch of an earlier profile run
         if traffic is None and args.traffic != "off" and os.path.exists(tpath):
@@ -814,16 +847,18 @@ def main():
                 ent = tj.get(k0["name"]) or ({k: 2 * v if isinstance(v, int) else v for k, v in tj.get(k0["name"][:-5], {}).items()}
                                              if k0["name"].endswith("_pair") else None)   # pair launch = 2 x the per-camera launch
                 if ent:
-                    traffic, tsrc = ent.get("hbm_bytes_per_launch"), "file: profiles/pmc_traffic.json (" + str(ent.get("kernel")) + ")"
+                    traffic, tsrc = ent.get("hbm_bytes_per_launch"), "file: profiles/pmc_traffic.json (" + str(ent.get("kernel")) + "), single-frame launches x frames per launch"
+                    traffic = int(traffic * k0["frames_per_launch"]) if traffic else traffic
             except Exception:
                 traffic = None
         roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0.get("achieved_GBs"), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": k0.get("frac_hbm_peak"),
                     "frac_of_achievable_6300": round(k0["achieved_GBs"] / HBM_ACHIEVABLE_GBS, 4) if k0.get("achieved_GBs") else None,
                     "traffic": traffic, "traffic_source": tsrc, "traffic_detail": tdetail if isinstance(tdetail, dict) else None,
-                    "traffic_over_algorithmic": round(traffic / (ALG_BYTES.get(k0["name"], 0) * npix), 3)
+                    "traffic_over_algorithmic": round(traffic / (ALG_BYTES.get(k0["name"], 0) * npix * k0["frames_per_launch"]), 3)
                     if traffic and ALG_BYTES.get(k0["name"]) else None,
-                    "avg_launch_us": k0["avg_us"], "alg_bytes_per_launch": ALG_BYTES.get(k0["name"], 0) * npix}
+                    "frames_per_launch": k0["frames_per_launch"], "us_per_frame": k0["avg_us"],
+                    "avg_launch_us": k0["avg_launch_us"], "alg_bytes_per_launch": ALG_BYTES.get(k0["name"], 0) * npix * k0["frames_per_launch"]}
 
     # outside the timed region: the other kernels of the path on the same frame (HIP-event timed, same stream):
     # the unfused phase-decode+unwrap kernel (north_star's named roofline target), the standalone remap and the
@@ -883,19 +918,30 @@ def main():
                 # stream-event time of F back-to-back calls (the LDS-DMA form's fix-up launches for tiles that do not fit it are
                 # part of a call; the per-kernel profiler would only see the main kernel)
                 ph_sw = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
-                for f in range(2):
+                for _ in range(12):                         # (the clocks have dropped while the maps were built: ~20 ms of work first)
+                    ctx.reconstruct_mf_batch(stack, BLACK_THR, True, W=W, xyz=xyz[0], has=has[0])
+                for f in range(F):
                     ctx.mf_rectify_decode_pair(stack[f % F, 0], stack[f % F, 1], BLACK_THR, W=W, want_valid=False, phase=ph_sw)
                 ctx.synchronize()
                 ctx.timer_begin()
                 for f in range(F):
                     ctx.mf_rectify_decode_pair(stack[f, 0], stack[f, 1], BLACK_THR, W=W, want_valid=False, phase=ph_sw)
-                per_frame_us = ctx.timer_end() / F * 1e3
+                single_us = ctx.timer_end() / F * 1e3
+                # ... and as the timed region runs it: the batch entry (groups of frames per launch), main kernel by the profiler
+                ctx.set_option(slr.capi.OPT_PROFILE_STRIDE, 1)
+                ctx.profile_enable(True); ctx.profile_reset()
+                for _ in range(3):
+                    ctx.reconstruct_mf_batch(stack, BLACK_THR, True, W=W, xyz=xyz[0], has=has[0])
+                pr = ctx.profile().get("slr_mf_rectify_decode_pair")
+                ctx.set_option(slr.capi.OPT_PROFILE_STRIDE, args.profile_stride)
+                ctx.profile_enable(False)
+                per_frame_us = pr[0] / pr[1] * 1e3 if pr and pr[1] else single_us
                 gbs = ALG_BYTES["slr_mf_rectify_decode_pair"] * npix / (per_frame_us * 1e-6) / 1e9
                 ent.update({"form_selected": [i["mf_form"] for i in info], "nofit_tiles": [i["dma_nofit_tiles"] for i in info],
                             "dma_tiles": info[0]["dma_tiles"], "quads_by_class": [i["quads_by_class"] for i in info],
                             "waves_by_mode": [i["waves_by_mode"] for i in info], "lds_nofit_tiles": [i["lds_nofit_tiles"] for i in info],
                             "split_tile_extra_entries": [i["dma_extra_entries"] for i in info],
-                            "decode_us_per_frame": round(per_frame_us, 1),
+                            "decode_us_per_frame": round(per_frame_us, 1), "decode_us_single_frame_calls": round(single_us, 1),
                             "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
             except Exception as e:                          # never break the bench line
                 ent["error"] = repr(e)
@@ -929,7 +975,7 @@ def main():
             "value": round(value, 2), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 in, f32 phase/XYZ (f64 undistort + Q reprojection)", "data": "synthetic",
-            "ms_per_frame": round(elapsed / args.steps / F * 1e3, 4),
+            "ms_per_frame": round(elapsed / args.steps / (F * PASSES) * 1e3, 4),
             "config": {"workload": {"mf": "%dx%d stereo, 3-freq x 4-step (14 planes/camera): rectify+decode+unwrap+match+triangulate",
                                     "ge": "%dx%d stereo, GRAY_EPI (Gray-code columns, 26 planes/camera at a 4096-wide projector): "
                                           "rectify+decode+code match+triangulate",
@@ -937,10 +983,10 @@ def main():
                                             "decode+bucket scatter+ray-ray triangulation",
                                     "hybrid": "%dx%d stereo, Gray-code columns + 3-freq x 4-step fringes in one stack (38 planes/camera, "
                                               "BASELINE config 3): one-pass rectify+Gray decode+phase decode, phase match+triangulate"}[mode] % (W, H)
-                                   + "; a step = %d distinct HBM-resident frames per GPU" % F,
+                                   + "; a step = %d passes over %d distinct HBM-resident frames per GPU (%d frames; every pass re-reads its input from HBM)" % (PASSES, F, PASSES * F),
                        "maps": (rig_desc or "synthetic near-identity rectification maps (synth.make_rectify_maps: 0.2 deg roll, k1 -0.08 / "
                                 "-0.06); verged rigs: see realistic_maps") if rectify else None,
-                       "mode": mode, "frames_per_gpu_per_step": F, "rectify": rectify, "streams_per_gpu": S,
+                       "mode": mode, "frames_per_gpu_per_step": F * PASSES, "distinct_frames": F, "passes_per_step": PASSES, "rectify": rectify, "streams_per_gpu": S,
                        "debug_flags": args.debug_flags,
                        "stack_row_pitch_bytes": pitch, "hip_event_profile_stride": max(1, args.profile_stride) if args.profile else 0,
                        "parallelism": "frames sharded over %d GPU(s)%s" % (
@@ -954,7 +1000,7 @@ def main():
             "collective": collective,
             "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
             # the same job with its one exchange step counted: all units / (timed steps + the all-gather that follows them)
-            "gather_inclusive_value": (round(world * npix * F * args.steps / (elapsed + gather_ms * 1e-3) / 1e6, 2) if gather_ms is not None
+            "gather_inclusive_value": (round(world * npix * F * PASSES * args.steps / (elapsed + gather_ms * 1e-3) / 1e6, 2) if gather_ms is not None
                                        else (round(value, 2) if final_gather else None)),
             "gather_proof": gather_proof,
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),

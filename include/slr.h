@@ -155,8 +155,11 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_MF_BATCH_GROUP: frames slr_reconstruct_mf_batch hands to ONE match + triangulate launch (default 8; 1 = frame by frame as
  * in rounds 1-3).  The undistortion tables K4 reads are per calibration (12 of its 35 bytes per pixel): a launch over a group of
  * frames walks a row of all of them on the same XCD, so the tables cross HBM once per group.  The phases of a group live in the
- * context's scratch (8 bytes per pixel and frame).  Identical results. */
+ * context's scratch (8 bytes per pixel and frame).  Identical results.
+ * SLR_OPT_MF_BATCH_DECODE_GROUP: frames of such a group whose fused rectify + decode (both cameras each) share ONE launch of the
+ * persistent LDS-DMA kernel (1..8, default 8; 1 = one launch per frame).  Identical results. */
 #define SLR_OPT_MF_BATCH_GROUP 15
+#define SLR_OPT_MF_BATCH_DECODE_GROUP 16
 /* SLR_OPT_DEBUG_POISON_SCRATCH (tests): 1 = every scratch buffer the context hands to a call (phases, codes, buckets, staging --
  * not the cached calibration tables) is filled with 0x7B bytes first, behind a device synchronisation: an intermediate a kernel
  * fails to write cannot pass for the previous call's.  Slow; 0 (default) = off. */

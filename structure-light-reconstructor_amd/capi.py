@@ -28,6 +28,7 @@ OPT_DEBUG_K4_STOP = 10         # -DSLR_DEBUG_HOOKS builds only
 OPT_BATCH_STREAMS = 12         # GRAY_ONLY batch: 2 (default) = frames pipelined over two streams, 1 = sequential
 OPT_DEBUG_POISON_SCRATCH = 13  # tests: scratch buffers are filled with 0x7B bytes before a call gets them
 OPT_MF_BATCH_GROUP = 15        # frames per match launch of reconstruct_mf_batch (default 8; 1 = frame by frame)
+OPT_MF_BATCH_DECODE_GROUP = 16 # frames per fused-decode launch inside such a group (1..8, default 8)
 OPT_EVAL_MODEL = 14            # 0 = strict IEEE (default), 1 = the reference's MSVC2010 x87 / fp:precise evaluation (slr.h)
 OPT_HYBRID_ONE_PASS = 11       # hybrid stacks: 0 = two fused launches (Gray planes, then white/black + fringes), 1 = one kernel
 OPT_PROFILE_STRIDE = 5         # the HIP-event profiler brackets every n-th launch of a kernel

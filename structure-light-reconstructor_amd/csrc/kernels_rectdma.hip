@@ -429,7 +429,7 @@ struct DmaJob {
     float *phase;
     uint8_t *valid;              // null: the flag is folded into the phase (NaN), see launch_mf_decode
 };
-struct DmaJobs { DmaJob j[2]; };
+struct DmaJobs { DmaJob j[kDmaMaxJobs]; };   // the cameras of one frame, or of a group of frames (slr_reconstruct_mf_batch): j[2 f + cam]
 
 // LDS-DMA of 16 bytes per lane: LDS[lds_dst + 16 * lane] = buffer[voff + soff .. + 15] (zeros beyond the descriptor's range).
 // M0 carries the LDS base and is compiler-reserved: saved and restored inside the one statement that uses it.
@@ -700,7 +700,7 @@ struct DmaPool {
     }
 };
 constexpr int kSchedStride = 16;                             // one counter per 64-byte line
-constexpr int kSchedDone = 2 * 8 * kSchedStride;             // sched[kSchedDone]: workgroups that have left the kernel
+constexpr int kSchedDone = kDmaMaxJobs * 8 * kSchedStride;   // sched[kSchedDone]: workgroups that have left the kernel
 constexpr size_t kSchedBytes = (size_t)(kSchedDone + kSchedStride) * sizeof(unsigned);
 size_t dma_sched_bytes() { return kSchedBytes; }
 
@@ -735,7 +735,7 @@ __device__ __forceinline__ void dma_sched_leave(unsigned *sched)
     unsigned v;                                             // (issued and waited for in one statement: an ordinary value)
     asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v) : "s"(sched + kSchedDone) : "memory");
     if (v + 1u == gridDim.x) {
-        for (int i = 0; i < 16; i++) __hip_atomic_store(sched + i * kSchedStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < kDmaMaxJobs * 8; i++) __hip_atomic_store(sched + i * kSchedStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(sched + kSchedDone, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1314,18 +1314,20 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
 // (stack layout, image width), nothing was launched.  depth: DMA issue distance A (1 or 2).
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
-                                     unsigned *sched, const DmaFixup *fix, bool *done, hipStream_t s)
+                                     unsigned *sched, const DmaFixup *fix, bool *done, hipStream_t s, const int *fix_slot)
 {
+    // fix_slot (n > 2: the cameras of a group of frames, job 2 f + cam): job c's slot in *fix; null: slot c
     *done = false;
-    if (shape < 0 || shape >= kDmaShapes || !sched) return hipSuccess;
+    if (shape < 0 || shape >= kDmaShapes || !sched || n < 1 || n > kDmaMaxJobs) return hipSuccess;
+    auto slot = [&](int c) { return fix_slot ? fix_slot[c] : c; };
     for (int c = 0; c < n; c++)
-        if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
+        if (fix && fix->nofit[slot(c)] > 0 && (!fix->map_xy[slot(c)] || !fix->map_frac[slot(c)])) return hipSuccess;
     DmaJobs j;
     for (int c = 0; c < n; c++) {
         if (!dma_job(pl[c], pitch, W, H, phase[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
-        if (fix) j.j[c].entries += fix->extras[c];
+        if (fix) j.j[c].entries += fix->extras[slot(c)];
     }
-    if (n == 1) j.j[1] = j.j[0];
+    for (int c = n; c < kDmaMaxJobs; c++) j.j[c] = j.j[0];
     const bool hv = valid[0] != nullptr;
     for (int c = 1; c < n; c++) if ((valid[c] != nullptr) != hv) return hipSuccess;
     *done = true;
@@ -1339,12 +1341,12 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
 #undef SLR_DMA_X
     // the tiles this form does not hold (none for mild maps): rewritten behind the main kernel
     for (int c = 0; c < n && e == hipSuccess; c++) {
-        if (!fix || fix->nofit[c] == 0) continue;
-        const unsigned cnt = fix->nofit[c];
+        if (!fix || fix->nofit[slot(c)] == 0) continue;
+        const unsigned cnt = fix->nofit[slot(c)];
         const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
 #define SLR_DMA_X(TW, TH, NT)                                                                                          \
         hipLaunchKernelGGL((mf_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], pitch, W, H, black_thr, \
-                           lut, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], valid[c])
+                           lut, fix->map_xy[slot(c)], fix->map_frac[slot(c)], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], valid[c])
         SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
         e = hipGetLastError();

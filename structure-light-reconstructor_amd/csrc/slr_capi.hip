@@ -70,6 +70,7 @@ struct slr_ctx {
     int opt_hybrid_one_pass = 0;   // SLR_OPT_HYBRID_ONE_PASS
     int opt_batch_streams = 2;     // SLR_OPT_BATCH_STREAMS
     int opt_mf_batch_group = 8;    // SLR_OPT_MF_BATCH_GROUP
+    int opt_mf_decode_group = 8;   // SLR_OPT_MF_BATCH_DECODE_GROUP
     bool und_valid = false;        // undistortion tables (S_UND_L/S_UND_R) match cal and und_w x und_h
     int und_w = 0, und_h = 0;
     bool rays_valid = false;       // unit-ray tables (S_RAYS_L/S_RAYS_R) match cal and rays_w x rays_h
@@ -1119,6 +1120,37 @@ static int decode_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
     return SLR_OK;
 }
 
+// the fused decode of both cameras of g frames of a batch in ONE launch (LDS-DMA form only): job 2 f + cam; the workgroups of the
+// frames walk a camera's tiles at the same pace, so its map digest and boxes (4 of the decode's 23 bytes per camera pixel) cross HBM
+// once per group.  *grouped = false: nothing launched (the caller decodes frame by frame).  Phases of frame f at phL / phR + f * n.
+static int decode_group_dev(slr_ctx *c, int g, const uint8_t *stack, size_t plane, int pitch, int W, int H, int black_thr,
+                            float *phL, float *phR, bool *grouped)
+{
+    *grouped = false;
+    if (g < 2 || 2 * g > kDmaMaxJobs || !dma_form_wanted(c, 0, 1)) return SLR_OK;
+    const size_t n = (size_t)W * H;
+    MfPlanes mp[kDmaMaxJobs];
+    float *ph[kDmaMaxJobs];
+    uint8_t *vd[kDmaMaxJobs];
+    const void *tl[kDmaMaxJobs];
+    int slot[kDmaMaxJobs];
+    for (int f = 0; f < g; f++)
+        for (int cam = 0; cam < 2; cam++) {
+            const uint8_t *base = stack + (size_t)f * 2 * SLR_MF_PLANES * plane + (size_t)cam * SLR_MF_PLANES * plane;
+            for (int i = 0; i < SLR_MF_PLANES; i++) mp[2 * f + cam].p[i] = base + plane * i;
+            ph[2 * f + cam] = (cam ? phR : phL) + (size_t)f * n;
+            vd[2 * f + cam] = nullptr;
+            tl[2 * f + cam] = c->d_dma_tiles[cam];
+            slot[2 * f + cam] = cam;
+        }
+    const DmaFixup fix = dma_fixup_of(c, 0, 1);
+    ProfScope ps(c, K_MF_RECT_DECODE_PAIR, true);
+    ps.r.units = g;
+    SLR_HIP(c, launch_mf_rect_decode_dma(mp, 2 * g, pitch, W, H, black_thr, c->d_lut, ph, vd, tl, c->opt_dma_shape, c->opt_dma_depth,
+                                         c->d_sched, &fix, grouped, c->stream, slot));
+    return SLR_OK;
+}
+
 static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int pitch, int W, int H,
                               int black_thr, int rectify, float *xyz, uint8_t *has)
 {
@@ -1238,12 +1270,19 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
             SLR_TRY(get_scratch(c, S_PHASE_R, (size_t)g * n * 4, &phR));
         }
         bool batched = false;
-        for (int j = 0; j < g && g > 1; j++) {
+        for (int j = 0; j < g && g > 1;) {                  // the fused decodes in sub-groups of SLR_OPT_MF_BATCH_DECODE_GROUP frames per launch
+            const int dg = g - j < c->opt_mf_decode_group ? g - j : c->opt_mf_decode_group;
+            bool decoded = false;
+            if (dg > 1 && rectify)
+                SLR_TRY(decode_group_dev(c, dg, stack + (size_t)(f0 + j) * 2 * SLR_MF_PLANES * plane, plane, pitch, W, H, black_thr,
+                                         (float *)phL + (size_t)j * n, (float *)phR + (size_t)j * n, &decoded));
+            if (decoded) { j += dg; continue; }
             const uint8_t *pl[SLR_MF_PLANES], *pr[SLR_MF_PLANES];
             const uint8_t *base = stack + (size_t)(f0 + j) * 2 * SLR_MF_PLANES * plane;
             for (int i = 0; i < SLR_MF_PLANES; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (SLR_MF_PLANES + i); }
             SLR_TRY(decode_pair_dev(c, pl, pr, pitch, W, H, black_thr, rectify, (float *)phL + (size_t)j * n, nullptr,
                                     (float *)phR + (size_t)j * n, nullptr));
+            j++;
         }
         if (g > 1)
             SLR_TRY(core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz + (size_t)f0 * n * 3,
@@ -1872,6 +1911,10 @@ int slr_set_option(slr_ctx *c, int option, int value)
         case SLR_OPT_MF_BATCH_GROUP:
             if (value < 1 || value > 64) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_BATCH_GROUP must be 1..64");
             c->opt_mf_batch_group = value;
+            return SLR_OK;
+        case SLR_OPT_MF_BATCH_DECODE_GROUP:
+            if (value < 1 || value > kDmaMaxJobs / 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_BATCH_DECODE_GROUP must be 1..8");
+            c->opt_mf_decode_group = value;
             return SLR_OK;
         case SLR_OPT_BATCH_STREAMS:
             if (value < 1 || value > 2) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_BATCH_STREAMS must be 1 or 2");

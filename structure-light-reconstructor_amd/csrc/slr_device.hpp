@@ -143,7 +143,8 @@ struct DmaFixup {
 hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W, int H, int black_thr, const float *lut,
                                      float *const *phase, uint8_t *const *valid, const void *const *tiles, int shape, int depth,
                                      unsigned *sched /* dma_sched_bytes() of zeros, owned by the context: the tile tickets */,
-                                     const DmaFixup *fix, bool *done, hipStream_t s);
+                                     const DmaFixup *fix, bool *done, hipStream_t s, const int *fix_slot = nullptr);
+constexpr int kDmaMaxJobs = 16;  // (frame, camera) jobs of one fused-decode launch: the two cameras of up to 8 frames
 size_t     dma_sched_bytes();
 
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,

@@ -164,7 +164,7 @@ def test_gray_dma_form_borders_and_strictness(dma_ctx, slr, oracle, synth):
 # ---------------------------------------------------------------------------------------------------------
 # K4 over a group of frames in one launch (slr_reconstruct_mf_batch, SLR_OPT_MF_BATCH_GROUP)
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("W,H,frames", [(4096, 21, 5), (2052, 9, 3), (1024, 12, 3)])
+@pytest.mark.parametrize("W,H,frames", [(4096, 21, 5), (2052, 9, 3), (1024, 12, 3), (4096, 300, 9)])
 def test_mf_batch_frame_groups_equal_frame_by_frame(ctx, slr, synth, W, H, frames):
     """the batch entry with groups of 1 (every frame on its own: rounds 1-3), 2, 4 and 8 frames per match launch (rows that are not a
     multiple of the 8 a group of workgroups takes, a last group that is not full, a row width the lean kernel does not take: those
@@ -177,14 +177,16 @@ def test_mf_batch_frame_groups_equal_frame_by_frame(ctx, slr, synth, W, H, frame
     stack = torch.stack([synth.render_mf_stack(W, H, seed=300 + f, noise=2) for f in range(frames)]).cuda()
     res = {}
     try:
-        for group in (1, 2, 4, 8):
-            ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, group)
+        for group in (1, 2, 4, 8, 8 + 256, 3, 8 + 512):  # (+ 256: the group's fused decodes frame by frame, + 512: three frames per decode launch)
+            ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, group & 255)
+            ctx.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, 1 if group & 256 else 3 if group & 512 else 8)
             x, h = ctx.reconstruct_mf_batch(stack, BLACK, True)
             ctx.synchronize()
             res[group] = (x.clone(), h.clone())
     finally:
         ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, 8)
-    for group in (2, 4, 8):
+        ctx.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, 8)
+    for group in (2, 4, 8, 8 + 256, 3, 8 + 512):
         assert torch.equal(res[group][0].view(torch.int32), res[1][0].view(torch.int32)) and torch.equal(res[group][1], res[1][1]), group
     x0, h0 = ctx.reconstruct_mf(stack[0, 0], stack[0, 1], BLACK, True)
     ctx.synchronize()
