@@ -40,9 +40,9 @@ def test_header_constants_match_the_binding(slr):
     cap = slr.capi
     for name in ("MF_MATCH_ALGO", "MF_DECODE_VEC", "RECT_DECODE_ALGO", "ASYNC_HOST", "PROFILE_STRIDE", "RECT_DMA_SHAPE",
                  "RECT_DMA_DEPTH", "DEBUG_RECT_RESIDENT", "DEBUG_FLAGS", "DEBUG_K4_STOP", "HYBRID_ONE_PASS", "BATCH_STREAMS", "DEBUG_POISON_SCRATCH",
-                 "EVAL_MODEL"):
+                 "EVAL_MODEL", "MF_BATCH_GROUP", "MF_BATCH_DECODE_GROUP"):
         assert defines["SLR_OPT_" + name] == getattr(cap, "OPT_" + name), name
-    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 15))   # no duplicate ids
+    assert sorted(v for k, v in defines.items() if k.startswith("SLR_OPT_")) == list(range(1, 17))   # no duplicate ids
     for name in ("OK", "ERR_INVALID_ARG", "ERR_NO_DEVICE", "ERR_HIP", "ERR_NOT_CONFIGURED", "ERR_UNSUPPORTED", "ERR_OOM"):
         assert enums["SLR_" + name] == getattr(cap, name), name
     assert (enums["SLR_MEM_HOST"], enums["SLR_MEM_DEVICE"]) == (cap.MEM_HOST, cap.MEM_DEVICE)

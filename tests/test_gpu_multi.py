@@ -231,7 +231,7 @@ def test_bench_two_ranks_with_a_collective_on_this_box():
         if r.returncode == 0 and lines:
             d = json.loads(lines[-1])
             assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-            assert d["config"]["frames_per_gpu_per_step"] == 2 and "all-gather" in d["config"]["parallelism"]
+            assert d["config"]["distinct_frames"] == 2 and d["config"]["frames_per_gpu_per_step"] == 2 * d["config"]["passes_per_step"] and "all-gather" in d["config"]["parallelism"]
             assert d["collective_backend"] == backend and d["collective_ranks"] == 2, d.get("collective")
             assert len(d["collective"]["devices"]) == 2 and d["collective"]["distinct_devices"] == 1   # both ranks on the one GPU
             # the exchange proves itself: every rank compared all 4 frames of its assembled cloud with their owners' checksums
