@@ -24,7 +24,7 @@ grep '^{"metric"' "$OUT/bench_stdout.log" | tail -1 > "$SUM/${TAG}_bench_line.js
 # 2. kernel trace + stats of the per-kernel driver
 SLR_WHAT=mf,gray,ge,ray rocprofv3 --kernel-trace --stats -f csv -d "$OUT/drv" -o drv -- python "$REPO/profiles/prof_driver.py" > "$OUT/drv_stdout.log" 2>&1
 cp "$OUT"/drv/*kernel_stats.csv "$SUM/${TAG}_driver_kernel_stats.csv" 2>/dev/null
-for M in ge gray hybrid; do
+for M in ge gray hybrid mfn; do
     rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench_$M" -o bench -- python "$REPO/bench.py" --mode $M --steps 5 --warmup 1 --cpu-baseline 0 --host-io 0 --traffic off \
         > "$OUT/bench_${M}_stdout.log" 2>&1
     cp "$OUT"/bench_$M/*kernel_stats.csv "$SUM/${TAG}_bench_${M}_kernel_stats.csv" 2>/dev/null
