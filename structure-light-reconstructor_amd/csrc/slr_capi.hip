@@ -1401,17 +1401,29 @@ int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack,
     SLR_TRY(need_calib(c));
     const size_t plane = (size_t)pitch * H, n = (size_t)W * H;
     void *phL, *phR, *cxs = nullptr;
-    SLR_TRY(get_scratch(c, S_PHASE_L, n * 4, &phL));
-    SLR_TRY(get_scratch(c, S_PHASE_R, n * 4, &phR));
     if (!code_x) SLR_TRY(get_scratch(c, S_CODEX_L, n * 8, &cxs));      // nobody wants the codes: one scratch pair for every frame
-    for (int f = 0; f < n_frames; f++) {
-        const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];
-        const uint8_t *base = stack + (size_t)f * 2 * planes_per_cam * plane;
-        for (int i = 0; i < np; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (planes_per_cam + i); }
-        int32_t *cx = code_x ? code_x + (size_t)f * 2 * n : (int32_t *)cxs;
-        SLR_TRY(hybrid_pair_dev(c, pl, pr, ncol, pitch, W, H, black_thr, white_thr, scan_w, cx, (float *)phL, cx + n, (float *)phR));
-        SLR_TRY(core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz + (size_t)f * n * 3, has + (size_t)f * n,
-                              nullptr));
+    // as slr_reconstruct_mf_batch: the phases of a group of frames, ONE match launch per group (the undistortion tables once per group)
+    for (int f0 = 0; f0 < n_frames;) {
+        const int g = n_frames - f0 < c->opt_mf_batch_group ? n_frames - f0 : c->opt_mf_batch_group;
+        SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));
+        SLR_TRY(get_scratch(c, S_PHASE_R, (size_t)g * n * 4, &phR));
+        for (int j = 0; j < g; j++) {
+            const int f = f0 + j;
+            const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];
+            const uint8_t *base = stack + (size_t)f * 2 * planes_per_cam * plane;
+            for (int i = 0; i < np; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (planes_per_cam + i); }
+            int32_t *cx = code_x ? code_x + (size_t)f * 2 * n : (int32_t *)cxs;
+            SLR_TRY(hybrid_pair_dev(c, pl, pr, ncol, pitch, W, H, black_thr, white_thr, scan_w, cx, (float *)phL + (size_t)j * n, cx + n,
+                                    (float *)phR + (size_t)j * n));
+        }
+        bool batched = false;
+        if (g > 1)
+            SLR_TRY(core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz + (size_t)f0 * n * 3,
+                                  has + (size_t)f0 * n, nullptr, 0, -1, g, n, &batched));
+        for (int j = 0; j < g && !batched; j++)
+            SLR_TRY(core_mf_match(c, (const float *)phL + (size_t)j * n, nullptr, (const float *)phR + (size_t)j * n, nullptr, W, H,
+                                  xyz + (size_t)(f0 + j) * n * 3, has + (size_t)(f0 + j) * n, nullptr));
+        f0 += g;
     }
     return SLR_OK;
 }
