@@ -1379,7 +1379,7 @@ struct GrayDmaJob {
     uint8_t *valid;              // may be null (the consumer reads validity off code_x == -1)
     float *phase;                // hybrid stacks only (invalid pixels: NaN)
 };
-struct GrayDmaJobs { GrayDmaJob j[2]; };
+struct GrayDmaJobs { GrayDmaJob j[kDmaMaxJobs]; };   // the cameras of one frame or of a group of frames: j[2 f + cam]
 
 constexpr int kGrayDmaWaves1 = 6;     // waves per SIMD the one-pair-per-phase Gray form is compiled for
 constexpr int kGrayDmaNpp = 2;        // plane pairs per phase of the fused Gray decode (1 and 2 measured equal)
@@ -1779,21 +1779,22 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
                                        uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
-                                       bool *done, hipStream_t s)
+                                       bool *done, hipStream_t s, const int *fix_slot)
 {
     *done = false;
-    if (!sched) return hipSuccess;
+    if (!sched || n < 1 || n > kDmaMaxJobs) return hipSuccess;
+    auto slot = [&](int c) { return fix_slot ? fix_slot[c] : c; };          // (job c's slot in *fix: launch_mf_rect_decode_dma)
     for (int c = 0; c < n; c++)
-        if (fix && fix->nofit[c] > 0 && (!fix->map_xy[c] || !fix->map_frac[c])) return hipSuccess;
+        if (fix && fix->nofit[slot(c)] > 0 && (!fix->map_xy[slot(c)] || !fix->map_frac[slot(c)])) return hipSuccess;
     if (shape != 1 && shape != 3 && shape != 4 && shape != 5) return hipSuccess;      // the 4-pixels-per-thread shapes
     if (ncol + nrow < 2) return hipSuccess;                 // (a tile needs two phases: the next digest arrives during the second)
     const int np = 2 + 2 * ncol + 2 * nrow;
     GrayDmaJobs j;
     for (int c = 0; c < n; c++) {
         if (!gray_dma_job(pl[c], np, pitch, W, H, code_x[c], code_y[c], valid[c], tiles[c], shape, j.j[c])) return hipSuccess;
-        if (fix) j.j[c].entries += fix->extras[c];
+        if (fix) j.j[c].entries += fix->extras[slot(c)];
     }
-    if (n == 1) j.j[1] = j.j[0];
+    for (int c = n; c < kDmaMaxJobs; c++) j.j[c] = j.j[0];
     *done = true;
     constexpr int NPP = kGrayDmaNpp;
     const bool odd = ((((1 + ncol + nrow) + NPP - 1) / NPP) & 1) != 0;   // phases (of NPP plane pairs) per tile
@@ -1811,12 +1812,12 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     }
 #undef SLR_GDMA_X
     for (int c = 0; c < n && e == hipSuccess; c++) {        // the tiles this form does not hold: rewritten behind the main kernel
-        if (!fix || fix->nofit[c] == 0) continue;
-        const unsigned cnt = fix->nofit[c];
+        if (!fix || fix->nofit[slot(c)] == 0) continue;
+        const unsigned cnt = fix->nofit[slot(c)];
         const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
 #define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
         hipLaunchKernelGGL((gray_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], ncol, nrow, pitch, W, H, \
-                           black_thr, white_thr, scan_w, scan_h, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), \
+                           black_thr, white_thr, scan_w, scan_h, fix->map_xy[slot(c)], fix->map_frac[slot(c)], dma_nofit_list(tiles[c], W, H, shape), \
                            cnt, tiles_x, code_x[c], code_y[c], valid[c])
         switch (shape) {
         case 1:  SLR_GDMA_X(256, 8, 512); break;

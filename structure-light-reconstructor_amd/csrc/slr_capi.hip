@@ -1805,6 +1805,8 @@ int slr_reconstruct_batch(slr_ctx *c, const slr_batch_desc *d, const uint8_t *st
     if (rect) { SLR_TRY(need_maps(c, 0, d->W, d->H)); SLR_TRY(need_maps(c, 1, d->W, d->H)); }
     if (d->mode == SLR_MODE_GE && d->have_color && !rect && d->pitch != d->W)
         return fail(c, SLR_ERR_UNSUPPORTED, "have_color without rectify needs pitch == W");
+    if (d->mode == SLR_MODE_MF && d->planes_per_cam == SLR_MF_PLANES)         // the grouped launches of the multi-frequency batch entry
+        return slr_reconstruct_mf_batch(c, d->n_frames, stack, d->pitch, d->W, d->H, d->black_thr, rect ? 1 : 0, xyz, has);
     const size_t plane = (size_t)d->pitch * d->H, n = (size_t)d->W * d->H, cells = (size_t)(d->scan_w > 0 ? d->scan_w : 0) * (d->scan_h > 0 ? d->scan_h : 0);
     for (int f = 0; f < d->n_frames; f++) {
         const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];

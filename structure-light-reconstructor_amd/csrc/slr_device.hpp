@@ -150,7 +150,7 @@ size_t     dma_sched_bytes();
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
                                        uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
-                                       bool *done, hipStream_t s);
+                                       bool *done, hipStream_t s, const int *fix_slot = nullptr);
 // BASELINE config 3: Gray code + multi-frequency phase in ONE pass over a hybrid stack (kernels_rectdma.hip)
 hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int pitch, int W, int H, int black_thr, int white_thr,
                                          int scan_w, const float *lut, int32_t *const *code_x, float *const *phase,
