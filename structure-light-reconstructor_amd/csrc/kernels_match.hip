@@ -489,7 +489,7 @@ struct K4Lean {
     double T[12];                      // matCoordTrans widened to f64 (exact)
 };
 
-template <int BLOCK, bool HAS_T, bool XCHG = false>
+template <int BLOCK, bool HAS_T, bool XCHG = false, bool TAME = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
                                                               int W, int H, int row0, K4Lean kc, int stop,
@@ -543,8 +543,13 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         load_valid_blocked<IPT>(validL, base, k0, k0 + IPT, true, vl);
     }
     const size_t trow = (size_t)row * W;
+    {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+        u32x4 *const t4 = reinterpret_cast<u32x4 *>(sh.t.key);   // (key and mink are adjacent: the whole table in 16-byte stores)
 #pragma unroll
-    for (int q = 0; q < 2 * IPT; q++) { sh.t.key[tid + q * BLOCK] = kEmpty; sh.t.mink[tid + q * BLOCK] = kEmpty; }
+        for (int q = 0; q < 2 * TS / 4 / BLOCK; q++) t4[tid + q * BLOCK] = e4;
+    }
     __syncthreads();
     SLR_K4_STOP_AT(1);
 
@@ -682,9 +687,17 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         const double w = kc.q14 * (double)(float)(ulx[i] - urx[i]) + kc.q15;
         // X = (float)(r / w), guarded by the exponents (anything unusual takes the real divisions below)
         auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
-        const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
-        const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
-        if (!(emin >= 1023u - 200u && emax < 1023u + 200u) && best[i] >= 0) bad |= 1u << i;
+        if constexpr (TAME) {
+            // (round 4) q3, q7, q11 are host-checked (finite, not -0, zero or within 2^+-100): r0 and r1 are zero or within
+            // 2^-152 .. 2^129 whenever the table entries are finite, and a zero numerator goes through the quotient sequence
+            // exactly (+-0 with the division's sign) -- only w's exponent and the entries' finiteness need a look
+            const bool fin = __builtin_isfinite(ulx[i]) && __builtin_isfinite(uly[i]);
+            if (!(expo(w) - (1023u - 200u) < 400u && fin) && best[i] >= 0) bad |= 1u << i;
+        } else {
+            const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
+            const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+            if (!(emin >= 1023u - 200u && emax < 1023u + 200u) && best[i] >= 0) bad |= 1u << i;
+        }
         // The three quotients r/w exactly as three IEEE divisions compute them on this GPU: the compiler expands x/w into
         // y = rcp(w) refined by two Newton steps, q = x*y, q' = fma(fma(-w, q, x), y, q) (plus operand scaling and a fix-up
         // that are the identity inside the exponent guard) -- y depends on w alone, so it is computed once for the three.
@@ -1456,10 +1469,11 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return hipGetLastError();
             }
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
-                if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<1024, true, true>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
-                                          W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);
-                else SLR_LAUNCH((mf_match_lean_kernel<1024, false, true>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR,
-                                W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);
+#define SLR_LEANX(T_, TAME_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
+                                      W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)
+                if (cal.has_T) { if (q_tame) SLR_LEANX(true, true); else SLR_LEANX(true, false); }
+                else { if (q_tame) SLR_LEANX(false, true); else SLR_LEANX(false, false); }
+#undef SLR_LEANX
                 return hipGetLastError();
             }
             if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);
