@@ -769,6 +769,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[0], best[1], best[2], best[3]);
 }
 
+#ifdef SLR_ALL_FORMS   // (measured, not faster than the 1024 x 4 form: SLR_OPT_MF_MATCH_ALGO 5 / 6 exist in `make FORMS=all` builds only)
 // ------------------------------------------------------------------------------------------------------
 // K4 (exact indexed form, lean, round 4): the same index as mf_match_lean_kernel -- hash dedup, representatives counting-sorted
 // into 0.25-wide bins, exact predicate on the window's pairs -- cut for instruction-level instead of wave-level parallelism:
@@ -1057,6 +1058,8 @@ __global__ __launch_bounds__(512, WPS) void mf_match_lean8_kernel(const float *_
     }
 #undef SLR_KCOL
 }
+
+#endif  // SLR_ALL_FORMS
 
 // K4 for rows wider than 4096 pixels.  The hash table of a whole 8192-pixel right row needs 128 KB of LDS (one 1024-thread
 // workgroup per CU, 8 pixels and too many registers per thread: 2.3x the time per pixel of a 4096-wide row).  "Smallest
@@ -1456,6 +1459,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return (q == 0.0 && zero_ok && !signbit(q)) || (isfinite(q) && fabs(q) >= 0x1p-100 && fabs(q) <= 0x1p100);
             };
             const bool q_tame = tame(kc.q3, true) && tame(kc.q7, true) && tame(kc.q11, false);
+#ifdef SLR_ALL_FORMS
             if (W > 2048 && (algo == 5 || algo == 6) && q_tame) {
 #define SLR_LEAN8(TS, WPS)                                                                                                       \
     do {                                                                                                                         \
@@ -1468,6 +1472,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 #undef SLR_LEAN8
                 return hipGetLastError();
             }
+#endif
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
 #define SLR_LEANX(T_, TAME_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
                                       W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)

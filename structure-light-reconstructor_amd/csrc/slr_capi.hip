@@ -1865,6 +1865,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
             if (value < 0 || value > 6) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..6");
 #ifndef SLR_ALL_FORMS
             if (value == 2) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 2 (sorted form) is compiled with -DSLR_ALL_FORMS only");
+            if (value == 5 || value == 6) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 5 / 6 (512 x 8 shapes) are compiled with -DSLR_ALL_FORMS only");
 #endif
             c->opt_mf_match_algo = value;
             return SLR_OK;

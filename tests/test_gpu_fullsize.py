@@ -125,7 +125,7 @@ def test_fullsize_mf_match_forms_agree_and_oracle_rows(ctx, oracle, scene, slr):
         ctx.set_rectify_maps(cam, maps[cam][0], maps[cam][1])
     dec = [ctx.mf_decode(st[cam], BLACK, rectify_cam=cam) for cam in range(2)]
     out = {}
-    algos = forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (3, 2, 1, 0, 4, 5, 6), required=(3, 1, 0, 4, 5, 6))   # (2, the sorted form: FORMS=all builds; 0 / 4 / 5 / 6: the lean shapes)
+    algos = forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (3, 2, 1, 0, 4, 5, 6), required=(3, 1, 0, 4))   # (2, the sorted form: FORMS=all builds; 0 / 4 / 5 / 6: the lean shapes)
     for algo in algos:
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
         out[algo] = ctx.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1])
