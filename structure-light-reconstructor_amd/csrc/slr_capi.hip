@@ -1124,7 +1124,7 @@ static int decode_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
 // frames walk a camera's tiles at the same pace, so its map digest and boxes (4 of the decode's 23 bytes per camera pixel) cross HBM
 // once per group.  *grouped = false: nothing launched (the caller decodes frame by frame).  Phases of frame f at phL / phR + f * n.
 static int decode_group_dev(slr_ctx *c, int g, const uint8_t *stack, size_t plane, int pitch, int W, int H, int black_thr,
-                            float *phL, float *phR, bool *grouped)
+                            float *phL, float *phR, bool *grouped, const MfPlanes *sets = nullptr /* [2 g]: job 2 f + cam (else: from `stack`) */)
 {
     *grouped = false;
     if (g < 2 || 2 * g > kDmaMaxJobs || !dma_form_wanted(c, 0, 1)) return SLR_OK;
@@ -1136,8 +1136,11 @@ static int decode_group_dev(slr_ctx *c, int g, const uint8_t *stack, size_t plan
     int slot[kDmaMaxJobs];
     for (int f = 0; f < g; f++)
         for (int cam = 0; cam < 2; cam++) {
-            const uint8_t *base = stack + (size_t)f * 2 * SLR_MF_PLANES * plane + (size_t)cam * SLR_MF_PLANES * plane;
-            for (int i = 0; i < SLR_MF_PLANES; i++) mp[2 * f + cam].p[i] = base + plane * i;
+            if (sets) mp[2 * f + cam] = sets[2 * f + cam];
+            else {
+                const uint8_t *base = stack + (size_t)f * 2 * SLR_MF_PLANES * plane + (size_t)cam * SLR_MF_PLANES * plane;
+                for (int i = 0; i < SLR_MF_PLANES; i++) mp[2 * f + cam].p[i] = base + plane * i;
+            }
             ph[2 * f + cam] = (cam ? phR : phL) + (size_t)f * n;
             vd[2 * f + cam] = nullptr;
             tl[2 * f + cam] = c->d_dma_tiles[cam];
@@ -1307,7 +1310,8 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
 // planes of a camera: white, black, 2 * ncol Gray planes (pattern, inverse per column bit, MSB first), 12 fringe planes (3 x 4).
 // One pass (one launch for both cameras) when the LDS-DMA form applies; else the two fused decodes of each camera.
 static int hybrid_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *const *pR, int ncol, int pitch, int W, int H,
-                           int black_thr, int white_thr, int scan_w, int32_t *cxL, float *phL, int32_t *cxR, float *phR)
+                           int black_thr, int white_thr, int scan_w, int32_t *cxL, float *phL, int32_t *cxR, float *phR,
+                           bool gray_part_only = false /* two-launch mode: the caller decodes the fringes (a group of frames in one launch) */)
 {
     const int np = 2 + 2 * ncol + 12;
     bool done = false;
@@ -1331,6 +1335,7 @@ static int hybrid_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
             SLR_TRY(core_gray_decode(c, 0, true, pL, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cxL, nullptr, nullptr));
             SLR_TRY(core_gray_decode(c, 1, true, pR, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cxR, nullptr, nullptr));
         }
+        if (gray_part_only) return SLR_OK;
         const uint8_t *ml[SLR_MF_PLANES], *mr[SLR_MF_PLANES];
         ml[0] = pL[0]; ml[1] = pL[1]; mr[0] = pR[0]; mr[1] = pR[1];
         for (int k = 0; k < 12; k++) { ml[2 + k] = pL[2 + 2 * ncol + k]; mr[2 + k] = pR[2 + 2 * ncol + k]; }
@@ -1407,6 +1412,10 @@ int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack,
         const int g = n_frames - f0 < c->opt_mf_batch_group ? n_frames - f0 : c->opt_mf_batch_group;
         SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));
         SLR_TRY(get_scratch(c, S_PHASE_R, (size_t)g * n * 4, &phR));
+        // two-launch mode: the fringe decodes (white, black, 12 fringes behind the Gray planes) of up to 8 frames in ONE launch of the
+        // persistent kernel, as in the multi-frequency batch; the Gray decodes stay one launch per frame (grouping them buys nothing)
+        const bool group_mf = !c->opt_hybrid_one_pass && g > 1 && g <= c->opt_mf_decode_group && 2 * g <= kDmaMaxJobs && dma_form_wanted(c, 0, 1);
+        MfPlanes sets[kDmaMaxJobs];
         for (int j = 0; j < g; j++) {
             const int f = f0 + j;
             const uint8_t *pl[SLR_MAX_GRAY_PLANES], *pr[SLR_MAX_GRAY_PLANES];
@@ -1414,7 +1423,21 @@ int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack,
             for (int i = 0; i < np; i++) { pl[i] = base + plane * i; pr[i] = base + plane * (planes_per_cam + i); }
             int32_t *cx = code_x ? code_x + (size_t)f * 2 * n : (int32_t *)cxs;
             SLR_TRY(hybrid_pair_dev(c, pl, pr, ncol, pitch, W, H, black_thr, white_thr, scan_w, cx, (float *)phL + (size_t)j * n, cx + n,
-                                    (float *)phR + (size_t)j * n));
+                                    (float *)phR + (size_t)j * n, group_mf));
+            if (group_mf && 2 * j + 1 < kDmaMaxJobs) {
+                sets[2 * j].p[0] = pl[0]; sets[2 * j].p[1] = pl[1]; sets[2 * j + 1].p[0] = pr[0]; sets[2 * j + 1].p[1] = pr[1];
+                for (int k = 0; k < 12; k++) { sets[2 * j].p[2 + k] = pl[2 + 2 * ncol + k]; sets[2 * j + 1].p[2 + k] = pr[2 + 2 * ncol + k]; }
+            }
+        }
+        if (group_mf) {
+            bool decoded = false;
+            SLR_TRY(decode_group_dev(c, g, nullptr, plane, pitch, W, H, black_thr, (float *)phL, (float *)phR, &decoded, sets));
+            for (int j = 0; j < g && !decoded; j++) {       // (the form does not take this stack after all: frame by frame)
+                const uint8_t *ml[SLR_MF_PLANES], *mr[SLR_MF_PLANES];
+                for (int k = 0; k < SLR_MF_PLANES; k++) { ml[k] = sets[2 * j].p[k]; mr[k] = sets[2 * j + 1].p[k]; }
+                SLR_TRY(decode_pair_dev(c, ml, mr, pitch, W, H, black_thr, 1, (float *)phL + (size_t)j * n, nullptr, (float *)phR + (size_t)j * n,
+                                        nullptr));
+            }
         }
         bool batched = false;
         if (g > 1)
