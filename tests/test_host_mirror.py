@@ -485,3 +485,25 @@ def test_missing_images_fail_like_the_reference(host, synth, tmp_path):
     assert ok == 0 and b"not found" in err.value
     ok = host.duke_run_project(str(tmp_path / "nowhere").encode(), 2, 0, 64, 64, W, H, 40, 0, 0, b".png", None, None, None, None, err, 512)
     assert ok == 0 and b"Calibration" in err.value
+
+
+def test_bench_frames_per_launch_bookkeeping():
+    """bench.py's kernel entries divide the profiler's per-frame times back into launches: the grouping rules of
+    slr_reconstruct_mf_batch (SLR_OPT_MF_BATCH_GROUP / _DECODE_GROUP) restated there must match the library's defaults"""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    a = types.SimpleNamespace(match_group=0, decode_group=0, match_algo=0, rect_algo=0)
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_match_triangulate") == 8.0
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_rectify_decode_pair") == 8.0
+    assert bench.frames_per_launch(a, "mf", False, 8, "slr_mf_rectify_decode_pair") == 1.0      # unrectified: the unfused decode, per frame
+    assert bench.frames_per_launch(a, "ge", True, 8, "slr_mf_match_triangulate") == 1.0
+    a.match_group, a.decode_group = 8, 3                                                          # 8 frames: decode launches of 3 + 3 + 2
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_rectify_decode_pair") == 8.0 / 3
+    a.match_group = 1
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_match_triangulate") == 1.0
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_rectify_decode_pair") == 1.0
+    a.match_group, a.decode_group = 5, 8                                                          # groups of 5 + 3
+    assert bench.frames_per_launch(a, "mf", True, 8, "slr_mf_match_triangulate") == 4.0
