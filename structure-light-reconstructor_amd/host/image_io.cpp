@@ -30,7 +30,8 @@ bool dims_ok(long long w, long long h, int want_w, int want_h, std::string &err)
 }
 
 // ---- PGM ---------------------------------------------------------------------------------------------------------------
-bool pgm_header(const uint8_t *buf_p, size_t buf_n, int &w, int &h, size_t &data_pos, std::string &err)
+// buf_n bytes of the file are in buf_p (the whole file, or its head when total_n > buf_n is the file's size)
+bool pgm_header(const uint8_t *buf_p, size_t buf_n, int &w, int &h, size_t &data_pos, std::string &err, size_t total_n = 0)
 {
     struct { const uint8_t *p; size_t n; size_t size() const { return n; } uint8_t operator[](size_t i) const { return p[i]; } } buf{buf_p, buf_n};
     size_t pos = 2;
@@ -48,7 +49,8 @@ bool pgm_header(const uint8_t *buf_p, size_t buf_n, int &w, int &h, size_t &data
     pos++;                                               // the single whitespace byte after maxval
     if (vals[2] < 1 || vals[2] > 255) { err = "PGM maxval must be 1..255"; return false; }
     if (!dims_ok(vals[0], vals[1], 0, 0, err)) return false;
-    if (pos > buf.size() || (unsigned long long)(vals[0] * vals[1]) > buf.size() - pos) { err = "truncated PGM"; return false; }
+    const size_t all = total_n > buf.size() ? total_n : buf.size();
+    if (pos > buf.size() || (unsigned long long)(vals[0] * vals[1]) > all - pos) { err = "truncated PGM"; return false; }
     w = (int)vals[0]; h = (int)vals[1]; data_pos = pos;
     return true;
 }
@@ -237,8 +239,43 @@ bool slurp(const std::string &path, FileBytes &out, std::string &err)
     return ok;
 }
 
+// A binary PGM whose pixels go to a caller-owned buffer (the series loader's page-locked slots): the header from the file's first
+// 4 KB, the pixels by ONE fread straight into dst -- no staging copy of the whole file (round 4: the staging malloc's page faults and
+// the second copy were half of a PGM scan's host time).  false + empty err: not that case, the caller takes the general path.
+static bool pgm_read_into(const std::string &path, int want_w, int want_h, uint8_t *dst, int &w, int &h, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    uint8_t head[4096];
+    const size_t got = fread(head, 1, sizeof head, f);
+    bool ok = false;
+    if (got >= 3 && head[0] == 'P' && head[1] == '5') {
+        size_t pos = 0;
+        long fsize = -1;
+        if (fseek(f, 0, SEEK_END) == 0) fsize = ftell(f);
+        std::string herr;
+        int hw = 0, hh = 0;
+        bool hdr = false;
+        hdr = fsize >= 0 && pgm_header(head, got, hw, hh, pos, herr, (size_t)fsize) && pos <= got;   // (parses inside the 4 KB head only)
+        if (!hdr) { fclose(f); return false; }           // (a header beyond the first 4 KB, or a bad one: the general path decides)
+        if (!dims_ok(hw, hh, want_w, want_h, err)) { fclose(f); return false; }
+        const size_t npx = (size_t)hw * hh, inhead = got - pos < npx ? got - pos : npx;
+        memcpy(dst, head + pos, inhead);
+        ok = fseek(f, (long)(pos + inhead), SEEK_SET) == 0 && (npx == inhead || fread(dst + inhead, 1, npx - inhead, f) == npx - inhead);
+        if (!ok) err = "truncated PGM";
+        w = hw; h = hh;
+    }
+    fclose(f);
+    return ok;
+}
+
 bool decode_any(const std::string &path, int want_w, int want_h, uint8_t *dst, std::vector<uint8_t> *own, int &w, int &h, std::string &err)
 {
+    if (dst && !own) {                                   // (a PGM into a caller-owned buffer: no staging copy)
+        std::string e2;
+        if (pgm_read_into(path, want_w, want_h, dst, w, h, e2)) return true;
+        if (!e2.empty()) { err = e2; return false; }
+    }
     FileBytes buf;
     if (!slurp(path, buf, err)) return false;
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
