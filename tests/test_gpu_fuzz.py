@@ -151,3 +151,32 @@ def test_fuzz_ray_buckets(ctx, oracle, synth, slr, seed):
     exyz, ecnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
     xyz, cnt = ctx.ray_triangulate(cxL, cyL, vL, cxR, cyR, vR, scan_w, scan_h)
     assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz), (W, H, scan_w, scan_h)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_mf_batch_frame_groups_on_verged_rigs(ctx, slr, synth, seed):
+    """the grouped launches of slr_reconstruct_mf_batch (round 4: the cameras of up to 8 frames per fused-decode launch -- 16 ticket pools
+    per XCD --, a group of frames per match launch) on the keystone maps of small verged rigs, where tiles are split into parts, pools
+    hold few entries and workgroups find nothing to do: every group size against frame-by-frame launches, bit for bit"""
+    rng = np.random.default_rng(4000 + seed)
+    W, H = [(1040, 524), (528, 260), (2064, 120), (4096, 64), (3008, 75), (2560, 301)][seed]
+    frames = int(rng.integers(2, 10))
+    rig = synth.make_verged_rig(W, H, float(rng.uniform(0.1, 0.3)), float(rng.uniform(-0.2, -0.05)))
+    ctx.set_calibration(rig["calib"])
+    synth.install_verged_maps(ctx, rig, W, H)
+    stack = torch.stack([synth.render_mf_stack(W, H, seed=int(rng.integers(1 << 20)), noise=2) for _ in range(frames)]).cuda()
+    res = {}
+    try:
+        for mg, dg in ((1, 1), (8, 8), (int(rng.integers(2, 8)), int(rng.integers(2, 8))), (8, 1)):
+            ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, mg)
+            ctx.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, dg)
+            x, h = ctx.reconstruct_mf_batch(stack, 40, True)
+            ctx.synchronize()
+            res[(mg, dg)] = (x.clone(), h.clone())
+    finally:
+        ctx.set_option(slr.capi.OPT_MF_BATCH_GROUP, 8)
+        ctx.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, 8)
+    ref = res[(1, 1)]
+    for key, (x, h) in res.items():
+        assert torch.equal(x.view(torch.int32), ref[0].view(torch.int32)) and torch.equal(h, ref[1]), (W, H, frames, key)
+    assert ref[1].float().mean().item() > 0.02
