@@ -138,7 +138,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * arrays and counts the buckets in a second kernel (instead of one fused kernel per camera), bit 4 = the LDS-tiled fused Gray
  * decode takes its 64 x 4 tiles (the form of stacks of 42 planes and more) whatever the plane count, bit 5 = the map digests of the
  * LDS-DMA fused decodes leave every wave the quads of its own block of a tile (instead of handing a tile's straddling quads to as
- * few waves as hold them; installed maps are digested again when the bit changes).  SLR_OPT_DEBUG_K4_STOP exists only
+ * few waves as hold them; installed maps are digested again when the bit changes), bit 6 = straddling waves keep the three-row read
+ * mode.  In slr_mfn_rectify_decode (config 5) the same bits pick the form: bit 0 = the per-pixel gather form, bit 1 = the
+ * register-staged tile form, bit 3 = 512 threads x 2 pixels instead of 256 x 4 in the LDS-DMA form, bit 4 = its ring of 4 plane
+ * groups (two workgroups per CU) instead of 3.  SLR_OPT_DEBUG_K4_STOP exists only
  * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9
