@@ -139,9 +139,9 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * decode takes its 64 x 4 tiles (the form of stacks of 42 planes and more) whatever the plane count, bit 5 = the map digests of the
  * LDS-DMA fused decodes leave every wave the quads of its own block of a tile (instead of handing a tile's straddling quads to as
  * few waves as hold them; installed maps are digested again when the bit changes), bit 6 = straddling waves keep the three-row read
- * mode.  In slr_mfn_rectify_decode (config 5) the same bits pick the form: bit 0 = the per-pixel gather form, bit 1 = the
- * register-staged tile form, bit 3 = 512 threads x 2 pixels instead of 256 x 4 in the LDS-DMA form, bit 4 = its ring of 4 plane
- * groups (two workgroups per CU) instead of 3.  SLR_OPT_DEBUG_K4_STOP exists only
+ * mode.  slr_mfn_rectify_decode (config 5): bit 0 = the per-pixel gather form, bit 1 = the register-staged tile form (as for the
+ * u8 decodes: no digest / no buffer form), and two bits of its own: bit 7 = 512 threads x 2 pixels instead of 256 x 4 in the LDS-DMA
+ * form, bit 8 = its ring of 4 plane groups (two workgroups per CU) instead of 3.  SLR_OPT_DEBUG_K4_STOP exists only
  * in -DSLR_DEBUG_HOOKS builds of the library (phase ablation of the match kernel; outputs are not written). */
 #define SLR_OPT_DEBUG_RECT_RESIDENT 8
 #define SLR_OPT_DEBUG_FLAGS 9
@@ -158,7 +158,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_MF_BATCH_GROUP: frames slr_reconstruct_mf_batch hands to ONE match + triangulate launch (default 8; 1 = frame by frame as
  * in rounds 1-3).  The undistortion tables K4 reads are per calibration (12 of its 35 bytes per pixel): a launch over a group of
  * frames walks a row of all of them on the same XCD, so the tables cross HBM once per group.  The phases of a group live in the
- * context's scratch (8 bytes per pixel and frame).  Identical results.
+ * context's scratch: 8 bytes per pixel and frame -- 0.8 GB at 4096x3000 with the default, 6.3 GB with the maximum of 64; the
+ * scratch is kept until the context is destroyed.  Where one match launch cannot take a group (another match form, a Q that is
+ * not cv::stereoRectify's, rows outside 2049..4096 pixels) the group shrinks to what one fused-decode launch serves, or to 1.
+ * Identical results.
  * SLR_OPT_MF_BATCH_DECODE_GROUP: frames of such a group whose fused rectify + decode (both cameras each) share ONE launch of the
  * persistent LDS-DMA kernel (1..8, default 8; 1 = one launch per frame).  Identical results. */
 #define SLR_OPT_MF_BATCH_GROUP 15
@@ -452,6 +455,9 @@ int slr_host_free(void *ptr);
 /* ---- measurement hooks (bench.py): HIP-event timing on the ctx stream ------------------------------ */
 int slr_timer_begin(slr_ctx *ctx);                 /* records an event on the ctx stream */
 int slr_timer_end(slr_ctx *ctx, float *ms);        /* records + synchronises, returns elapsed ms */
+/* the box's streaming rate as MI355X_MICROARCH.md measures it: a float4 non-temporal copy of `bytes` (a multiple of 16; both
+ * device pointers 16-byte aligned) on the ctx stream, asynchronous -- bracket it with slr_timer_begin / _end */
+int slr_stream_copy(slr_ctx *ctx, void *dst, const void *src, size_t bytes);
 /* per-kernel profiler: when enabled every kernel launch is bracketed by two HIP events on the ctx stream */
 int          slr_profile_enable(slr_ctx *ctx, int on);
 int          slr_profile_reset(slr_ctx *ctx);

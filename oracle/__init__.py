@@ -68,6 +68,7 @@ def lib():
         _lib.slro_wrapped_phase_ev.restype = C.c_int
         _lib.slro_heterodyne_ev.restype = C.c_float
         _lib.slro_line_line_intersection_x87.restype = C.c_int
+        _lib.slro_x87_quotient_mismatches.restype = C.c_long
     return _lib
 
 
@@ -393,3 +394,8 @@ def ray_triangulate_x87(offL, itemsL, offR, itemsR, camL, camR, scan_w, scan_h, 
     lib().slro_ray_triangulate_x87(_p(offL), _p(iL), _p(offR), _p(iR), C.byref(camL), C.byref(camR), _p(Ta),
                                    C.c_int(scan_w), C.c_int(scan_h), _p(xyz), _p(cnt))
     return xyz, cnt
+
+
+def x87_quotient_mismatches(lo, hi):
+    """integers d in [lo, hi) for which the device's multiply + 2 fma form of P123 / (2*PI) * 255 (x87 model) differs from the division"""
+    return int(lib().slro_x87_quotient_mismatches(C.c_long(lo), C.c_long(hi)))

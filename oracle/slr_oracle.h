@@ -169,6 +169,8 @@ int   slro_line_line_intersection_x87(const float p1[3], const float v1[3], cons
 void  slro_ray_triangulate_x87(const int32_t *offL, const uint32_t *itemsL, const int32_t *offR, const uint32_t *itemsR,
                                const slro_camera *camL, const slro_camera *camR, const float *T, int scan_w, int scan_h,
                                float *xyz_sum, uint8_t *count);
+/* the device's constant-divisor form of :268's division under the x87 model, counted against the division (slr_oracle_x87.c) */
+long  slro_x87_quotient_mismatches(long lo, long hi);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,29 @@ void slro_mf_decode_ev(const uint8_t *const planes[SLRO_MF_PLANES], int pitch, i
         }
 }
 
+/* The device code (decode_common.hpp, het_finish_x87) replaces the f64 division of mfreconstruct.cpp:268 under this model by a
+ * multiply and two fused multiply-adds with constants (Markstein's quotient by a constant).  This restates THOSE operations --
+ * test infrastructure for the identity, not a second decode -- and counts the integers d in [lo, hi), d = P123 * 2^24 before
+ * the f32 rounding of its store, for which they do not reproduce (float)((double)P123 / (2.0 * PI) * 255.0) bit for bit. */
+long slro_x87_quotient_mismatches(long lo, long hi)
+{
+    const float PI = SLRO_PI_F;
+    const double c = (double)(2 * PI), cq = c * 16777216.0, rq = (1.0 / c) * (1.0 / 16777216.0);
+    long bad = 0;
+    for (long d = lo; d < hi; d++) {
+        const float F123 = (float)d;                               /* the one rounding of the x87 store, at the 2^24 scale */
+        const float P123 = F123 * (1.0f / 16777216.0f);            /* exact */
+        const float want = (float)((double)P123 / (2.0 * (double)PI) * 255.0);
+        const double x = (double)F123;
+        const double q0 = x * rq;
+        const double r = fma(-q0, cq, x);
+        const double q = fma(r, rq, q0);
+        const float got = (float)(q * 255.0);
+        if (memcmp(&got, &want, sizeof got) != 0) bad++;
+    }
+    return bad;
+}
+
 /* mfreconstruct.cpp:284-333 under either model: the match predicate (:295) and the disparity (:299) */
 void slro_mf_triangulate_rows_ev(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                                  int W, int H, int row0, int row1, const slro_camera *camL, const slro_camera *camR,

@@ -49,7 +49,7 @@ SYMBOLS = [
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
     "slr_prefix_index", "slr_compact_points", "slr_cloud_checksums", "slr_verify_assembled",
     "slr_host_alloc", "slr_host_free",
-    "slr_timer_begin", "slr_timer_end", "slr_profile_enable", "slr_profile_reset",
+    "slr_timer_begin", "slr_timer_end", "slr_stream_copy", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
 ]
 
@@ -670,6 +670,13 @@ class Context:
         out = np.zeros(nf, np.uint64)
         self._chk(self.lib.slr_cloud_checksums(self.h, C.c_int(nf), C.c_int(W), C.c_int(H), _ptr(xyz), _ptr(has), _ptr(out)))
         return out
+
+    def stream_copy(self, dst, src):
+        """float4 non-temporal device copy on the ctx stream (the box's streaming rate; asynchronous)"""
+        nbytes = src.numel() * src.element_size()
+        assert dst.numel() * dst.element_size() == nbytes
+        self._mem([dst, src])
+        self._chk(self.lib.slr_stream_copy(self.h, _ptr(dst), _ptr(src), C.c_size_t(nbytes)))
 
     def timer_begin(self):
         self._chk(self.lib.slr_timer_begin(self.h))

@@ -84,13 +84,25 @@ __device__ __forceinline__ float heterodyne_q24(int P0, int P1, int P2)
 // and P23 are formed exactly as in the strict model (het_pair_q24: an exact difference, one rounding).  Then
 //   P123 = P12 - P23 (+ 2*PI): the operands are f32 images of integers below 2^28, so the sum is exact in int32 and
 //          v_cvt_f32_i32 is the ONE rounding of the x87 store (the strict model rounds twice in the + branch);
-//   phase = P123 / (2*PI) * 255: quotient and product rounded to 53 bits, one narrowing to f32 -- real f64 arithmetic here (an
-//          opt-in parity mode: the cost, ~40 % more VALU time in the decode, is the price of the division).
+//   phase = P123 / (2*PI) * 255: quotient and product rounded to 53 bits, one narrowing to f32.  The quotient by the CONSTANT
+//          c = (double)(2*PI) is Markstein's sequence in f64 -- q = x*rc, r = fma(-q, c, x) (exact), q' = fma(r, rc, q) == RN(x / c)
+//          for rc = RN(1 / c) -- three v_fma_f64-class instructions at the f32 issue rate instead of the ~25 of an IEEE f64 division
+//          (round 4's form: +40 % VALU time in the decode).  q' == x / c bit for bit for EVERY value F123 can take (all 2.1e8 integers
+//          d of the line above, through the same f32 rounding: tests/test_x87_model.py::test_x87_quotient_by_constant runs the
+//          oracle-side restatement of exactly these operations against the division).
+//          The 2^24 scale of F123 rides in the constants (c * 2^24 and rc * 2^-24: exact, so every step is the same rounding of the
+//          same real number as on the unscaled P123).
+constexpr double kX87TwoPIQ24 = (double)kTwoPI * 16777216.0;
+constexpr double kX87RcpTwoPIQ24 = (1.0 / (double)kTwoPI) * (1.0 / 16777216.0);   // RN(1 / c) * 2^-24 (constant-folded IEEE division)
 __device__ __forceinline__ float het_finish_x87(float F12, float F23)
 {
-    const int d = ((int)F12 - (int)F23) + ((F12 > F23) ? 0 : kQ24TwoPI);
-    const float F123 = (float)d;
-    const double q = (double)F123 / (double)(kTwoPI * 16777216.0f);     // == P123 / (2*PI): the 2^24 scales cancel exactly
+    // (F12, F23 are f32 images of integers: the conversion back is exact.  The fused decodes also pass the junk pairs of a sentinel
+    //  wrapped phase, whose result is discarded: saturating conversions and wrapping integer arithmetic, nothing undefined)
+    const int d = (int)(((unsigned)__float2int_rz(F12) - (unsigned)__float2int_rz(F23)) + ((F12 > F23) ? 0u : (unsigned)kQ24TwoPI));
+    const double x = (double)(float)d;                                   // P123 * 2^24: the ONE rounding of the x87 store, widened
+    const double q0 = x * kX87RcpTwoPIQ24;
+    const double r = __builtin_fma(-q0, kX87TwoPIQ24, x);
+    const double q = __builtin_fma(r, kX87RcpTwoPIQ24, q0);              // == P123 / (2*PI) rounded to 53 bits
     return (float)(q * 255.0);
 }
 template <bool X87>

@@ -156,4 +156,28 @@ hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_fr
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The box's streaming rate, measured the way MI355X_MICROARCH.md quotes it ("float4 copy": 6.29 TB/s): 16 bytes per lane,
+// non-temporal both ways, a grid of a few workgroups per CU striding over the buffer.  bench.py reports the decode's rate against
+// this figure next to the 8 TB/s peak (a library memcpy is NOT a ceiling: torch's copy_ ran at 5.1 TB/s where the fused decode's
+// own unfused form streams 5.5).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n16)
+{
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    const f32x4_t *s4 = reinterpret_cast<const f32x4_t *>(src);
+    f32x4_t *d4 = reinterpret_cast<f32x4_t *>(dst);
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+}
+
+hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s)
+{
+    const size_t n16 = bytes / 16;
+    const size_t want = (n16 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 256u * 8u ? (want ? want : 1) : 256u * 8u);      // 8 workgroups of 4 waves per CU
+    SLR_LAUNCH(stream_copy_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(dst), n16);
+    return hipGetLastError();
+}
+
 }  // namespace slr

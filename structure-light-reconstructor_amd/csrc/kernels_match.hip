@@ -489,7 +489,11 @@ struct K4Lean {
     double T[12];                      // matCoordTrans widened to f64 (exact)
 };
 
-template <int BLOCK, bool HAS_T, bool XCHG = false, bool TAME = false>
+// X87 (SLR_OPT_EVAL_MODEL = 1): the two lines of mfreconstruct.cpp:295 / :299 that the reference's x87 binary
+// evaluates differently -- the predicate sees the EXACT difference of the two phases (f64: the difference of two floats of this
+// range is exact in 53 bits) and the disparity reaches the double unrounded.  The index is the same: its bins only have to
+// hold every pair closer than 0.1 + rounding, which a 0.25-wide bin and its neighbours do under either predicate.
+template <int BLOCK, bool HAS_T, bool XCHG = false, bool TAME = false, bool X87 = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
                                                               int W, int H, int row0, K4Lean kc, int stop,
@@ -650,10 +654,19 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
             const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
             const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
-            const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
-            const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
-            const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
-            const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+            unsigned h0, h1, h2, h3;
+            if constexpr (X87) {
+                const double pd = (double)p;
+                h0 = fabs(pd - (double)c0.x) < 0.1 ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                h1 = fabs(pd - (double)c0.z) < 0.1 ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                h2 = fabs(pd - (double)c1.x) < 0.1 ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                h3 = fabs(pd - (double)c1.z) < 0.1 ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+            } else {
+                h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+            }
             bk = min(min(bk, h0), min(h1, min(h2, h3)));
         }
         best[i] = (int)bk;                               // 0xFFFFFFFF == -1: no match
@@ -684,7 +697,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     for (int i = 0; i < IPT; i++) {
         // p3D = Q * [ulx, uly, ulx - urx, 1] with Q's structural zeros and ones dropped (reproject(): exact no-ops)
         const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
-        const double w = kc.q14 * (double)(float)(ulx[i] - urx[i]) + kc.q15;
+        const double w = kc.q14 * (X87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i])) + kc.q15;   // :299
         // X = (float)(r / w), guarded by the exponents (anything unusual takes the real divisions below)
         auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
         if constexpr (TAME) {
@@ -719,7 +732,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         for (int i = 0; i < IPT; i++) {
             if (!((bad >> i) & 1u)) continue;
             const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
-            const double w = kc.q14 * (double)(float)(ulx[i] - urx[i]) + kc.q15;
+            const double w = kc.q14 * (X87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i])) + kc.q15;
             const float X0 = (float)(r0 / w), X1 = (float)(r1 / w), X2 = (float)(r2 / w);
 #pragma unroll
             for (int j = 0; j < IPT; j++)
@@ -1400,7 +1413,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const float *xyz, const uint8_t *has, int W, const DevCalib &cal,
                              int algo, const float *undL_xy, const float *undRx, size_t frame_px)
 {
-    return (algo == 0 || algo == 4) && !cal.eval_x87 && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
+    return (algo == 0 || algo == 4) && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
            (uintptr_t)undL_xy % 16 == 0 && (uintptr_t)phaseL % 16 == 0 && (uintptr_t)phaseR % 16 == 0 && (uintptr_t)xyz % 16 == 0 &&
            (uintptr_t)has % 4 == 0 && frame_px % 4 == 0;
 }
@@ -1438,19 +1451,20 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                vec_ok, undL, undRx, xyz, has, match_k)
 #endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
-        if ((algo == 0 || (algo >= 4 && algo <= 6)) && !cal.eval_x87 && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+        if ((algo == 0 || (algo >= 4 && algo <= 6)) && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
             K4Lean kc;
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
             for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
             const float4 *undL4 = (const float4 *)undL_xy;
             const unsigned grid = nframes > 1 ? (unsigned)(((H + 7) / 8) * 8 * nframes) : (unsigned)H;   // (frames batched: whole groups of 8 rows)
+            const bool x87 = cal.eval_x87 != 0;              // SLR_OPT_EVAL_MODEL = 1: the same kernels, predicate and disparity of the x87 binary
+#define SLR_LEAN1(BLOCK, T_, X_) SLR_LAUNCH((mf_match_lean_kernel<BLOCK, T_, false, false, X_>), dim3(grid), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
+                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)
 #define SLR_LEAN(BLOCK)                                                                                                          \
     do {                                                                                                                         \
-        if (cal.has_T) SLR_LAUNCH((mf_match_lean_kernel<BLOCK, true>), dim3(grid), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR, \
-                                  W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);                   \
-        else SLR_LAUNCH((mf_match_lean_kernel<BLOCK, false>), dim3(grid), dim3(BLOCK), 0, s, phaseL, validL, phaseR, validR,      \
-                        W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px);                             \
+        if (cal.has_T) { if (x87) SLR_LEAN1(BLOCK, true, true); else SLR_LEAN1(BLOCK, true, false); }                             \
+        else { if (x87) SLR_LEAN1(BLOCK, false, true); else SLR_LEAN1(BLOCK, false, false); }                                     \
     } while (0)
             // round 4, rows of 2049..4096 pixels: algo 0 = 1024 threads x 4 pixels with the row's XYZ stored through LDS (whole
             // kilobytes per store instruction: 86 vs 91 us in the batch); 4 = the same without the exchange (round 2); 5 / 6 = 512
@@ -1460,7 +1474,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             };
             const bool q_tame = tame(kc.q3, true) && tame(kc.q7, true) && tame(kc.q11, false);
 #ifdef SLR_ALL_FORMS
-            if (W > 2048 && (algo == 5 || algo == 6) && q_tame) {
+            if (W > 2048 && (algo == 5 || algo == 6) && q_tame && !x87) {
 #define SLR_LEAN8(TS, WPS)                                                                                                       \
     do {                                                                                                                         \
         if (cal.has_T) SLR_LAUNCH((mf_match_lean8_kernel<true, TS, WPS>), dim3(H), dim3(512), 0, s, phaseL, validL, phaseR, validR, \
@@ -1474,15 +1488,18 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             }
 #endif
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
-#define SLR_LEANX(T_, TAME_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
+#define SLR_LEANX2(T_, TAME_, X_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_, X_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
                                       W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)
+#define SLR_LEANX(T_, TAME_) do { if (x87) SLR_LEANX2(T_, TAME_, true); else SLR_LEANX2(T_, TAME_, false); } while (0)
                 if (cal.has_T) { if (q_tame) SLR_LEANX(true, true); else SLR_LEANX(true, false); }
                 else { if (q_tame) SLR_LEANX(false, true); else SLR_LEANX(false, false); }
 #undef SLR_LEANX
+#undef SLR_LEANX2
                 return hipGetLastError();
             }
             if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);
 #undef SLR_LEAN
+#undef SLR_LEAN1
             return hipGetLastError();
         }
         if (nframes > 1) return hipErrorInvalidValue;

@@ -1074,8 +1074,8 @@ hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int
         (size_t)W * H * 4 < (1ull << 31)) {                  // the LDS-DMA form (SLR_OPT_DEBUG_FLAGS bit 1: the register-staged tile form)
         const int tiles_x = (W + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH;
         // shipped: 256 threads x 4 pixels, ring of 3 (1.32 ms per 8192 x 6000 camera; 512 x 2: 1.39; ring of 4: 1.45 / 1.51).
-        // SLR_OPT_DEBUG_FLAGS bit 4: a ring of 4 groups, two workgroups per CU; bit 3: 512 threads x 2 pixels
-        const bool ring4 = tl_debug.gray_small_tiles, nt256 = !tl_debug.no_decode_count;
+        // SLR_OPT_DEBUG_FLAGS bit 8: a ring of 4 groups, two workgroups per CU; bit 7: 512 threads x 2 pixels
+        const bool ring4 = tl_debug.mfn_ring4, nt256 = !tl_debug.mfn_nt512;
         const int per_cu = ring4 ? 2 : 3;
         unsigned tb = (unsigned)(tiles_x * tiles_y < 256 * per_cu ? tiles_x * tiles_y : 256 * per_cu);
         tb = (tb + 7u) & ~7u;

@@ -267,17 +267,28 @@ __host__ __device__ __forceinline__ void cam2world(const DevCamera &c, float p[3
     p[0] = out[0]; p[1] = out[1]; p[2] = out[2];
 }
 
-__device__ __forceinline__ void pixel_ray(uint32_t item, const DevCamera &c, const float pos[3], float ray[3])
+// x87 != 0 (SLR_OPT_EVAL_MODEL = 1): the two compound float expressions of this function as the reference's
+// MSVC2010 x87 binary evaluates them -- (p - cc) / fc with one rounding at the store (utilities.cpp:51-52), the sum of squares
+// at 53 bits, rounded once when it is passed to sqrt(float) (utilities.cpp:21).  cam2WorldSpace is OpenCV library code (its GEMM
+// accumulates in f64 either way) and undistortPoints is f64 in the source.
+__device__ __forceinline__ void pixel_ray(uint32_t item, const DevCamera &c, const float pos[3], float ray[3], int x87 = 0)
 {
     float ux, uy, pt[3];
     undistort_point_ray((float)(item >> 16), (float)(item & 0xFFFFu), c, ux, uy);   // item = col<<16 | row
-    pt[0] = (ux - c.ccx) / c.fcx;                  // utilities.cpp:51-53
-    pt[1] = (uy - c.ccy) / c.fcy;
+    if (x87) {
+        pt[0] = (float)(((double)ux - (double)c.ccx) / (double)c.fcx);
+        pt[1] = (float)(((double)uy - (double)c.ccy) / (double)c.fcy);
+    } else {
+        pt[0] = (ux - c.ccx) / c.fcx;              // utilities.cpp:51-53
+        pt[1] = (uy - c.ccy) / c.fcy;
+    }
     pt[2] = 1.0f;
     cam2world(c, pt);
     ray[0] = pos[0] - pt[0]; ray[1] = pos[1] - pt[1]; ray[2] = pos[2] - pt[2];
     // utilities.cpp:21-25: sqrt(float) overload, max(0.000001, mag) in f64, divide by the f32 narrowing
-    const double mag = (double)sqrtf(ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2]);
+    const float ss = x87 ? (float)((double)ray[0] * (double)ray[0] + (double)ray[1] * (double)ray[1] + (double)ray[2] * (double)ray[2])
+                         : ray[0] * ray[0] + ray[1] * ray[1] + ray[2] * ray[2];
+    const double mag = (double)sqrtf(ss);
     const float dv = (float)(0.000001 > mag ? 0.000001 : mag);
     ray[0] /= dv; ray[1] /= dv; ray[2] /= dv;
 }
@@ -294,9 +305,9 @@ __global__ __launch_bounds__(256) void ray_table_kernel(DevCalib cal, int W, int
     if (col >= (unsigned)W) return;
     const size_t o = ((size_t)row * W + col) * 3;
     float r[3];
-    pixel_ray((col << 16) | row, cal.cam[0], posL, r);
+    pixel_ray((col << 16) | row, cal.cam[0], posL, r, cal.eval_x87);
     raysL[o] = r[0]; raysL[o + 1] = r[1]; raysL[o + 2] = r[2];
-    pixel_ray((col << 16) | row, cal.cam[1], posR, r);
+    pixel_ray((col << 16) | row, cal.cam[1], posR, r, cal.eval_x87);
     raysR[o] = r[0]; raysR[o + 1] = r[1]; raysR[o + 2] = r[2];
 }
 
@@ -347,19 +358,44 @@ __device__ __forceinline__ void div3(float b, float c, float a, float den, float
     qb = b / den; qc = c / den; qa = a / den;
 }
 
-// utilities.cpp:399-425
+// Vec3f::dot under the x87 model (utilities.cpp:404-408): s += a[i] * b[i] with the product exact on the 53-bit stack and ONE
+// rounding per step at the store -- fma in f64 (the product of two floats is exact there), narrowed
+__device__ __forceinline__ float dot3_x87(const float a[3], const float b[3])
+{
+    float s = 0;
+    s = (float)__builtin_fma((double)a[0], (double)b[0], (double)s);
+    s = (float)__builtin_fma((double)a[1], (double)b[1], (double)s);
+    s = (float)__builtin_fma((double)a[2], (double)b[2], (double)s);
+    return s;
+}
+
+// utilities.cpp:399-425.  X87 (SLR_OPT_EVAL_MODEL = 1): the dot products as above, denom = a*c - b*b rounded once (:412), s and t
+// with their quotients and products at 53 bits and one rounding each (:417-418) -- plain f64 arithmetic, a parity mode; the
+// Point3f operators of :420-424 store every f32 operation in both models.
+template <bool X87 = false>
 __device__ __forceinline__ bool line_line(const float p1[3], const float v1[3], const float p2[3], const float v2[3],
                                           float out[3])
 {
     const float v12[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    float s, t;
+    if constexpr (X87) {
+        const float a = dot3_x87(v1, v1), c = dot3_x87(v2, v2), b = dot3_x87(v1, v2);
+        const float d = dot3_x87(v12, v1), e = dot3_x87(v12, v2);
+        const float denom = (float)((double)a * (double)c - (double)b * (double)b);
+        if (fabsf(denom) < 0.1f) return false;
+        const double bq = (double)b / (double)denom, cq = (double)c / (double)denom, aq = (double)a / (double)denom;
+        s = (float)(bq * (double)e - cq * (double)d);
+        t = (float)(-bq * (double)d + aq * (double)e);
+    } else {
     const float a = dot3(v1, v1), c = dot3(v2, v2), b = dot3(v1, v2);
     const float d = dot3(v12, v1), e = dot3(v12, v2);
     const float denom = a * c - b * b;
     if (fabsf(denom) < 0.1f) return false;
     float bq, cq, aq;
     div3(b, c, a, denom, bq, cq, aq);
-    const float s = bq * e - cq * d;
-    const float t = -bq * d + aq * e;
+    s = bq * e - cq * d;
+    t = -bq * d + aq * e;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const float u = p1[k] + s * v1[k];
@@ -372,6 +408,7 @@ __device__ __forceinline__ bool line_line(const float p1[3], const float v1[3], 
 // Utilities::line_lineIntersection over arrays (utilities.cpp:399-425): n lines through p1 along v1[i] against n lines through p2
 // along v2[i] -- the function K6 runs per pixel pair, exposed so that it (and its shared-reciprocal divisions) can be checked on
 // rays K6's calibrated unit rays never produce: perpendicular, nearly parallel, tiny, huge
+template <bool X87>
 __global__ __launch_bounds__(256) void line_line_kernel(size_t n, const float *__restrict__ p1, const float *__restrict__ p2,
                                                         const float *__restrict__ v1, const float *__restrict__ v2,
                                                         float *__restrict__ out, uint8_t *__restrict__ ok)
@@ -380,7 +417,7 @@ __global__ __launch_bounds__(256) void line_line_kernel(size_t n, const float *_
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) {
         const float r1[3] = {v1[3 * i], v1[3 * i + 1], v1[3 * i + 2]}, r2[3] = {v2[3 * i], v2[3 * i + 1], v2[3 * i + 2]};
         float X[3] = {0.0f, 0.0f, 0.0f};
-        const bool hit = line_line(a, r1, b, r2, X);
+        const bool hit = line_line<X87>(a, r1, b, r2, X);
         out[3 * i] = hit ? X[0] : 0.0f; out[3 * i + 1] = hit ? X[1] : 0.0f; out[3 * i + 2] = hit ? X[2] : 0.0f;
         ok[i] = hit ? 1 : 0;
     }
@@ -390,7 +427,8 @@ hipError_t launch_line_line(size_t n, const float *p1, const float *p2, const fl
                             hipStream_t s)
 {
     const unsigned blocks = (unsigned)((n + 255) / 256 < 8192 ? ((n + 255) / 256 ? (n + 255) / 256 : 1) : 8192);
-    SLR_LAUNCH(line_line_kernel, dim3(blocks), dim3(256), 0, s, n, p1, p2, v1, v2, out, ok);
+    if (tl_debug.eval_x87) SLR_LAUNCH(line_line_kernel<true>, dim3(blocks), dim3(256), 0, s, n, p1, p2, v1, v2, out, ok);
+    else SLR_LAUNCH(line_line_kernel<false>, dim3(blocks), dim3(256), 0, s, n, p1, p2, v1, v2, out, ok);
     return hipGetLastError();
 }
 
@@ -627,6 +665,7 @@ constexpr unsigned kTriCap = kTriCells * kTriPer;
 // shared, and the dispatcher balances at that grain).  (The first staged forms -- both buckets of 256 cells in LDS, 74-81 KB --
 // ran 8 waves per CU, and their lanes waited half of their lives.)
 constexpr unsigned kSmallCells = 64, kSmallRows = 12;
+template <bool X87>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ray_triangulate_small_kernel(
     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ items, TriArgs cal, unsigned nb, int W, const float *__restrict__ raysL,
     const float *__restrict__ raysR, const uint32_t *__restrict__ order, const uint32_t *__restrict__ hist, float *__restrict__ xyz_sum,
@@ -689,7 +728,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         for (int c = 0; c < 3; c++) nxt[c] = kn == 12 ? ex[0][c] : kn == 13 ? ex[1][c] : kn == 14 ? ex[2][c] : ex[3][c];
                     }
                     float X[3];
-                    if (line_line(pos[0], r1[k1], pos[1], ray2, X)) acc.add(cal, X);
+                    if (line_line<X87>(pos[0], r1[k1], pos[1], ray2, X)) acc.add(cal, X);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);               // (rows scheduled into each other want hundreds of registers)
@@ -701,6 +740,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 // The general form of one cell: buckets of any size, everything from global memory, one lane.  Only cells with more items than
 // the staged form holds come here (a projector pixel seen by thousands of camera pixels: a decode gone wrong).
+template <bool X87>
 __device__ __noinline__ void cell_general(const uint32_t *__restrict__ offs, uint32_t *__restrict__ items, const TriArgs &cal, unsigned nb,
                                           unsigned b, int W, const float *__restrict__ raysL, const float *__restrict__ raysR, CellSum &acc)
 {
@@ -715,11 +755,12 @@ __device__ __noinline__ void cell_general(const uint32_t *__restrict__ offs, uin
         for (unsigned c2 = r0; c2 < r1; c2++) {
             float ray2[3], X[3];
             load_ray(raysR, items[c2], W, ray2);
-            if (line_line(posL, ray1, posR, ray2, X)) acc.add(cal, X);
+            if (line_line<X87>(posL, ray1, posR, ray2, X)) acc.add(cal, X);
         }
     }
 }
 
+template <bool X87>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void ray_triangulate_staged_kernel(const uint32_t *__restrict__ offs, uint32_t *__restrict__ items,
                                                               TriArgs cal, unsigned nb, int W,
                                                               const float *__restrict__ raysL, const float *__restrict__ raysR,
@@ -756,7 +797,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool fits = t >= c0 && t < nc && hi[0] <= kTriCap && hi[1] <= kTriCap;
         const unsigned run = (unsigned)__syncthreads_count(fits);    // (fits is monotone in t: the count is the run's length)
         if (run == 0) {                                      // one cell beyond the capacity: the general form, on its own lane
-            if (t == c0) cell_general(offs, items, cal, nb, b, W, raysL, raysR, acc);
+            if (t == c0) cell_general<X87>(offs, items, cal, nb, b, W, raysL, raysR, acc);
             c0 += 1;
             continue;
         }
@@ -818,7 +859,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned kn = k2 + 1 < hi[1] ? k2 + 1 : k2;            // the next pair's ray is on its way during this one
                     nxt[0] = s_ray[1][0][kn]; nxt[1] = s_ray[1][1][kn]; nxt[2] = s_ray[1][2][kn];
                     float X[3];
-                    if (line_line(pos[0], ray1, pos[1], ray2, X)) acc.add(cal, X);
+                    if (line_line<X87>(pos[0], ray1, pos[1], ray2, X)) acc.add(cal, X);
                 }
             }
         c0 = c1;
@@ -866,9 +907,16 @@ hipError_t launch_ray_triangulate(const uint32_t *offs, uint32_t *items, const D
     ta.has_T = cal.has_T;
     const uint32_t *order = list, *hist = list + nb;
     const unsigned sb = (unsigned)((nb + kSmallCells - 1) / kSmallCells);
-    SLR_LAUNCH(ray_triangulate_small_kernel, dim3(sb), dim3(kSmallCells), 0, s, offs, (const uint32_t *)items, ta, (unsigned)nb, W, raysL, raysR,
+    if (cal.eval_x87) {                                      // SLR_OPT_EVAL_MODEL = 1 (the ray tables were built under it as well)
+        SLR_LAUNCH(ray_triangulate_small_kernel<true>, dim3(sb), dim3(kSmallCells), 0, s, offs, (const uint32_t *)items, ta, (unsigned)nb, W, raysL,
+                   raysR, order, hist, xyz_sum, count);
+        SLR_LAUNCH(ray_triangulate_staged_kernel<true>, dim3(256), dim3(kTriCells), 0, s, offs, items, ta, (unsigned)nb, W, raysL, raysR, order, hist,
+                   xyz_sum, count);
+        return hipGetLastError();
+    }
+    SLR_LAUNCH(ray_triangulate_small_kernel<false>, dim3(sb), dim3(kSmallCells), 0, s, offs, (const uint32_t *)items, ta, (unsigned)nb, W, raysL, raysR,
                order, hist, xyz_sum, count);
-    SLR_LAUNCH(ray_triangulate_staged_kernel, dim3(256), dim3(kTriCells), 0, s, offs, items, ta, (unsigned)nb, W, raysL, raysR, order, hist,
+    SLR_LAUNCH(ray_triangulate_staged_kernel<false>, dim3(256), dim3(kTriCells), 0, s, offs, items, ta, (unsigned)nb, W, raysL, raysR, order, hist,
                xyz_sum, count);
     return hipGetLastError();
 }

@@ -814,7 +814,9 @@ struct DmaSched {
     }
 };
 
-template <int TW, int TH, int NT, int A, bool HASVALID>
+// X87: SLR_OPT_EVAL_MODEL = 1 -- the heterodyne tail as the reference's MSVC2010 x87 binary rounds it (het_finish_x87,
+// decode_common.hpp; the launcher hands over the x87 variant of the tables): the one place where the two models' decodes differ
+template <int TW, int TH, int NT, int A, bool HASVALID, bool X87 = false>
 struct DmaDecode {
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS, D = A + 1;
@@ -910,7 +912,11 @@ struct DmaDecode {
     }
 
     static __device__ __forceinline__ float pair_q24(int Pa, int Pb) { return dma_pair_q24(Pa, Pb); }
-    static __device__ __forceinline__ float finish_q24(float Fa, float Fb) { return dma_finish_q24(Fa, Fb); }
+    static __device__ __forceinline__ float finish_q24(float Fa, float Fb)
+    {
+        if constexpr (X87) return het_finish_x87(Fa, Fb);
+        else return dma_finish_q24(Fa, Fb);
+    }
 
     // phase P of a tile whose phase 0 uses LDS buffer K0.  voff_cur: this thread's chunk of the current tile's box.
     template <int K0, int P>
@@ -1052,12 +1058,12 @@ constexpr int dma_waves_per_simd()
 template <int LDS_BYTES, int NT>
 constexpr int mf_dma_waves() { return dma_waves_per_simd<LDS_BYTES, NT>() > 6 ? 6 : dma_waves_per_simd<LDS_BYTES, NT>(); }
 
-template <int TW, int TH, int NT, int A, bool HASVALID>
+template <int TW, int TH, int NT, int A, bool HASVALID, bool X87 = false>
 __global__ __launch_bounds__(NT, (HASVALID ? 4 : mf_dma_waves<DmaDecode<TW, TH, NT, A, HASVALID>::LDS_BYTES, NT>())) SLR_TICKET_KERNEL
 void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, const float *__restrict__ lut_g,
                                int tiles_x, int tiles_y, unsigned *__restrict__ sched)
 {
-    typedef DmaDecode<TW, TH, NT, A, HASVALID> Dec;
+    typedef DmaDecode<TW, TH, NT, A, HASVALID, X87> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Dec d;
@@ -1184,7 +1190,7 @@ void mf_rect_decode_dma_kernel(DmaJobs jobs, int njobs, int pitch, int W, int H,
 // for them (and writes junk), and these kernels rewrite them behind it on the same stream: one workgroup per listed tile,
 // every pixel gathered straight from global memory (same make_tap / sample / decode as the direct-gather form).
 // ------------------------------------------------------------------------------------------------------
-template <int TW, int TH>
+template <int TW, int TH, bool X87 = false>
 __global__ __launch_bounds__(256) void mf_rect_fixup_kernel(MfPlanes pl, int pitch, int W, int H, int black_thr,
                                                             const float *__restrict__ lut_g, const int16_t *__restrict__ map_xy,
                                                             const uint16_t *__restrict__ map_frac, const unsigned *__restrict__ list,
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(256) void mf_rect_fixup_kernel(MfPlanes pl, int pit
 #pragma unroll
             for (int k = 0; k < SLR_MF_PLANES; k++) g[k] = sample(pl.p[k], pitch, W, H, tap);
             int v;
-            const float ph = mf_pixel(g, black_thr, lut, v);
+            const float ph = mf_pixel<X87>(g, black_thr, lut, v);
             phase[m] = valid || v ? ph : kInvalidPhase;
             if (valid) valid[m] = (uint8_t)v;
         }
@@ -1280,19 +1286,19 @@ static bool dma_job(const MfPlanes &pl, int pitch, int W, int H, float *phase, u
     return true;
 }
 
-template <int TW, int TH, int NT, int A, bool HV>
+template <int TW, int TH, int NT, int A, bool HV, bool X87 = false>
 static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, const float *lut, unsigned *sched,
                                      hipStream_t s)
 {
-    typedef DmaDecode<TW, TH, NT, A, HV> Dec;
-    auto kern = mf_rect_decode_dma_kernel<TW, TH, NT, A, HV>;
+    typedef DmaDecode<TW, TH, NT, A, HV, X87> Dec;
+    auto kern = mf_rect_decode_dma_kernel<TW, TH, NT, A, HV, X87>;
     static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     int res = resident.get(dev);
     if (!res) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
+        if (e0 != hipSuccess) return e0;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -1304,6 +1310,11 @@ static hipError_t launch_dma_variant(const DmaJobs &j, int njobs, int pitch, int
     const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
+    // The tile tickets start from zero.  The last workgroup of a launch clears them, which is enough as long as every launch runs to
+    // its end; a launch that was aborted (or a debugger detaching) would leave them behind and the next launch would silently skip
+    // or repeat tiles -- 2 KB of memset in stream order in front of every launch rules that out (ADVICE r3 / VERDICT r4 item 11).
+    hipError_t e = hipMemsetAsync(sched, 0, kSchedBytes, s);
+    if (e != hipSuccess) return e;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, lut,
                tiles_x, tiles_y, sched);
     return hipGetLastError();
@@ -1332,8 +1343,13 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
     for (int c = 1; c < n; c++) if ((valid[c] != nullptr) != hv) return hipSuccess;
     *done = true;
     hipError_t e = hipSuccess;
+    // SLR_OPT_EVAL_MODEL = 1: the same kernel with the x87 heterodyne tail (`lut` is then the x87 variant of the tables); it exists at
+    // the default DMA distance only (SLR_OPT_RECT_DMA_DEPTH is a tuning knob of the strict build)
+    const bool x87 = tl_debug.eval_x87;
 #define SLR_DMA_X(TW, TH, NT)                                                                                          \
-    e = depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true>(j, n, pitch, W, H, black_thr, lut, sched, s)     \
+    e = x87        ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true, true>(j, n, pitch, W, H, black_thr, lut, sched, s)     \
+                         : launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), false, true>(j, n, pitch, W, H, black_thr, lut, sched, s))   \
+      : depth >= 2 ? (hv ? launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), true>(j, n, pitch, W, H, black_thr, lut, sched, s)     \
                          : launch_dma_variant<TW, TH, NT, SLR_DMA_DEPTH2(TW, TH, NT), false>(j, n, pitch, W, H, black_thr, lut, sched, s))   \
                    : (hv ? launch_dma_variant<TW, TH, NT, 1, true>(j, n, pitch, W, H, black_thr, lut, sched, s)              \
                          : launch_dma_variant<TW, TH, NT, 1, false>(j, n, pitch, W, H, black_thr, lut, sched, s))
@@ -1345,7 +1361,9 @@ hipError_t launch_mf_rect_decode_dma(const MfPlanes *pl, int n, int pitch, int W
         const unsigned cnt = fix->nofit[slot(c)];
         const int tiles_x = (W + dma_shape_tw(shape) - 1) / dma_shape_tw(shape);
 #define SLR_DMA_X(TW, TH, NT)                                                                                          \
-        hipLaunchKernelGGL((mf_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], pitch, W, H, black_thr, \
+        if (x87) hipLaunchKernelGGL((mf_rect_fixup_kernel<TW, TH, true>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], pitch, W, H, black_thr, \
+                           lut, fix->map_xy[slot(c)], fix->map_frac[slot(c)], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], valid[c]); \
+        else hipLaunchKernelGGL((mf_rect_fixup_kernel<TW, TH>), dim3(cnt * (unsigned)(TW * TH / 256) < 16384u ? cnt * (unsigned)(TW * TH / 256) : 16384u), dim3(256), 0, s, pl[c], pitch, W, H, black_thr, \
                            lut, fix->map_xy[slot(c)], fix->map_frac[slot(c)], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], valid[c])
         SLR_DMA_SHAPE_SWITCH(shape, SLR_DMA_X)
 #undef SLR_DMA_X
@@ -1389,7 +1407,7 @@ constexpr int kGrayDmaNpp = 2;        // plane pairs per phase of the fused Gray
 // same integer heterodyne): ONE pass over one box geometry and one digest gives the code image AND the phase image, the shadow
 // mask computed once.  The reference's modes are exclusive (mainwindow.h:94); each output equals its own mode's decode
 // (reconstruct.cpp:79-97,381-407 and mfreconstruct.cpp:210-269).  Validity travels in-band: code -1 / phase NaN.
-template <int TW, int TH, int NT, int NPP, bool HYB = false>
+template <int TW, int TH, int NT, int NPP, bool HYB = false, bool X87 = false /* HYB: the fringe part under SLR_OPT_EVAL_MODEL = 1 */>
 struct GrayDma {
     static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
     typedef DmaGeom<TW, TH, NT> Gm;
@@ -1491,7 +1509,13 @@ struct GrayDma {
         pm[q] = mx;
         if (m == 1) gxs[q] = (unsigned)Pw;
         else if (m == 3) { fo[q] = dma_pair_q24((int)gxs[q], Pw); gxs[q] = (unsigned)Pw; }
-        else fo[q] = mx != kDmaSentinel ? dma_finish_q24(fo[q], dma_pair_q24((int)gxs[q], Pw)) : kInvalidPhase;
+        else {
+            const float F23 = dma_pair_q24((int)gxs[q], Pw);
+            float ph;
+            if constexpr (X87) ph = het_finish_x87(fo[q], F23);
+            else ph = dma_finish_q24(fo[q], F23);
+            fo[q] = mx != kDmaSentinel ? ph : kInvalidPhase;
+        }
     }
     // the differences of pair j (>= 1) of the thread's pixels go where they belong.  Wave-uniform facts stay out of the per-pixel
     // work: whether the contrast test can fire at all (whiteThreshold's default is 0, SURVEY Q10: it never does), and whether the
@@ -1622,13 +1646,13 @@ constexpr int gray_dma_waves()
     return dma_waves_per_simd<LDS_BYTES, NT>() > cap ? cap : dma_waves_per_simd<LDS_BYTES, NT>();
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false>
+template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false, bool X87 = false>
 __global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB>::LDS_BYTES, NT, NPP>())) SLR_TICKET_KERNEL
 void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
                                  int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched,
                                  const float *__restrict__ lut_g)
 {
-    typedef GrayDma<TW, TH, NT, NPP, HYB> Dec;
+    typedef GrayDma<TW, TH, NT, NPP, HYB, X87> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Dec d;
@@ -1745,19 +1769,19 @@ static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, 
     return true;
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false>
+template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false, bool X87 = false>
 static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol,
                                           int nrow, int scan_w, int scan_h, unsigned *sched, hipStream_t s, const float *lut = nullptr)
 {
-    typedef GrayDma<TW, TH, NT, NPP, HYB> Dec;
-    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD, HYB>;
+    typedef GrayDma<TW, TH, NT, NPP, HYB, X87> Dec;
+    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD, HYB, X87>;
     static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
     int res = resident.get(dev);
     if (!res) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        hipError_t e0 = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Dec::LDS_BYTES);
+        if (e0 != hipSuccess) return e0;
         int per_cu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NT, Dec::LDS_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
@@ -1769,6 +1793,8 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
     const int r = (tl_debug.rect_resident > 0 ? tl_debug.rect_resident : res) / njobs;   // tests: few workgroups -> many tiles each
     int nbx = r / 8 < per ? r / 8 : per;
     if (nbx < 1) nbx = 1;
+    hipError_t e = hipMemsetAsync(sched, 0, kSchedBytes, s);         // (the tickets start from zero: see launch_dma_variant)
+    if (e != hipSuccess) return e;
     SLR_LAUNCH(kern, dim3(8u * (unsigned)nbx * (unsigned)njobs), dim3(NT), Dec::LDS_BYTES, s, j, njobs, pitch, W, H, black_thr, white_thr,
                ncol, nrow, scan_w, scan_h, tiles_x, tiles_y, sched, lut);
     return hipGetLastError();
@@ -1859,8 +1885,11 @@ hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, 
     *done = true;
     constexpr int NPP = kHybNpp;
     const bool odd = ((((1 + ncol + 6) + NPP - 1) / NPP) & 1) != 0;     // phases (of NPP plane pairs) per tile
-    hipError_t e = odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
-                       : launch_gray_dma_variant<128, 16, 512, NPP, false, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut);
+    const bool x87 = tl_debug.eval_x87;                     // (`lut` is then the x87 variant of the tables)
+    hipError_t e = x87 ? (odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
+                              : launch_gray_dma_variant<128, 16, 512, NPP, false, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut))
+                       : (odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
+                              : launch_gray_dma_variant<128, 16, 512, NPP, false, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut));
     // tiles the form does not hold: the two gather fix-ups, one per output
     for (int c = 0; c < n && e == hipSuccess; c++) {
         if (!fix || fix->nofit[c] == 0) continue;
@@ -1872,7 +1901,9 @@ hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, 
         hipLaunchKernelGGL((gray_rect_fixup_kernel<128, 16>), dim3(grid), dim3(256), 0, s, pl[c], ncol, 0, pitch, W, H, black_thr, white_thr,
                            scan_w, 0, fix->map_xy[c], fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, code_x[c],
                            (int32_t *)nullptr, (uint8_t *)nullptr);
-        hipLaunchKernelGGL((mf_rect_fixup_kernel<128, 16>), dim3(grid), dim3(256), 0, s, mp, pitch, W, H, black_thr, lut, fix->map_xy[c],
+        if (x87) hipLaunchKernelGGL((mf_rect_fixup_kernel<128, 16, true>), dim3(grid), dim3(256), 0, s, mp, pitch, W, H, black_thr, lut, fix->map_xy[c],
+                           fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], (uint8_t *)nullptr);
+        else hipLaunchKernelGGL((mf_rect_fixup_kernel<128, 16>), dim3(grid), dim3(256), 0, s, mp, pitch, W, H, black_thr, lut, fix->map_xy[c],
                            fix->map_frac[c], dma_nofit_list(tiles[c], W, H, shape), cnt, tiles_x, phase[c], (uint8_t *)nullptr);
         e = hipGetLastError();
     }

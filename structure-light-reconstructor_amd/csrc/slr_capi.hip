@@ -131,7 +131,6 @@ int mf_rect_algo(const slr_ctx *c, int a, int b)
 bool dma_form_wanted(const slr_ctx *c, int a, int b)
 {
     if (c->opt_rect_algo != 0 && c->opt_rect_algo != 7) return false;
-    if (c->debug.eval_x87) return false;                    // SLR_OPT_EVAL_MODEL = 1 runs the plain forms (launch_mf_decode_x87)
     for (int cam = a; cam <= b; cam++) {
         if (!c->d_dma_tiles[cam] || c->dma_shape_built[cam] != c->opt_dma_shape) return false;
         if (4ull * c->dma_stats[cam][0] > dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape)) return false;
@@ -735,7 +734,8 @@ int slr_get_rectify_info(slr_ctx *c, int cam, slr_rectify_info *out)
     const bool dma = dma_form_wanted(c, cam, cam);
     // an explicit 7 that these maps do not allow (no tables, or too many tiles that no split makes fit) makes the decode calls
     // fail with SLR_ERR_UNSUPPORTED: report that (-1), not the form auto would have fallen back to
-    out->mf_form = dma ? 7 : c->opt_rect_algo == 7 ? -1
+    // (SLR_OPT_EVAL_MODEL = 1 has the LDS-DMA form and the per-pixel gather only: round 1's register-staged forms 2..6 are strict-model kernels)
+    out->mf_form = dma ? 7 : c->opt_rect_algo == 7 ? -1 : c->debug.eval_x87 ? 1
                  : (c->opt_rect_algo != 0 ? c->opt_rect_algo : mf_rect_algo(c, cam, cam));
     out->dma_shape = c->opt_dma_shape; out->dma_depth = c->opt_dma_depth;
     if (c->d_dma_tiles[cam] && c->dma_shape_built[cam] == c->opt_dma_shape) {
@@ -929,7 +929,7 @@ int slr_mfn_rectify_decode(slr_ctx *c, int cam, const uint16_t *const *planes, i
         SLR_TRY(get_scratch(c, S_STAGE0 + 1, n * 4, &dph));
         SLR_TRY(get_scratch(c, S_STAGE0 + 2, n, &dv));
     }
-    { ProfScope ps(c, K_MFN_RECT_DECODE, true);
+    { ProfScope ps(c, K_MFN_RECT_DECODE);                   // (not "exact": the LDS-DMA form is two launches, the decode and its fix-up pass)
       SLR_HIP(c, launch_mfn_rect_decode(dp, n_freq, n_step, pitch, W, H, black_thr, c->d_map_xy[cam], c->d_map_frac[cam], row0, rows,
                                         src_row0, src_rows, (float *)dph, (uint8_t *)dv, c->stream)); }
     if (mem != SLR_MEM_DEVICE) {
@@ -1168,6 +1168,18 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
     return core_mf_match(c, (const float *)phL, nullptr, (const float *)phR, nullptr, W, H, xyz, has, nullptr);
 }
 
+// Frames per group of the batch entries.  The phase scratch of a group costs 8 bytes per pixel and frame (0.8 GB at 4096x3000 with
+// the default 8), so a group is only as large as it pays: SLR_OPT_MF_BATCH_GROUP frames when ONE match launch can take them (the
+// lean K4: stereoRectify's Q, rows of 2049..4096 pixels, W % 4 == 0 -- the pointer-independent part of mf_match_batches_frames),
+// else no more than one fused-decode launch serves (SLR_OPT_MF_BATCH_DECODE_GROUP, when the LDS-DMA form applies), else 1.
+static int mf_batch_group_of(const slr_ctx *c, int W, int rectify)
+{
+    const bool match_groups = (c->opt_mf_match_algo == 0 || c->opt_mf_match_algo == 4) && c->cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0;
+    if (match_groups) return c->opt_mf_batch_group;
+    const int dg = rectify && dma_form_wanted(c, 0, 1) ? c->opt_mf_decode_group : 1;
+    return dg < c->opt_mf_batch_group ? dg : c->opt_mf_batch_group;
+}
+
 // the checks slr_reconstruct_mf_batch applies to its arguments (also run for EVERY context of a multi-GPU call before any of
 // them is given work)
 static int mf_batch_check(slr_ctx *c, int pitch, int W, int H, int rectify)
@@ -1265,8 +1277,9 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
     // K4 reads 12 bytes of per-CALIBRATION undistortion tables per pixel (a third of its traffic): the frames of a batch are decoded
     // into a phase scratch of `group` frames and matched by ONE launch whose workgroups take a row of all those frames one after the
     // other on the same XCD -- the tables come from HBM once per group (SLR_OPT_MF_BATCH_GROUP, default 8; 1 = frame by frame)
+    const int gmax = mf_batch_group_of(c, W, rectify);
     for (int f0 = 0; f0 < n_frames;) {
-        const int g = n_frames - f0 < c->opt_mf_batch_group ? n_frames - f0 : c->opt_mf_batch_group;
+        const int g = n_frames - f0 < gmax ? n_frames - f0 : gmax;
         void *phL = nullptr, *phR = nullptr;
         if (g > 1) {
             SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));
@@ -1408,8 +1421,9 @@ int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack,
     void *phL, *phR, *cxs = nullptr;
     if (!code_x) SLR_TRY(get_scratch(c, S_CODEX_L, n * 8, &cxs));      // nobody wants the codes: one scratch pair for every frame
     // as slr_reconstruct_mf_batch: the phases of a group of frames, ONE match launch per group (the undistortion tables once per group)
+    const int gmax = mf_batch_group_of(c, W, 1);
     for (int f0 = 0; f0 < n_frames;) {
-        const int g = n_frames - f0 < c->opt_mf_batch_group ? n_frames - f0 : c->opt_mf_batch_group;
+        const int g = n_frames - f0 < gmax ? n_frames - f0 : gmax;
         SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));
         SLR_TRY(get_scratch(c, S_PHASE_R, (size_t)g * n * 4, &phR));
         // two-launch mode: the fringe decodes (white, black, 12 fringes behind the Gray planes) of up to 8 frames in ONE launch of the
@@ -1922,7 +1936,9 @@ int slr_set_option(slr_ctx *c, int option, int value)
             c->debug.rect_resident = value;
             return SLR_OK;
         case SLR_OPT_DEBUG_FLAGS:
-            if (value < 0 || value > 127) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..127");
+            if (value < 0 || value > 511) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_DEBUG_FLAGS must be 0..511");
+            c->debug.mfn_nt512 = (value & 128) != 0;
+            c->debug.mfn_ring4 = (value & 256) != 0;
             c->debug.no_tiled_map = (value & 1) != 0;
             c->debug.no_buffer_form = (value & 2) != 0;
             c->debug.no_ge_lean = (value & 4) != 0;
@@ -1968,10 +1984,11 @@ int slr_set_option(slr_ctx *c, int option, int value)
                 int lut[kDecodeLutWords];
                 if (!build_decode_lut(lut, value != 0)) return fail(c, SLR_ERR_HIP, "decode table layout");
                 SLR_TRY(use_device(c));
-                SLR_HIP(c, hipStreamSynchronize(c->stream));         // no launch may still be reading the old tables
+                SLR_HIP(c, hipDeviceSynchronize());                  // no launch (on the context's stream or its pipeline stream) may still be reading the old tables
                 SLR_HIP(c, hipMemcpy(c->d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
                 c->debug.eval_x87 = value != 0;
                 c->cal.eval_x87 = value;
+                c->rays_valid = false;                               // GRAY_ONLY's unit-ray tables depend on the model (pixel_ray, kernels_ray.hip)
             }
             return SLR_OK;
         }
@@ -2008,6 +2025,15 @@ int slr_timer_end(slr_ctx *c, float *ms)
     SLR_HIP(c, hipEventRecord(c->t1, c->stream));
     SLR_HIP(c, hipEventSynchronize(c->t1));
     SLR_HIP(c, hipEventElapsedTime(ms, c->t0, c->t1));
+    return SLR_OK;
+}
+
+int slr_stream_copy(slr_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (bytes % 16 != 0 || (uintptr_t)dst % 16 != 0 || (uintptr_t)src % 16 != 0) return fail(c, SLR_ERR_INVALID_ARG, "slr_stream_copy: 16-byte granularity");
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, launch_stream_copy(src, dst, bytes, c->stream));
     return SLR_OK;
 }
 

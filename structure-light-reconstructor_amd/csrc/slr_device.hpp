@@ -70,6 +70,8 @@ struct DebugKnobs {
     bool no_quad_sort = false;   // LDS-DMA fused decodes: every wave keeps the quads of its own block of the tile (read when maps are installed)
     bool no_promote = false;     // LDS-DMA fused decodes: straddling waves keep the three-row read mode (no promotion to per-pixel reads)
     bool gray_small_tiles = false;// fused Gray decode, LDS-tiled form: 64 x 4 tiles whatever the plane count (else: 42 planes and more)
+    bool mfn_nt512 = false;      // config 5, LDS-DMA rectified decode: 512 threads x 2 pixels instead of 256 x 4
+    bool mfn_ring4 = false;      // config 5, LDS-DMA rectified decode: a ring of 4 plane groups (two workgroups per CU) instead of 3
     int k4_stop = 0;
     bool poison_scratch = false; // SLR_OPT_DEBUG_POISON_SCRATCH
     bool eval_x87 = false;       // SLR_OPT_EVAL_MODEL = 1 (not a debug knob, but it travels the same way: per call, per thread)
@@ -183,6 +185,7 @@ hipError_t launch_ge_match(const int32_t *codeL, const uint8_t *validL, const in
 hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                              float *phase, uint8_t *valid, hipStream_t s);
 hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_frames, size_t n_px, unsigned long long *d_out, hipStream_t s);
+hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes /* multiple of 16, both 16-byte aligned */, hipStream_t s);
 hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                                   const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
                                   float *phase, uint8_t *valid, hipStream_t s);

@@ -32,9 +32,25 @@ def local_slots(assembled, rank, world, assignment="cyclic"):
     return assembled[rank::world] if assignment == "cyclic" else assembled[rank * S:(rank + 1) * S]
 
 
+def _alias(out, src, rank):
+    """How `src` lies relative to `out` for an all-gather whose chunk `rank` is src-sized: "inplace" -- src IS chunk `rank` of out
+    (RCCL / NCCL's in-place rule: sendbuff == recvbuff + rank * count), "disjoint" -- no byte in common, "overlap" -- anything else
+    (never valid as an aliased input: the caller must hand a copy)."""
+    sz = src.numel() * src.element_size()
+    o0, s0 = out.data_ptr(), src.data_ptr()
+    if s0 + sz <= o0 or s0 >= o0 + out.numel() * out.element_size():
+        return "disjoint"
+    return "inplace" if (src.is_contiguous() and out.is_contiguous() and s0 == o0 + rank * sz) else "overlap"
+
+
 def _all_gather(out, src, group):
-    """dist.all_gather_into_tensor, in place on RCCL when `src` is this rank's own chunk of `out`; a gloo group (the CPU tests,
-    the dry run of the N > 1 path on a one-GPU box) gets host tensors and a private copy of an aliased input."""
+    """dist.all_gather_into_tensor, in place on RCCL when `src` is this rank's own chunk of `out` (checked: an aliased input that
+    is NOT at recvbuff + rank * count would corrupt the result or hang, and only on hardware with two or more GPUs) -- any other
+    aliasing gets a private copy; a gloo group (the CPU tests, the dry run of the N > 1 path on a one-GPU box) gets host tensors
+    and a private copy of an aliased input."""
+    kind = _alias(out, src, dist.get_rank(group))
+    if kind == "overlap":
+        src = src.clone()
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out, src, group=group)
     elif out.is_cuda:
@@ -43,7 +59,7 @@ def _all_gather(out, src, group):
         dist.all_gather_into_tensor(host, src.cpu(), group=group)
         out.copy_(host)
     else:
-        dist.all_gather_into_tensor(out, src.clone(), group=group)
+        dist.all_gather_into_tensor(out, src.clone() if kind == "inplace" else src, group=group)
 
 
 def gather_point_clouds(xyz_local, has_local, n_frames, group=None, out=None, assignment="cyclic"):
@@ -78,15 +94,24 @@ def gather_point_clouds(xyz_local, has_local, n_frames, group=None, out=None, as
 
 
 def frame_checksums(xyz, has):
-    """One 64-bit word per frame of xyz [n][H][W][3] f32 / has [n][H][W] u8: position-weighted sums of the raw bits (wrapping
-    int64 arithmetic), computed on the arrays' device.  Used to prove an assembled cloud: every rank checksums its LOCAL
-    results, the words travel by a second (tiny) all-gather, and each gathered frame must reproduce its owner's word."""
+    """One 64-bit word per frame of xyz [n][H][W][3] f32 / has [n][H][W] u8: sums of the raw bits weighted per ELEMENT -- by row
+    and by position inside the row (wrapping int64 arithmetic) -- so that a shifted or permuted row, swapped channels or pixels
+    and a misaligned chunk all change the word, not only a changed row sum.  Computed on the arrays' device.  Used to prove an
+    assembled cloud: every rank checksums its LOCAL results, the words travel by a second (tiny) all-gather, and each gathered
+    frame must reproduce its owner's word.  (The library's own proof, slr_cloud_checksums, weights per pixel and channel too; the
+    two are different functions and are never compared with each other.)"""
     n, H = xyz.shape[0], xyz.shape[1]
     w = torch.arange(1, H + 1, dtype=torch.int64, device=xyz.device)
     out = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    wx = wh = None
     for f in range(n):
-        rx = xyz[f].contiguous().view(torch.int32).view(H, -1).sum(dim=1, dtype=torch.int64)
-        rh = has[f].contiguous().view(H, -1).sum(dim=1, dtype=torch.int64)
+        bx = xyz[f].contiguous().view(torch.int32).view(H, -1)
+        bh = has[f].contiguous().view(H, -1)
+        if wx is None:
+            wx = torch.arange(bx.shape[1], dtype=torch.int64, device=xyz.device) % 65521 + 1
+            wh = torch.arange(bh.shape[1], dtype=torch.int64, device=xyz.device) % 65521 + 1
+        rx = (bx.to(torch.int64) * wx).sum(dim=1)
+        rh = (bh.to(torch.int64) * wh).sum(dim=1)
         out[f] = (rx * w).sum() * 1000003 + (rh * w).sum()
     return out
 
@@ -130,7 +155,13 @@ def reconstruct_sharded(n_frames, H, W, load_frame, reconstruct, device, group=N
     g_has = torch.zeros((S * world, H, W), dtype=torch.uint8, device=device)
     loc_xyz, loc_has = local_slots(g_xyz, rank, world, assignment), local_slots(g_has, rank, world, assignment)
     for s, f in enumerate(shard_frames(n_frames, rank, world, assignment)):
-        reconstruct(load_frame(f), loc_xyz[s], loc_has[s])
+        try:
+            reconstruct(load_frame(f), loc_xyz[s], loc_has[s])
+        except TypeError as e:
+            if "positional argument" in str(e):              # a callback of the old signature reconstruct(frame) -> (xyz, has)
+                raise TypeError("reconstruct_sharded: `reconstruct` must take (frame, xyz_out, has_out) and write the frame's cloud "
+                                "into the two views (round 4 changed the signature from reconstruct(frame) -> (xyz, has))") from e
+            raise
     mine = frame_checksums(loc_xyz, loc_has) if verify else None              # before the (in-place) gather touches anything
     xyz, has = gather_point_clouds(loc_xyz, loc_has, n_frames, group, out=(g_xyz, g_has), assignment=assignment)
     if verify:

@@ -49,6 +49,28 @@ def _worker(rank, world, port, n_frames, out_dir, assignment="cyclic"):
         has_out.copy_(torch.from_numpy(has))
 
     assert sdist.shard_frames(n_frames, rank, world) == list(range(rank, n_frames, world))
+    # On RCCL the gather is IN PLACE (the shard already lies in its place in the assembled arrays); gloo un-aliases its input, so
+    # the in-place rule (sendbuff == recvbuff + rank * count) would otherwise never be checked without two GPUs.  Here every
+    # collective of the job is intercepted: the backend reports "nccl", the aliasing every call arrives with is recorded and
+    # must be NCCL's in-place form (or disjoint buffers), and the exchange itself then runs over gloo on a private copy.
+    real_gather, seen = dist.all_gather_into_tensor, []
+
+    def checked_gather(out, src, group=None):
+        kind = sdist._alias(out, src, dist.get_rank(group))
+        seen.append(kind)
+        assert kind in ("inplace", "disjoint"), "an all-gather input that overlaps its output outside the in-place rule"
+        if kind == "inplace":
+            assert src.data_ptr() == out.data_ptr() + dist.get_rank(group) * src.numel() * src.element_size()
+        return real_gather(out, src.clone(), group=group)
+
+    sdist.dist.get_backend, keep_backend = (lambda group=None: "nccl"), sdist.dist.get_backend
+    sdist.dist.all_gather_into_tensor = checked_gather
+    try:
+        xyz_n, has_n = sdist.reconstruct_sharded(n_frames, H, W, lambda f: f, reconstruct, torch.device("cpu"), verify=True,
+                                                 assignment=assignment)
+    finally:
+        sdist.dist.get_backend, sdist.dist.all_gather_into_tensor = keep_backend, real_gather
+    assert "inplace" in seen                                 # the shard slots really were gathered in place
     xyz, has = sdist.reconstruct_sharded(n_frames, H, W, lambda f: f, reconstruct, torch.device("cpu"), verify=True,
                                          assignment=assignment)
     # the proof must be able to fail: a frame that is not its owner's makes verify_gathered raise on every rank
@@ -58,6 +80,7 @@ def _worker(rank, world, port, n_frames, out_dir, assignment="cyclic"):
     if mine.shape[0] < S:
         mine = torch.cat([mine, sdist.frame_checksums(torch.zeros((S - mine.shape[0], H, W, 3)), torch.zeros((S - mine.shape[0], H, W), dtype=torch.uint8))])
     assert sdist.verify_gathered(xyz, has, mine, n_frames, assignment=assignment) == n_frames
+    assert torch.equal(xyz_n.view(torch.int32), xyz.view(torch.int32)) and torch.equal(has_n, has)   # the "nccl" route == the gloo route
     broken = xyz.clone()
     broken[1, 3, 5, 0] += 1.0
     try:
@@ -118,6 +141,22 @@ def test_shard_helpers():
     assert c.shape == (2,) and c[0] != c[1]
     x2 = x.clone(); x2[0, 0, 0, 0], x2[0, 1, 0, 0] = x[0, 1, 0, 0], x[0, 0, 0, 0]      # two rows' values exchanged: position-weighted
     assert sdist.frame_checksums(x2, h)[0] != c[0] and sdist.frame_checksums(x2, h)[1] == c[1]
+    # ... per ELEMENT: a swap inside a row (two pixels, two channels) and a shifted mask row change the word as well
+    x3 = x.clone(); x3[0, 0, 0, 0], x3[0, 0, 1, 0] = x[0, 0, 1, 0], x[0, 0, 0, 0]
+    x4 = x.clone(); x4[0, 0, 0, 0], x4[0, 0, 0, 2] = x[0, 0, 0, 2], x[0, 0, 0, 0]
+    assert sdist.frame_checksums(x3, h)[0] != c[0] and sdist.frame_checksums(x4, h)[0] != c[0]
+    h2 = torch.zeros_like(h); h2[0, 0, 0] = 1
+    h3 = torch.zeros_like(h); h3[0, 0, 1] = 1
+    assert sdist.frame_checksums(x, h2)[0] != sdist.frame_checksums(x, h3)[0]
+    # the aliasing rule of the in-place all-gather, both assignments (world 2, 3 slots per rank)
+    g = torch.zeros((6, 4, 5, 3))
+    for rank in range(2):
+        blk, cyc = sdist.local_slots(g, rank, 2, "blocked"), sdist.local_slots(g, rank, 2, "cyclic")
+        assert sdist._alias(g, blk, rank) == "inplace" and sdist._alias(g, blk, 1 - rank) == "overlap"
+        for s_ in range(3):
+            assert sdist._alias(g[2 * s_:2 * s_ + 2], cyc[s_:s_ + 1], rank) == "inplace"
+            assert sdist._alias(g[2 * s_:2 * s_ + 2], cyc[s_:s_ + 1], 1 - rank) == "overlap"
+    assert sdist._alias(g, torch.zeros((3, 4, 5, 3)), 0) == "disjoint" and sdist._alias(g, g[1:4], 0) == "overlap"
 
 
 # ---- row-band sharding of one frame (config 5) ---------------------------------------------------------------

@@ -127,3 +127,76 @@ def test_x87_fullsize_decode_and_sampled_match(xctx, oracle, synth):
     x, h, mk = xctx.mf_triangulate(ph[0][r0:r1], vd[0][r0:r1], ph[1][r0:r1], vd[1][r0:r1], row0=r0, image_h=H)
     ex, eh, emk = oracle.mf_triangulate_ev(ph[0], vd[0], ph[1], vd[1], camL, camR, Q, 1, T=T, rows=(r0, r1))
     assert bits_equal(np.asarray(mk), emk[r0:r1]) and bits_equal(np.asarray(h), eh[r0:r1]) and bits_equal(np.asarray(x), ex[r0:r1])
+
+
+# ---- GRAY_ONLY under the x87 model: normalize / pixelToImageSpace / line_lineIntersection (utilities.cpp:19-28, 47-56, 399-425) ----
+@pytest.mark.parametrize("W,H,scan_w,scan_h,with_T", [(160, 120, 64, 48, False), (96, 64, 40, 33, True), (1024, 768, 300, 200, False)])
+def test_x87_ray_triangulate_against_the_x87_oracle(xctx, ctx, oracle, synth, W, H, scan_w, scan_h, with_T):
+    """K6 with SLR_OPT_EVAL_MODEL = 1 (unit-ray tables and the ray-ray midpoints as the x87 binary rounds them) == the oracle's x87
+    restatement, bit for bit; the default context still computes the strict model, and the two differ on these scenes"""
+    calib, _ = synth.make_calibration(W, H, with_T=with_T, baseline=400.0, theta=0.6)
+    xctx.set_calibration(calib)
+    ctx.set_calibration(calib)
+    camL, camR, _, T = calib_parts(oracle, calib)
+    st = synth.render_gray_stack(W, H, scan_w, scan_h, seed=41, noise=2, rows=True)
+    ncol, nrow = synth.gray_num_bits(scan_w), synth.gray_num_bits(scan_h)
+    dec = [oracle.gray_decode(st[c].numpy(), ncol, nrow, BLACK, 0, scan_w, scan_h) for c in range(2)]
+    offL, itL = oracle.gray_bucket(dec[0][0], dec[0][1], dec[0][2], scan_w, scan_h)
+    offR, itR = oracle.gray_bucket(dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    exyz, ecnt = oracle.ray_triangulate_x87(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    sxyz, scnt = oracle.ray_triangulate(offL, itL, offR, itR, camL, camR, scan_w, scan_h, T)
+    xyz, cnt = xctx.ray_triangulate(dec[0][0], dec[0][1], dec[0][2], dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    assert bits_equal(cnt, ecnt) and bits_equal(xyz, exyz)
+    assert (ecnt > 1).any()
+    x0, c0 = ctx.ray_triangulate(dec[0][0], dec[0][1], dec[0][2], dec[1][0], dec[1][1], dec[1][2], scan_w, scan_h)
+    assert bits_equal(c0, scnt) and bits_equal(x0, sxyz)
+    assert not bits_equal(sxyz, exyz)                      # (the models differ here: a silent strict path would be noticed)
+    # the whole-path entry (decode + buckets + K6 from the planes) under the x87 model
+    x2, c2 = xctx.reconstruct_gray(st[0].cuda(), st[1].cuda(), ncol, nrow, BLACK, 0, scan_w, scan_h)
+    xctx.synchronize()
+    assert bits_equal(c2.cpu().numpy(), ecnt) and bits_equal(x2.cpu().numpy(), exyz)
+
+
+def test_x87_line_line_intersections(xctx, oracle):
+    """Utilities::line_lineIntersection under the x87 model on rays of many scales, around the |denom| < 0.1 rejection and nearly
+    perpendicular ones, against the oracle's restatement (slro_line_line_intersection_x87) on a sample, and against an independent
+    NumPy float64 transcription of the same rules on all of them"""
+    rng = np.random.default_rng(78)
+    n = 200000
+    f = np.float32
+
+    def unit(m):
+        v = rng.standard_normal((m, 3)); return v / np.linalg.norm(v, axis=1, keepdims=True)
+    v1 = unit(n); v2 = unit(n)
+    q = n // 4
+    v1[q:2 * q] *= np.exp2(rng.integers(-20, 12, (q, 1))); v2[q:2 * q] *= np.exp2(rng.integers(-20, 12, (q, 1)))
+    ang = np.arcsin(np.sqrt(np.linspace(0.0995, 0.1005, q)))                                             # sin^2 around 0.1
+    v2[2 * q:3 * q] = v1[2 * q:3 * q] * np.cos(ang)[:, None] + np.cross(v1[2 * q:3 * q], unit(q)) * np.sin(ang)[:, None]
+    v1 = v1.astype(f); v2 = v2.astype(f)
+    p1 = np.array([3.5, -20.25, 1000.0], f); p2 = np.array([-410.0, 7.0, 955.5], f)
+    D = np.float64
+    with np.errstate(all="ignore"):
+        def d3(a, b):                                       # Vec3f::dot: product exact at 53 bits, one rounding to f32 per step
+            s = np.zeros(a.shape[:-1] if a.ndim > 1 else b.shape[:-1], f)
+            for i in range(3):
+                s = (s.astype(D) + a[..., i].astype(D) * b[..., i].astype(D)).astype(f)
+            return s
+        v12 = (p1 - p2)[None]
+        a = d3(v1, v1); c = d3(v2, v2); b = d3(v1, v2); d = d3(v12, v1); e = d3(v12, v2)
+        den = (a.astype(D) * c.astype(D) - b.astype(D) * b.astype(D)).astype(f)
+        hit = ~(np.abs(den) < f(0.1))
+        bq, cq, aq = b.astype(D) / den.astype(D), c.astype(D) / den.astype(D), a.astype(D) / den.astype(D)
+        s_ = (bq * e.astype(D) - cq * d.astype(D)).astype(f)
+        t_ = (-bq * d.astype(D) + aq * e.astype(D)).astype(f)
+        exp = f(0.5) * ((p1[None] + s_[:, None] * v1) + (p2[None] + t_[:, None] * v2))
+    exp[~hit] = 0
+    for i in rng.integers(0, n, 3000):                       # the NumPy transcription is the oracle's
+        ok_i, o_i = oracle.line_line_intersection_x87(p1, v1[i], p2, v2[i])
+        assert ok_i == bool(hit[i])
+        if ok_i and np.isfinite(o_i).all():
+            assert bits_equal(o_i, exp[i]), i
+    out, ok = xctx.line_line_intersections(p1, p2, v1, v2)
+    assert np.array_equal(ok != 0, hit)
+    fin = np.isfinite(exp).all(axis=1)
+    assert fin.sum() > 0.9 * n and 0.3 * q < hit[2 * q:3 * q].sum() < 0.7 * q
+    assert bits_equal(out[fin], exp[fin])

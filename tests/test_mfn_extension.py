@@ -249,14 +249,14 @@ def test_gpu_mfn_rectify_tiled_form_equals_the_gather_form(ctx, slr, synth, W, H
     """the LDS-tiled form of the 4 x 8 rectifying decode (contiguous stack, W % 8 == 0: what config 5 runs) against the per-pixel
     gather form (SLR_OPT_DEBUG_FLAGS bit 0), bit for bit: ragged last tiles, borders, maps whose tile boxes do not fit the LDS image
     (strength 40: those tiles run the gather code -- inside the register-staged kernel, in the LDS-DMA form's fix-up pass), row bands
-    with source windows.  Flags 0 / 16: the LDS-DMA form (ring of 3 / 4 plane groups; + 8: 512 threads x 2 pixels), 2: the register-staged tile form."""
+    with source windows.  Flags 0 / 256: the LDS-DMA form (ring of 3 / 4 plane groups; + 128: 512 threads x 2 pixels), 2: the register-staged tile form."""
     F, N = 4, 8
     st = synth.render_mfn_stack(W, H, F, N, noise=0.5, seed=W + H).cuda()
     for cam in range(2):
         mx, mf = synth.make_rectify_maps(W, H, cam, strength=strength)
         ctx.set_rectify_maps(cam, mx.numpy(), mf.numpy())
     res = {}
-    for flags in (1, 0, 2, 16, 8, 24):                  # gather; LDS-DMA 256 x 4, ring of 3 (shipped); register-staged tiles; ring of 4; the 512-thread LDS-DMA forms
+    for flags in (1, 0, 2, 256, 128, 384):                  # gather; LDS-DMA 256 x 4, ring of 3 (shipped); register-staged tiles; ring of 4; the 512-thread LDS-DMA forms
         ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, flags)
         out = []
         for cam in range(2):
@@ -269,7 +269,7 @@ def test_gpu_mfn_rectify_tiled_form_equals_the_gather_form(ctx, slr, synth, W, H
         ctx.synchronize()
         res[flags] = out
     ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
-    for flags in (0, 2, 16, 8, 24):
+    for flags in (0, 2, 256, 128, 384):
         assert len(res[flags]) == len(res[1])
         for a, b in zip(res[flags], res[1]):
             assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), flags

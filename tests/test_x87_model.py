@@ -135,3 +135,13 @@ def test_x87_line_line_intersection_against_numpy():
         ok0, strict = O.line_line_intersection(p1, v1, p2, v2)
         ndiff += int(ok0 and not np.array_equal(strict.view(np.int32), got.view(np.int32)))
     assert ndiff > 0                                    # the two models do differ in the last places (that is the point)
+
+
+def test_x87_quotient_by_constant():
+    """decode_common.hpp's het_finish_x87 forms P123 / (2*PI) -- an f64 division under the x87 model -- as one multiply and two
+    fused multiply-adds with constants.  Every value P123 can take on the device (all integers d = P123 * 2^24 before the f32
+    rounding of the store, 1 .. 2 * (2*PI * 2^24) + 1) gives the division's bits; the range beyond, too."""
+    two_pi_q24 = int(np.float32(2) * PI * np.float32(16777216.0))
+    assert two_pi_q24 == 105414600
+    assert O.x87_quotient_mismatches(0, 2 * two_pi_q24 + 2) == 0
+    assert O.x87_quotient_mismatches((1 << 30) - 3000000, 1 << 30) == 0
