@@ -647,27 +647,38 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         qe[i] = act ? i1 * 8u : 0u;
     }
     const char *const pkb = reinterpret_cast<const char *>(sh.b.pk2);
+    // X87: the exact-difference predicate needs f64 only where the f32 difference can round.  Sterbenz: for floats with
+    // c in [p / 2, 2 p] the difference p - c is exact in f32.  With |p| >= 0.25 every candidate within 0.125 of p lies in that
+    // range, so its f32 difference IS the exact one and `fabsf(p - c) < 0.1f` is the x87 predicate bit for bit; a candidate
+    // further away than 0.125 fails both predicates (a rounded difference of 0.125 or more never drops below 0.1).  Only pixels
+    // with a phase inside (-0.25, 0.25) -- a few per frame -- need the f64 form: a wave that holds one runs it for all its lanes.
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         unsigned bk = 0xFFFFFFFFu;
         const float p = pl[i];
-        for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
-            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
-            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
-            unsigned h0, h1, h2, h3;
-            if constexpr (X87) {
-                const double pd = (double)p;
-                h0 = fabs(pd - (double)c0.x) < 0.1 ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
-                h1 = fabs(pd - (double)c0.z) < 0.1 ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
-                h2 = fabs(pd - (double)c1.x) < 0.1 ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
-                h3 = fabs(pd - (double)c1.z) < 0.1 ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
-            } else {
-                h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
-                h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
-                h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
-                h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+        bool wide = false;
+        if constexpr (X87) wide = __ballot(qa[i] < qe[i] && !(fabsf(p) >= 0.25f)) != 0ull;      // (wave-uniform)
+        if (X87 && wide) {
+            const double pd = (double)p;
+            for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                const unsigned h0 = fabs(pd - (double)c0.x) < 0.1 ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                const unsigned h1 = fabs(pd - (double)c0.z) < 0.1 ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                const unsigned h2 = fabs(pd - (double)c1.x) < 0.1 ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                const unsigned h3 = fabs(pd - (double)c1.z) < 0.1 ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                bk = min(min(bk, h0), min(h1, min(h2, h3)));
             }
-            bk = min(min(bk, h0), min(h1, min(h2, h3)));
+        } else {
+            for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                bk = min(min(bk, h0), min(h1, min(h2, h3)));
+            }
         }
         best[i] = (int)bk;                               // 0xFFFFFFFF == -1: no match
     }

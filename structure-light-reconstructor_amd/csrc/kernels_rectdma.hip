@@ -1407,16 +1407,22 @@ constexpr int kGrayDmaNpp = 2;        // plane pairs per phase of the fused Gray
 // same integer heterodyne): ONE pass over one box geometry and one digest gives the code image AND the phase image, the shadow
 // mask computed once.  The reference's modes are exclusive (mainwindow.h:94); each output equals its own mode's decode
 // (reconstruct.cpp:79-97,381-407 and mfreconstruct.cpp:210-269).  Validity travels in-band: code -1 / phase NaN.
-template <int TW, int TH, int NT, int NPP, bool HYB = false, bool X87 = false /* HYB: the fringe part under SLR_OPT_EVAL_MODEL = 1 */>
+// A (round 5): DMA issue distance.  A = 1 is the form above (two buffers, every phase drains the vector-memory queue).  A = 2 is
+// the multi-frequency kernel's scheme with this kernel's run-time phase count: THREE buffers of one plane pair each, the planes of
+// phase k + 2 issued during phase k, and COUNTED waits -- every wave issues the same static sequence of LDS-DMA operations, so the
+// wait at the top of phase k lets exactly the operations issued during phase k - 1 stay in flight (see phase2()).
+template <int TW, int TH, int NT, int NPP, bool HYB = false, bool X87 = false /* HYB: the fringe part under SLR_OPT_EVAL_MODEL = 1 */, int A = 1>
 struct GrayDma {
     static_assert(NPP == 1 || NPP == 2, "plane pairs per phase");
+    static_assert(A == 1 || (A == 2 && NPP == 1), "DMA distance 2: one plane pair per phase, three buffers");
+    static constexpr int D = A + 1;                                         // LDS buffers of 2 * NPP plane images
     typedef DmaGeom<TW, TH, NT> Gm;
     static constexpr int PX = Gm::PX, PS = Gm::PS, RS = Gm::RS;
     // SPLIT (twice as many threads as a plane image has chunks): the waves' first half fetches the first half of a phase's
     // 2 * NPP planes, the second half the rest
     static constexpr bool SPLIT = 2 * Gm::NCH <= NT;
     // dynamic LDS from address 0: 2 buffers of 2 * NPP plane images | digest of the tile | weight tables
-    static constexpr int DIG_OFF = 4 * NPP * PS, DIG_BYTES = TW * TH * 4;     // (no scratch slot: waves without chunks issue no DMAs)
+    static constexpr int DIG_OFF = D * 2 * NPP * PS, DIG_BYTES = TW * TH * 4; // (no scratch slot: waves without chunks issue no DMAs)
     // (HYB with two plane pairs per phase: the blend weights are computed per tile instead of tabulated -- the 8 KB the tables
     //  take would push the workgroup over a third of the CU's LDS)
     static constexpr bool NOWT = HYB && NPP == 2;
@@ -1637,6 +1643,80 @@ struct GrayDma {
         }
         if (k < nq) phase<K ^ 1, false>(k, ty, tx, act, voff_cur);
     }
+
+    // ---- A = 2 ------------------------------------------------------------------------------------------------------------------
+    // LDS-DMA operations a wave issues, in program order (the static sequence the counted waits rely on), nq >= 4 phases per tile:
+    //   phase k:  [k == 2: PX / 4 digest DMAs of the next tile]  PLANE_DMAS plane DMAs of phase k + 2 (of the next tile from nq - 2 on)
+    // At the top of phase k the planes of phase k must have landed; what was issued behind them is phase k - 1's share of the
+    // sequence: PLANE_DMAS, plus the digest DMAs when k - 1 == 2.  Loads retire in order among themselves; the previous tile's
+    // output stores (issued in phase 0, behind that phase's DMAs) are NOT counted, so the wait of phase 1 also retires them (as in
+    // the multi-frequency kernel: a count that included them could pass with a DMA still pending).  The ticket of the next tile is
+    // drawn in phase 0 and picked up in phase 1, its digest fetched in phase 2 (the digest in LDS is only read in phase 0), its
+    // first planes in phases nq - 2 and nq - 1.
+    static constexpr int PLANE_DMAS2 = SPLIT ? 1 : 2;
+    template <int B, bool FIRST>
+    __device__ __forceinline__ void phase2(int k, int ty, int tx, bool act, unsigned voff_cur)
+    {
+        static_assert(A == 2, "the counted-wait form");
+        if (plane_wave) {
+            if (k == 3) wait_vm<PLANE_DMAS2 + PX / 4>(); else wait_vm<PLANE_DMAS2>();
+        } else if (FIRST) wait_vm<0>();                      // (a wave without chunks only waits for its share of the digest)
+        asm volatile("s_barrier" ::: "memory");
+        if constexpr (FIRST) sc.draw();
+        else if (k == 1) sc.pick_up();
+        if (k == 2) issue_digest((unsigned)sc.nxt, sc.has_next);
+        {
+            const int kp = k + 2;
+            const bool nxt_tile = kp >= nq;
+            issue_planes(nxt_tile ? kp - nq : kp, (B + 2) % 3, nxt_tile ? sc.voff_next : voff_cur);
+        }
+        if constexpr (FIRST) {
+            if (out_pending) flush();
+            out_pending = false;
+        }
+        if (!act) {
+            if constexpr (FIRST) sc.publish();
+            return;
+        }
+        if constexpr (FIRST) {
+            const unsigned *dg = reinterpret_cast<const unsigned *>(smem + DIG_OFF + threadIdx.x * (PX * 4));
+            mode = dma_tap_setup<PX, RS, TAP_WT, WT1_OFF>(smem, lds0, dg, tap, qbase, second, oslot);
+#pragma unroll
+            for (int q = 0; q < PX; q++) { acc[q] = 0; gxs[q] = 0; }
+            flags = 0;
+        }
+        constexpr unsigned i00 = (unsigned)(B * 2 * PS), i01 = i00 + PS;
+        __builtin_amdgcn_s_setprio(1);
+        {
+            int sd[PX];
+            dma_differences<PX, i00, i01, (unsigned)RS>(mode, tap, qbase, second, sd);
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int q = 0; q < PX; q++) flags |= (sd[q] > black_thr ? 1u : 0u) << q;   // computeShadows, reconstruct.cpp:218-224
+            } else pair_steps(k, sd);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if constexpr (FIRST) sc.publish();
+        const bool last = k + 1 == nq;
+        if (HYB ? (k == ncol && !FIRST) : last) finish(ty, tx);
+        if (HYB && last) { out_ty = ty; out_tx = tx; out_pending = true; }
+    }
+    // a tile whose phase 0 uses buffer K0; the next tile's phase 0 uses buffer (K0 + nq) % 3
+    template <int K0>
+    __device__ __forceinline__ void tile2(int ty, int tx, bool act, unsigned voff_cur)
+    {
+        phase2<K0, true>(0, ty, tx, act, voff_cur);
+        int k = 1;
+        for (; k + 2 < nq; k += 3) {
+            phase2<(K0 + 1) % 3, false>(k, ty, tx, act, voff_cur);
+            phase2<(K0 + 2) % 3, false>(k + 1, ty, tx, act, voff_cur);
+            phase2<K0, false>(k + 2, ty, tx, act, voff_cur);
+        }
+        if (k < nq) {
+            phase2<(K0 + 1) % 3, false>(k, ty, tx, act, voff_cur);
+            if (k + 1 < nq) phase2<(K0 + 2) % 3, false>(k + 1, ty, tx, act, voff_cur);
+        }
+    }
 };
 
 template <int LDS_BYTES, int NT, int NPP>
@@ -1646,13 +1726,15 @@ constexpr int gray_dma_waves()
     return dma_waves_per_simd<LDS_BYTES, NT>() > cap ? cap : dma_waves_per_simd<LDS_BYTES, NT>();
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false, bool X87 = false>
-__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB>::LDS_BYTES, NT, NPP>())) SLR_TICKET_KERNEL
+// ROT: how the buffer of a tile's phase 0 moves from tile to tile -- A = 1: the phase count's parity (1 = the two buffers swap
+// roles), A = 2: the phase count mod 3
+template <int TW, int TH, int NT, int NPP, int ROT, bool HYB = false, bool X87 = false, int A = 1>
+__global__ __launch_bounds__(NT, (gray_dma_waves<GrayDma<TW, TH, NT, NPP, HYB, X87, A>::LDS_BYTES, NT, NPP>())) SLR_TICKET_KERNEL
 void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol, int nrow,
                                  int scan_w, int scan_h, int tiles_x, int tiles_y, unsigned *__restrict__ sched,
                                  const float *__restrict__ lut_g)
 {
-    typedef GrayDma<TW, TH, NT, NPP, HYB, X87> Dec;
+    typedef GrayDma<TW, TH, NT, NPP, HYB, X87, A> Dec;
     typedef DmaGeom<TW, TH, NT> Gm;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Dec d;
@@ -1724,19 +1806,22 @@ void gray_rect_decode_dma_kernel(GrayDmaJobs jobs, int njobs, int pitch, int W, 
     bool cur_act;
     unsigned voff_cur = d.sc.box_voff(cur, cur_ty, cur_tx, cur_act);
     d.out_pending = false;
-    d.issue_digest((unsigned)cur, true);                    // prologue = what the last phase of a previous tile would have issued
+    d.issue_digest((unsigned)cur, true);                    // prologue = what the last phase(s) of a previous tile would have issued
     d.issue_planes(0, 0, voff_cur);
+    if constexpr (A == 2) d.issue_planes(1, 1, voff_cur);
 
     for (;;) {
 #define SLR_GDMA_TILE(K0)                                                                                      \
         {                                                                                                      \
-            d.template tile<K0>(cur_ty, cur_tx, cur_act, voff_cur);                                            \
+            if constexpr (A == 2) d.template tile2<K0>(cur_ty, cur_tx, cur_act, voff_cur);                     \
+            else d.template tile<K0>(cur_ty, cur_tx, cur_act, voff_cur);                                       \
             if (!d.sc.has_next) break;                                                                         \
             cur = d.sc.nxt; voff_cur = d.sc.voff_next;                                                         \
             cur_ty = d.sc.nxt_ty; cur_tx = d.sc.nxt_tx; cur_act = d.sc.nxt_act;                                \
         }
         SLR_GDMA_TILE(0)
-        if constexpr (ODD) SLR_GDMA_TILE(1)
+        if constexpr (ROT != 0) SLR_GDMA_TILE(ROT % Dec::D)
+        if constexpr (A == 2 && ROT != 0) SLR_GDMA_TILE((2 * ROT) % Dec::D)
 #undef SLR_GDMA_TILE
     }
     // (only what a tile left behind: a wave that was idle in every entry its workgroup decoded -- parts of split tiles as a workgroup's
@@ -1769,12 +1854,12 @@ static bool gray_dma_job(const GrayPlanes &pl, int np, int pitch, int W, int H, 
     return true;
 }
 
-template <int TW, int TH, int NT, int NPP, bool ODD, bool HYB = false, bool X87 = false>
+template <int TW, int TH, int NT, int NPP, int ROT, bool HYB = false, bool X87 = false, int A = 1>
 static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int pitch, int W, int H, int black_thr, int white_thr, int ncol,
                                           int nrow, int scan_w, int scan_h, unsigned *sched, hipStream_t s, const float *lut = nullptr)
 {
-    typedef GrayDma<TW, TH, NT, NPP, HYB, X87> Dec;
-    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ODD, HYB, X87>;
+    typedef GrayDma<TW, TH, NT, NPP, HYB, X87, A> Dec;
+    auto kern = gray_rect_decode_dma_kernel<TW, TH, NT, NPP, ROT, HYB, X87, A>;
     static DevSlots resident;                             // resident workgroups of this kernel, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1804,7 +1889,7 @@ static hipError_t launch_gray_dma_variant(const GrayDmaJobs &j, int njobs, int p
 // layout, image width, a tile shape without a Gray instantiation), nothing was launched
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
+                                       uint8_t *const *valid, const void *const *tiles, int shape, int depth, unsigned *sched, const DmaFixup *fix,
                                        bool *done, hipStream_t s, const int *fix_slot)
 {
     *done = false;
@@ -1824,10 +1909,17 @@ hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, in
     *done = true;
     constexpr int NPP = kGrayDmaNpp;
     const bool odd = ((((1 + ncol + nrow) + NPP - 1) / NPP) & 1) != 0;   // phases (of NPP plane pairs) per tile
+    // round 5: the counted-wait form (DMA distance 2, one plane pair per phase) whenever a tile has the four phases it needs;
+    // depth 1 (SLR_OPT_RECT_DMA_DEPTH) keeps round 2's form, two plane pairs per phase and a drained queue every phase
+    const int nq2 = 1 + ncol + nrow;
+    const bool a2 = nq2 >= 4 && depth >= 2;
     hipError_t e = hipSuccess;
 #define SLR_GDMA_X(TW, TH, NT)                                                                                                     \
-    e = odd ? launch_gray_dma_variant<TW, TH, NT, NPP, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)    \
-            : launch_gray_dma_variant<TW, TH, NT, NPP, false>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)
+    e = a2 ? (nq2 % 3 == 0 ? launch_gray_dma_variant<TW, TH, NT, 1, 0, false, false, 2>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)   \
+            : nq2 % 3 == 1 ? launch_gray_dma_variant<TW, TH, NT, 1, 1, false, false, 2>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)   \
+                           : launch_gray_dma_variant<TW, TH, NT, 1, 2, false, false, 2>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s))  \
+      : odd ? launch_gray_dma_variant<TW, TH, NT, NPP, 1>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)    \
+            : launch_gray_dma_variant<TW, TH, NT, NPP, 0>(j, n, pitch, W, H, black_thr, white_thr, ncol, nrow, scan_w, scan_h, sched, s)
     switch (shape) {
     case 1:  SLR_GDMA_X(256, 8, 512); break;
 #ifdef SLR_ALL_FORMS
@@ -1886,10 +1978,10 @@ hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, 
     constexpr int NPP = kHybNpp;
     const bool odd = ((((1 + ncol + 6) + NPP - 1) / NPP) & 1) != 0;     // phases (of NPP plane pairs) per tile
     const bool x87 = tl_debug.eval_x87;                     // (`lut` is then the x87 variant of the tables)
-    hipError_t e = x87 ? (odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
-                              : launch_gray_dma_variant<128, 16, 512, NPP, false, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut))
-                       : (odd ? launch_gray_dma_variant<128, 16, 512, NPP, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
-                              : launch_gray_dma_variant<128, 16, 512, NPP, false, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut));
+    hipError_t e = x87 ? (odd ? launch_gray_dma_variant<128, 16, 512, NPP, 1, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
+                              : launch_gray_dma_variant<128, 16, 512, NPP, 0, true, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut))
+                       : (odd ? launch_gray_dma_variant<128, 16, 512, NPP, 1, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut)
+                              : launch_gray_dma_variant<128, 16, 512, NPP, 0, true>(j, n, pitch, W, H, black_thr, white_thr, ncol, 0, scan_w, 0, sched, s, lut));
     // tiles the form does not hold: the two gather fix-ups, one per output
     for (int c = 0; c < n && e == hipSuccess; c++) {
         if (!fix || fix->nofit[c] == 0) continue;

@@ -393,7 +393,7 @@ int core_gray_decode(slr_ctx *c, int cam, bool rectify, const uint8_t *const *pl
         const void *const tl[1] = {c->d_dma_tiles[cam]};
         const DmaFixup fix = dma_fixup_of(c, cam, cam);
         SLR_HIP(c, launch_gray_rect_decode_dma(&gp, 1, ncol, nrow, pitch, W, H, black_thr, white_thr, scan_w, scan_h, xs, ys, vd, tl,
-                                               c->opt_dma_shape, c->d_sched, &fix, &done, c->stream));
+                                               c->opt_dma_shape, c->opt_dma_depth, c->d_sched, &fix, &done, c->stream));
         if (done) return SLR_OK;
     }
     if (rectify && c->opt_rect_algo == 7)
@@ -1342,7 +1342,7 @@ static int hybrid_pair_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_t *
             const DmaFixup fix = dma_fixup_of(c, 0, 1);
             ProfScope ps(c, K_GRAY_RECT_DECODE_PAIR, true);
             SLR_HIP(c, launch_gray_rect_decode_dma(gp, 2, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, xs, ys, vd, tl,
-                                                   c->opt_dma_shape, c->d_sched, &fix, &paired, c->stream));
+                                                   c->opt_dma_shape, c->opt_dma_depth, c->d_sched, &fix, &paired, c->stream));
         }
         if (!paired) {
             SLR_TRY(core_gray_decode(c, 0, true, pL, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, cxL, nullptr, nullptr));
@@ -1500,7 +1500,7 @@ int slr_reconstruct_ge(slr_ctx *c, const uint8_t *const *planesL, const uint8_t 
         ProfScope ps(c, K_GRAY_RECT_DECODE_PAIR, true);
         const DmaFixup fix = dma_fixup_of(c, 0, 1);
         SLR_HIP(c, launch_gray_rect_decode_dma(gp, 2, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0, xs, ys, vd, tl,
-                                               c->opt_dma_shape, c->d_sched, &fix, &paired, c->stream));
+                                               c->opt_dma_shape, c->opt_dma_depth, c->d_sched, &fix, &paired, c->stream));
     }
     if (!paired) {
         SLR_TRY(core_gray_decode(c, 0, rectify != 0, dl, ncol, 0, pitch, W, H, black_thr, white_thr, scan_w, 0,

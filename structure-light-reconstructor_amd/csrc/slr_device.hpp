@@ -151,7 +151,8 @@ size_t     dma_sched_bytes();
 
 hipError_t launch_gray_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int nrow, int pitch, int W, int H, int black_thr,
                                        int white_thr, int scan_w, int scan_h, int32_t *const *code_x, int32_t *const *code_y,
-                                       uint8_t *const *valid, const void *const *tiles, int shape, unsigned *sched, const DmaFixup *fix,
+                                       uint8_t *const *valid, const void *const *tiles, int shape, int depth /* SLR_OPT_RECT_DMA_DEPTH: 2 = the
+                                       counted-wait form (round 5), 1 = round 2's form */, unsigned *sched, const DmaFixup *fix,
                                        bool *done, hipStream_t s, const int *fix_slot = nullptr);
 // BASELINE config 3: Gray code + multi-frequency phase in ONE pass over a hybrid stack (kernels_rectdma.hip)
 hipError_t launch_hybrid_rect_decode_dma(const GrayPlanes *pl, int n, int ncol, int pitch, int W, int H, int black_thr, int white_thr,

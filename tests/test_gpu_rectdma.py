@@ -232,3 +232,35 @@ def test_split_tiles_as_a_workgroups_only_entries(dma_ctx, slr, synth, W, H):
         ctx.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
         ctx.set_option(slr.capi.OPT_RECT_DECODE_ALGO, 0)
         ctx.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 0)
+
+
+@pytest.mark.parametrize("W,H,scan_w,scan_h,strength,resident", [(640, 200, 1100, 0, 1.0, 0), (1280, 96, 100, 37, 2.0, 8), (512, 130, 5, 0, 1.0, 16),
+                                                                 (2048, 64, 4096, 600, 1.5, 0), (400 // 16 * 16, 77, 300, 7, 3.0, 8), (256, 40, 4, 0, 1.0, 0)])
+def test_gray_dma_counted_wait_form_equals_the_drained_form_and_the_oracle(dma_ctx, slr, oracle, synth, W, H, scan_w, scan_h, strength, resident):
+    """The fused Gray decode's round-5 form (SLR_OPT_RECT_DMA_DEPTH = 2, the default: three LDS buffers of one plane pair, the
+    planes of phase k + 2 in flight, counted vmcnt waits) against round 2's form (depth 1: two buffers, the queue drained every
+    phase) and the oracle's remap + getProjPixel (reconstruct.cpp:325-407): phase counts 1 + ncol + nrow of every residue mod 3
+    (the buffer of a tile's phase 0 rotates by that from tile to tile), too few phases for the form (falls back), many tiles
+    per workgroup, both tile shapes, codes + rows + valid bytes."""
+    ctx = dma_ctx
+    ncol, nrow = synth.gray_num_bits(scan_w), (synth.gray_num_bits(scan_h) if scan_h else 0)
+    st = synth.render_gray_stack(W, H, scan_w, scan_h if scan_h else None, seed=W + ncol, noise=2, rows=scan_h > 0)
+    ctx.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, resident)
+    for cam in range(2):
+        mx, mf = synth.make_rectify_maps(W, H, cam, strength=strength)
+        mxn, mfn = mx.numpy(), mf.numpy()
+        raw = st[cam].numpy()
+        rect = np.stack([oracle.remap_u8(raw[p], mxn, mfn) for p in range(raw.shape[0])])
+        ex, ey, ev = oracle.gray_decode(rect, ncol, nrow, BLACK, 3, scan_w, scan_h)
+        dev = st[cam].cuda()
+        for shape in (3, 1):
+            for depth in (2, 1):
+                _opts(ctx, slr, 0, shape, depth)
+                ctx.set_rectify_maps(cam, mxn, mfn)
+                assert ctx.rectify_info(cam)["mf_form"] in (7, 5, 6)
+                cx, cy, v = ctx.gray_decode(dev, ncol, nrow, BLACK, 3, scan_w, scan_h, rectify_cam=cam)
+                ctx.synchronize()
+                assert bits_equal(np_of(v), ev) and bits_equal(np_of(cx), ex), (shape, depth, cam)
+                if nrow:
+                    assert bits_equal(np_of(cy), ey), (shape, depth, cam)
+        assert (ev != 0).mean() > 0.2

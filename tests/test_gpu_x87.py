@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import bits_equal, calib_parts
+from util import bits_equal, calib_parts, forms
 
 pytestmark = pytest.mark.gpu
 
@@ -171,7 +171,8 @@ def test_x87_line_line_intersections(xctx, oracle):
     q = n // 4
     v1[q:2 * q] *= np.exp2(rng.integers(-20, 12, (q, 1))); v2[q:2 * q] *= np.exp2(rng.integers(-20, 12, (q, 1)))
     ang = np.arcsin(np.sqrt(np.linspace(0.0995, 0.1005, q)))                                             # sin^2 around 0.1
-    v2[2 * q:3 * q] = v1[2 * q:3 * q] * np.cos(ang)[:, None] + np.cross(v1[2 * q:3 * q], unit(q)) * np.sin(ang)[:, None]
+    perp = np.cross(v1[2 * q:3 * q], unit(q)); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    v2[2 * q:3 * q] = v1[2 * q:3 * q] * np.cos(ang)[:, None] + perp * np.sin(ang)[:, None]
     v1 = v1.astype(f); v2 = v2.astype(f)
     p1 = np.array([3.5, -20.25, 1000.0], f); p2 = np.array([-410.0, 7.0, 955.5], f)
     D = np.float64
@@ -200,3 +201,83 @@ def test_x87_line_line_intersections(xctx, oracle):
     fin = np.isfinite(exp).all(axis=1)
     assert fin.sum() > 0.9 * n and 0.3 * q < hit[2 * q:3 * q].sum() < 0.7 * q
     assert bits_equal(out[fin], exp[fin])
+
+
+def _flip_pairs(rng, n):
+    """n (left phase t, right phase b) pairs of floats, |t| < 0.25, whose EXACT difference lies between the midpoint of the two
+    floats around 0.1 and the double 0.1: the x87 predicate accepts them, the f32 difference rounds up to 0.1f and the strict one
+    does not.  (No such pair exists with |t| >= 0.25: Sterbenz.)"""
+    f = np.float32
+    lo = (np.float64(np.nextafter(f(0.1), f(0))) + np.float64(f(0.1))) / 2
+    out = []
+    while len(out) < n:
+        t = f(rng.random() * 0.5 - 0.25)
+        side = 1.0 if rng.random() < 0.5 else -1.0
+        b0 = np.array(f(np.float64(t) + side * 0.1))
+        for u in rng.permutation(7) - 3:
+            b = (b0.view(np.int32) + np.int32(u)).view(f)[()]
+            if lo < abs(np.float64(t) - np.float64(b)) < 0.1:
+                out.append((t, b))
+                break
+    return out
+
+
+@pytest.mark.parametrize("W", [700, 4096, 3000 // 4 * 4, 8192])
+def test_x87_match_predicate_on_adversarial_rows(xctx, ctx, oracle, synth, slr, W):
+    """mfreconstruct.cpp:295 under the x87 model -- fabs of the EXACT difference < 0.1 -- where it differs from the strict
+    predicate: a left phase inside (-0.25, 0.25) and a right phase whose exact difference to it lies just below 0.1 while the f32
+    difference rounds up to 0.1f.  Rows 0-11: one such pair per row (the edge candidate in an early column, an exact match in a
+    later one: the x87 search stops at the first, the strict one at the second), the left phase varying along the row in three
+    well separated levels; rows 12-17: left phases of 0.25 and more with candidates an ulp or two around the edge (the lean
+    kernel's f32 fast path: both models agree there); the rest random.  The lean kernel, the general forms and the sweep against the
+    oracle's x87 search; the strict context against the strict oracle on the same rows."""
+    rng = np.random.default_rng(W + 5)
+    H = 24
+    f = np.float32
+    calib, _ = synth.make_calibration(W, H, with_T=(W == 700))
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    for c in (xctx, ctx):
+        c.set_calibration(calib)
+    phL = (rng.random((H, W)) * 600 + 50).astype(f)
+    phR = (rng.random((H, W)) * 600 + 1000).astype(f)                               # far from every left phase
+    for r in range(12):
+        pairs = _flip_pairs(rng, 3)
+        lv = np.array([q[0] for q in pairs], f)
+        # three levels at least 0.25 apart would not fit (-0.25, 0.25): keep the levels in separate column ranges of the left row and
+        # give each its own edge candidate; a candidate may also match another level's pixels -- the oracle decides, both models see it
+        seg = W // 3
+        for m_, (t, b) in enumerate(pairs):
+            phL[r, m_ * seg:(m_ + 1) * seg if m_ < 2 else W] = t
+            k1 = int(rng.integers(0, W // 2))
+            phR[r, k1] = b
+            phR[r, W // 2 + int(rng.integers(0, W // 2))] = t                      # an exact match further right
+    for r in range(12, 18):
+        big = (rng.random(W) * 400 + 0.25).astype(f)
+        if r >= 16:
+            big[:] = f(0.25) if r == 16 else np.nextafter(f(0.25), f(0))           # the boundary of the fast path itself
+        side = np.where(rng.random(W) < 0.5, 1.0, -1.0)
+        edge = ((big.astype(np.float64) + side * 0.1).astype(f).view(np.int32) + rng.integers(-2, 3, W).astype(np.int32)).view(f)
+        phL[r] = big
+        phR[r] = edge[rng.permutation(W)]
+    vL = (rng.random((H, W)) < 0.97).astype(np.uint8)
+    vR = np.ones((H, W), np.uint8)
+    exyz, ehas, emk = oracle.mf_triangulate_ev(phL, vL, phR, vR, camL, camR, Q, 1, T=T)
+    sxyz, shas, smk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
+    assert (emk[:12] != smk[:12]).sum() > W                  # the predicates differ on the flip rows ...
+    assert bits_equal(emk[12:18], smk[12:18]) and ehas[12:16].sum() > 0                # ... and not where |phase| >= 0.25
+    for algo in forms(xctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 4, 3, 1), required=(0, 4, 3, 1)):
+        xctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
+        xyz, has, mk = xctx.mf_triangulate(phL, vL, phR, vR)
+        assert bits_equal(mk, emk), algo
+        assert bits_equal(has, ehas) and bits_equal(xyz, exyz), algo
+    xctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
+    xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
+    assert bits_equal(mk, smk) and bits_equal(has, shas) and bits_equal(xyz, sxyz)
+    # the whole-path form of the call (no valid bytes, NaN-folded, device arrays, no match columns): what the batch entry launches
+    nan = f(np.nan)
+    fl = np.where(vL != 0, phL, nan).astype(f)
+    ones = np.ones((H, W), np.uint8)
+    x2, h2, _ = xctx.mf_triangulate(torch.from_numpy(fl).cuda(), torch.from_numpy(ones).cuda(), torch.from_numpy(phR).cuda(),
+                                    torch.from_numpy(ones).cuda(), want_match=False)
+    xctx.synchronize()
+    assert bits_equal(h2.cpu().numpy(), ehas) and bits_equal(x2.cpu().numpy(), exyz)
