@@ -178,9 +178,15 @@ const char  *slr_last_error(const slr_ctx *ctx);
  *       ulx - urx is stored to a double unrounded (mfreconstruct.cpp:246-268, :295, :299).  On BASELINE's scene the two models
  *       differ in the last place of 37 % of the phases and pick another first-match column for 2.2-2.4 % of the matched pixels
  *       (tests/x87_sensitivity.py); neither can be pinned without the MSVC2010 toolchain, so a host that must
- *       match the shipped Windows binary chooses here.  Mode 1 runs the plain kernel forms (per-pixel gather for the rectifying
- *       decode, the general match kernel) and real f64 divisions: about 1.5x the time per frame.  Gray-code modes are integer
- *       work up to the Q reprojection and are the same under both. */
+ *       match the shipped Windows binary chooses here.  Since round 5 mode 1 runs the SAME kernels as mode 0 -- the LDS-DMA fused
+ *       decode (single, pair and grouped launches, the hybrid stack's too) with the x87 variant of the wrapped-phase table and
+ *       a three-instruction f64 quotient by 2*PI, the lean match kernel (grouped launches included) with the exact-difference
+ *       predicate where it can differ at all (|phase| < 0.25: Sterbenz) and the unrounded disparity -- at 1-2 % more time per
+ *       frame (bench.py --eval-model x87); bit for bit against oracle/slr_oracle_x87.c on whole 4096x3000 frames
+ *       (tests/test_gpu_timed_path.py).  GRAY_ONLY (slr_ray_triangulate / slr_reconstruct_gray / slr_line_line_intersections):
+ *       normalize, pixelToImageSpace and line_lineIntersection (utilities.cpp:19-28, 47-56, 399-425) keep their 53-bit
+ *       intermediates under mode 1 as well (the unit-ray tables are rebuilt when the mode changes); GRAY_EPI is integer work up to
+ *       the f64 Q reprojection and is the same under both. */
 #define SLR_OPT_EVAL_MODEL 14
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 

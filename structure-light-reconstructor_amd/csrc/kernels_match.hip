@@ -793,6 +793,268 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[0], best[1], best[2], best[3]);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K4, lean form, PERSISTENT (round 5; the grouped launches of slr_reconstruct_mf_batch: no valid bytes, no match columns).
+// mf_match_lean_kernel<1024, ., true, ., .> with the rows of a launch walked by 2 resident workgroups per CU instead of one
+// workgroup per row: with the undistortion tables coming from L2 (frames grouped) the kernel is no longer waiting for HBM but for
+// its own VALU work (79 % busy) -- and for the 16 bytes per pixel of phases at the head of every row, which nothing overlapped
+// inside a workgroup.  Here a workgroup issues the loads of its NEXT row's phases (8 registers) before it starts on the current
+// one, so they arrive during ~13 us of index build and queries; the launch / argument-load / tail of 24000 short workgroups
+// goes as well.  Same arithmetic, same LDS layout, same results (tests/test_gpu_lean.py: == the per-row form, bit for bit).
+// Workgroup w runs on XCD w % 8 and takes the items q = w / 8, w / 8 + G / 8, ... of that XCD: item q = (row (q / nframes) * 8 + xcd,
+// frame q % nframes) -- a row of all frames on the same XCD, close in time, as in the per-row form.
+// ------------------------------------------------------------------------------------------------------
+template <bool HAS_T, bool TAME, bool X87>
+__global__ __launch_bounds__(1024, 8) void mf_match_lean_persist_kernel(const float *__restrict__ phaseL0, const float *__restrict__ phaseR0,
+                                                                        int W, int H, int row0, K4Lean kc,
+                                                                        const float4 *__restrict__ undL, const float *__restrict__ undRx,
+                                                                        float *__restrict__ xyz0, uint8_t *__restrict__ has0,
+                                                                        int nframes, size_t frame_px)
+{
+    constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT, TS = 2 * N, kPer = kBins / BLOCK;
+    constexpr unsigned kEmpty = 0xFFFFFFFFu;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ union {
+        struct { unsigned key[TS]; unsigned mink[TS]; } t;               // phase bits -> smallest column
+        struct { f32x4 pk2[N / 2 + 3]; unsigned bs[kBins + 3]; } b;      // pairs of (phi, column as bits) grouped by bin (+ sentinels, + a sink); bin index
+    } sh;
+    __shared__ unsigned scan_tmp[BLOCK / 64];
+    static_assert(sizeof(sh.b) <= sizeof(sh.t), "the index must fit the dead hash table (two workgroups per CU)");
+
+    const int tid = threadIdx.x, k0 = tid * IPT;
+    const bool inrow = k0 < W;                           // W % 4 == 0: a thread's 4 pixels are all inside or all outside
+    const int xcd = (int)blockIdx.x & 7, lw = (int)blockIdx.x >> 3, nl = (int)gridDim.x >> 3;
+    const int items = ((H - xcd + 7) / 8) * nframes;     // rows xcd, xcd + 8, ... of every frame
+    auto item_of = [&](int q, int &brow, size_t &fo) { brow = (q / nframes) * 8 + xcd; fo = (size_t)(q % nframes) * frame_px; };
+
+    // pr / pl: the current row's phases.  Each is re-loaded for the NEXT row right behind its last use in the current one (pr: the
+    // scatter of the pairs; pl: the queries) -- into the same registers, so the prefetch costs none (a second set of 8 spilled at
+    // the 64 registers of two 1024-thread workgroups per CU)
+    float pr[IPT] = {0, 0, 0, 0}, pl[IPT] = {0, 0, 0, 0};
+    if (lw < items && inrow) {
+        int brow; size_t fo;
+        item_of(lw, brow, fo);
+        load_f32_blocked<IPT>(phaseR0 + fo + (size_t)brow * W, k0, k0 + IPT, true, pr);
+        load_f32_blocked<IPT>(phaseL0 + fo + (size_t)brow * W, k0, k0 + IPT, true, pl);
+    }
+#pragma unroll 1
+    for (int q = lw; q < items; q += nl) {
+        int brow; size_t fo;
+        item_of(q, brow, fo);
+        float *const xyz = xyz0 + 3 * fo;
+        uint8_t *const has = has0 + fo;
+        const int row = brow + row0;
+        const size_t base = (size_t)brow * W, trow = (size_t)row * W;
+        const bool more = q + nl < items && inrow;
+        size_t nbase = 0;                                // the next item's row, as an offset into the phase arrays
+        if (more) { int nb; size_t nfo; item_of(q + nl, nb, nfo); nbase = nfo + (size_t)nb * W; }
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+            u32x4 *const t4 = reinterpret_cast<u32x4 *>(sh.t.key);   // (key and mink are adjacent: the whole table in 16-byte stores)
+#pragma unroll
+            for (int j = 0; j < 2 * TS / 4 / BLOCK; j++) t4[tid + j * BLOCK] = e4;
+        }
+        __syncthreads();
+
+        // A. distinct values and their smallest column (as mf_match_lean_kernel)
+        unsigned slot[IPT], bits[IPT], old[IPT];
+        bool cand[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            bits[i] = __float_as_uint(pr[i]);
+            const bool ok = inrow && (pr[i] == pr[i]);               // NaN (= no phase) can never satisfy the predicate
+            const bool dup = i > 0 && ok && bits[i] == bits[i - 1];
+            cand[i] = ok && !dup;
+            slot[i] = (bits[i] * 2654435761u) >> (32 - __builtin_ctz(TS));
+        }
+#pragma unroll
+        for (int i = 0; i < IPT; i++) old[i] = cand[i] ? atomicCAS(&sh.t.key[slot[i]], kEmpty, bits[i]) : kEmpty;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            if (cand[i]) {
+                unsigned h = slot[i], o = old[i];
+                while (o != kEmpty && o != bits[i]) {
+                    h = (h + 1) & (TS - 1);
+                    o = atomicCAS(&sh.t.key[h], kEmpty, bits[i]);
+                }
+                atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
+                slot[i] = h;
+            }
+        }
+        __syncthreads();
+        unsigned *const cnt = sh.t.key;                      // the key half is dead: bin counters (+ one sink per thread)
+        unsigned repmask = 0;
+        unsigned mk4[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) mk4[i] = sh.t.mink[slot[i]];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) cnt[tid + j * BLOCK] = 0u;
+#pragma unroll
+        for (int i = 0; i < IPT; i++)
+            if (cand[i] && mk4[i] == (unsigned)(k0 + i)) repmask |= 1u << i;
+        __syncthreads();                                     // the whole table is dead from here on
+
+        // B. counting sort of the representatives by phase bin
+        unsigned bin[IPT], rank[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) bin[i] = (repmask >> i) & 1u ? (unsigned)phase_bin(pr[i]) : (unsigned)(kBins + tid);
+#pragma unroll
+        for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&cnt[bin[i]], 1u);
+        __syncthreads();
+        float2 *const pk = reinterpret_cast<float2 *>(sh.b.pk2);
+        {
+            unsigned c[kPer], sum = 0;
+#pragma unroll
+            for (int j = 0; j < kPer; j++) { c[j] = cnt[tid * kPer + j]; sum += c[j]; }
+            unsigned total;
+            unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);
+#pragma unroll
+            for (int j = 0; j < kPer; j++) { sh.b.bs[1 + tid * kPer + j] = excl; excl += c[j]; }   // bs lies in the mink half
+            if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
+        }
+        __syncthreads();
+        {
+            const unsigned total = sh.b.bs[kBins + 1];
+            if (tid < 4) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
+            unsigned st[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; i++) st[i] = sh.b.bs[1 + ((repmask >> i) & 1u ? bin[i] : (unsigned)kBins)];
+#pragma unroll
+            for (int i = 0; i < IPT; i++) {
+                const unsigned at = (repmask >> i) & 1u ? st[i] + rank[i] : (unsigned)N + 4u;
+                pk[at] = make_float2(pr[i], __uint_as_float((unsigned)(k0 + i)));
+            }
+        }
+        if (more) load_f32_blocked<IPT>(phaseR0 + nbase, k0, k0 + IPT, true, pr);     // the next row's right phases: in flight from here
+        __syncthreads();
+
+        // queries
+        int best[IPT];
+        unsigned qa[IPT], qe[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const bool act = inrow && pl[i] == pl[i];
+            const int b = phase_bin(pl[i]);
+            const unsigned i0 = sh.b.bs[b], i1 = sh.b.bs[b + 3];
+            qa[i] = (i0 & ~1u) * 8u;
+            qe[i] = act ? i1 * 8u : 0u;
+        }
+        const char *const pkb = reinterpret_cast<const char *>(sh.b.pk2);
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            unsigned bk = 0xFFFFFFFFu;
+            const float p = pl[i];
+            bool wide = false;
+            if constexpr (X87) wide = __ballot(qa[i] < qe[i] && !(fabsf(p) >= 0.25f)) != 0ull;      // (see mf_match_lean_kernel: Sterbenz)
+            if (X87 && wide) {
+                const double pd = (double)p;
+                for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                    const unsigned h0 = fabs(pd - (double)c0.x) < 0.1 ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                    const unsigned h1 = fabs(pd - (double)c0.z) < 0.1 ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                    const unsigned h2 = fabs(pd - (double)c1.x) < 0.1 ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                    const unsigned h3 = fabs(pd - (double)c1.z) < 0.1 ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                    bk = min(min(bk, h0), min(h1, min(h2, h3)));
+                }
+            } else {
+                for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                    const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                    const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                    const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                    const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                    bk = min(min(bk, h0), min(h1, min(h2, h3)));
+                }
+            }
+            best[i] = (int)bk;
+        }
+        __syncthreads();                                     // every wave is done with the index: the row's XYZ goes through its LDS
+
+        // triangulation (mfreconstruct.cpp:297-326), branch-free for the 4 pixels (as mf_match_lean_kernel)
+        const size_t tk0 = trow + (inrow ? k0 : 0);
+        const f32x4 ua = *reinterpret_cast<const f32x4 *>(undL + tk0 / 2);
+        const f32x4 ub = *(reinterpret_cast<const f32x4 *>(undL + tk0 / 2) + 1);
+        float urx[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) urx[i] = undRx[trow + (inrow && best[i] >= 0 ? best[i] : 0)];
+        const float ulx[IPT] = {ua.x, ua.z, ub.x, ub.z}, uly[IPT] = {ua.y, ua.w, ub.y, ub.w};
+        float out[12];
+        unsigned hw = 0;
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+            const double w = kc.q14 * (X87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i])) + kc.q15;   // :299
+            auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
+            if constexpr (TAME) {
+                const bool fin = __builtin_isfinite(ulx[i]) && __builtin_isfinite(uly[i]);
+                if (!(expo(w) - (1023u - 200u) < 400u && fin) && best[i] >= 0) bad |= 1u << i;
+            } else {
+                const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
+                const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+                if (!(emin >= 1023u - 200u && emax < 1023u + 200u) && best[i] >= 0) bad |= 1u << i;
+            }
+            double y = __builtin_amdgcn_rcp(w);
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            const double r[3] = {r0, r1, r2};
+            float X[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double qq = r[c] * y;
+                const double e = __builtin_fma(-w, qq, r[c]);
+                X[c] = (float)__builtin_fma(e, y, qq);
+            }
+            out[3 * i] = X[0]; out[3 * i + 1] = X[1]; out[3 * i + 2] = X[2];
+        }
+        if (__builtin_expect(bad != 0, 0)) {                 // exact zeros, w == 0, NaN, extreme exponents: the three real divisions
+#pragma unroll 1
+            for (int i = 0; i < IPT; i++) {
+                if (!((bad >> i) & 1u)) continue;
+                const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+                const double w = kc.q14 * (X87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i])) + kc.q15;
+                const float X0 = (float)(r0 / w), X1 = (float)(r1 / w), X2 = (float)(r2 / w);
+#pragma unroll
+                for (int j = 0; j < IPT; j++)
+                    if (j == i) { out[3 * j] = X0; out[3 * j + 1] = X1; out[3 * j + 2] = X2; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            if constexpr (HAS_T) {                           // matCoordTrans(3x4 f32) * [X;1]: f64 accumulate, narrow once
+                const double X0 = (double)out[3 * i], X1 = (double)out[3 * i + 1], X2 = (double)out[3 * i + 2];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    double s_ = __builtin_fma(kc.T[c * 4], X0, 0.0);
+                    s_ = __builtin_fma(kc.T[c * 4 + 1], X1, s_);
+                    s_ = __builtin_fma(kc.T[c * 4 + 2], X2, s_);
+                    out[3 * i + c] = (float)(s_ + kc.T[c * 4 + 3]);
+                }
+            }
+            const bool m = best[i] >= 0;
+            out[3 * i] = m ? out[3 * i] : 0.0f; out[3 * i + 1] = m ? out[3 * i + 1] : 0.0f; out[3 * i + 2] = m ? out[3 * i + 2] : 0.0f;
+            hw |= (m ? 1u : 0u) << (8 * i);
+        }
+        const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+        {
+            f32x4 *const x4 = reinterpret_cast<f32x4 *>(&sh);
+            x4[3 * tid] = v0; x4[3 * tid + 1] = v1; x4[3 * tid + 2] = v2;
+            if (more) load_f32_blocked<IPT>(phaseL0 + nbase, k0, k0 + IPT, true, pl);     // ... and its left phases (behind the f64 work: registers)
+            __syncthreads();
+            f32x4 *const r4 = reinterpret_cast<f32x4 *>(xyz + 3 * base);
+            const int n4 = 3 * W / 4;                        // 16-byte words of the row
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (tid + j * BLOCK < n4) __builtin_nontemporal_store(x4[tid + j * BLOCK], r4 + tid + j * BLOCK);
+        }
+        if (inrow) __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + base + k0));
+        __syncthreads();                                     // the exchange space is read: the next row clears the table
+    }
+}
+
 #ifdef SLR_ALL_FORMS   // (measured, not faster than the 1024 x 4 form: SLR_OPT_MF_MATCH_ALGO 5 / 6 exist in `make FORMS=all` builds only)
 // ------------------------------------------------------------------------------------------------------
 // K4 (exact indexed form, lean, round 4): the same index as mf_match_lean_kernel -- hash dedup, representatives counting-sorted
@@ -1247,6 +1509,215 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K4 for aligned rows of 4097 .. 8192 pixels (round 5; BASELINE config 5's 8192-pixel rows).  The chunked kernel above builds
+// the hash + bin index twice and queries it four times per 8192-pixel row, with the general kernel's code: 0.85 ms per
+// 8192 x 6000 frame.  This one keeps the WHOLE right row in one index that fits half a CU's LDS:
+//   * no hash: config 5's phases come from atan2 of a DFT bin -- continuous values, practically all distinct -- so "one
+//     representative per distinct value" buys nothing there; every valid right pixel (minus a pixel whose left neighbour has the
+//     same bits) goes into the counting sort by 0.25-wide bin.  Duplicates are merely more pairs in a window: the query takes
+//     the smallest column over everything that satisfies the reference's predicate, exactly as before;
+//   * the (phase, column) pairs of 8192 pixels are 64 KB, the bin index is 16-bit (offsets <= 8192): 72 KB, two 1024-thread
+//     workgroups per CU; the 32-bit bin counters of the build live in the pairs' space (dead before the scatter);
+//   * a thread owns two runs of 4 pixels, columns 4t.. and 4096 + 4t.., so that every global access keeps the 1024 x 4 form's
+//     shape (16 bytes per lane at a 16- or 48-byte stride: see the store-stride note at mf_match_lean_kernel);
+//   * window query, NaN sentinels, K4Lean constants and the shared-reciprocal quotients as in mf_match_lean_kernel.
+// mfreconstruct.cpp:272-334.  Bit-equal to the sweep, the chunked kernel and the oracle (tests/test_gpu_parity.py, W = 5000 / 8192).
+// ------------------------------------------------------------------------------------------------------
+template <bool HAS_T, bool X87>
+__device__ __forceinline__ void k4_lean_tri4(const int best[4], bool inrun, size_t trow, int k0, const K4Lean &kc,
+                                             const float4 *__restrict__ undL, const float *__restrict__ undRx, float out[12], unsigned &hw)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const size_t tk0 = trow + (inrun ? k0 : 0);
+    const f32x4 ua = *reinterpret_cast<const f32x4 *>(undL + tk0 / 2);
+    const f32x4 ub = *(reinterpret_cast<const f32x4 *>(undL + tk0 / 2) + 1);
+    float urx[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) urx[i] = undRx[trow + (inrun && best[i] >= 0 ? best[i] : 0)];
+    const float ulx[4] = {ua.x, ua.z, ub.x, ub.z}, uly[4] = {ua.y, ua.w, ub.y, ub.w};
+    hw = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double r0 = (double)ulx[i] + kc.q3, r1 = (double)uly[i] + kc.q7, r2 = kc.q11;
+        const double w = kc.q14 * (X87 ? (double)ulx[i] - (double)urx[i] : (double)(float)(ulx[i] - urx[i])) + kc.q15;   // :299
+        auto expo = [](double x) -> unsigned { return ((unsigned)__double2hiint(x) >> 20) & 0x7FFu; };
+        const unsigned e0 = expo(r0), e1 = expo(r1), e2 = expo(r2), e3 = expo(w);
+        const unsigned emin = min(min(e0, e1), min(e2, e3)), emax = max(max(e0, e1), max(e2, e3));
+        float X[3];
+        if (emin >= 1023u - 200u && emax < 1023u + 200u) {   // (see mf_match_lean_kernel: the compiler's own division sequence, y shared)
+            double y = __builtin_amdgcn_rcp(w);
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            y = __builtin_fma(y, __builtin_fma(-w, y, 1.0), y);
+            const double r[3] = {r0, r1, r2};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double q = r[c] * y;
+                const double e = __builtin_fma(-w, q, r[c]);
+                X[c] = (float)__builtin_fma(e, y, q);
+            }
+        } else {
+            X[0] = (float)(r0 / w); X[1] = (float)(r1 / w); X[2] = (float)(r2 / w);
+        }
+        if constexpr (HAS_T) {                           // matCoordTrans(3x4 f32) * [X;1]: f64 accumulate, narrow once
+            const double X0 = (double)X[0], X1 = (double)X[1], X2 = (double)X[2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                double s = __builtin_fma(kc.T[c * 4], X0, 0.0);
+                s = __builtin_fma(kc.T[c * 4 + 1], X1, s);
+                s = __builtin_fma(kc.T[c * 4 + 2], X2, s);
+                X[c] = (float)(s + kc.T[c * 4 + 3]);
+            }
+        }
+        const bool m = best[i] >= 0;
+        out[3 * i] = m ? X[0] : 0.0f; out[3 * i + 1] = m ? X[1] : 0.0f; out[3 * i + 2] = m ? X[2] : 0.0f;
+        hw |= (m ? 1u : 0u) << (8 * i);
+    }
+}
+
+template <bool HAS_T, bool X87>
+__global__ __launch_bounds__(1024, 8) void mf_match_wide_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
+                                                                const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
+                                                                int W, int H, int row0, K4Lean kc,
+                                                                const float4 *__restrict__ undL, const float *__restrict__ undRx,
+                                                                float *__restrict__ xyz, uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+{
+    constexpr int BLOCK = 1024, HALF = 4096, N = 2 * HALF;
+    constexpr int kPer = kBins / BLOCK;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __shared__ union {
+        f32x4 pk2[N / 2 + 4];                            // pairs of (phi, column as bits) grouped by bin, + 4 sentinels, + a sink for non-candidates
+        unsigned cnt[kBins + BLOCK];                     // the build's bin counters (+ one sink per thread): dead before the scatter
+    } sh;
+    __shared__ unsigned short bs[kBins + 4];             // bs[0] = 0, bs[1 + b] = first pair of bin b, two copies of the total behind the last bin
+    __shared__ unsigned scan_tmp[BLOCK / 64];
+    static_assert(sizeof(sh) + sizeof(bs) + sizeof(scan_tmp) <= 80 * 1024, "two workgroups per CU");
+
+    const int row = (int)blockIdx.x + row0, tid = (int)threadIdx.x;   // absolute image row (row0: first row of a band)
+    const size_t base = (size_t)blockIdx.x * W, trow = (size_t)row * W;
+    const int k0[2] = {4 * tid, HALF + 4 * tid};
+    const bool in[2] = {k0[0] < W, k0[1] < W};           // W % 4 == 0: a run is whole inside or outside the row
+
+    // the right row
+    float pr[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    unsigned vr[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+        if (in[r]) {
+            load_f32_blocked<4>(phaseR + base, k0[r], k0[r] + 4, true, pr[r]);
+            load_valid_blocked<4>(validR, base, k0[r], k0[r] + 4, true, vr[r]);
+        }
+#pragma unroll
+    for (int q = 0; q < (kBins + BLOCK) / BLOCK; q++) sh.cnt[tid + q * BLOCK] = 0u;
+    __syncthreads();
+    unsigned bin[2][4], rank[2][4];
+    unsigned cmask = 0;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ok = in[r] && vr[r][i] && (pr[r][i] == pr[r][i]);            // NaN can never satisfy the predicate
+            // the same value one column to the left: that pixel has the smaller column and the same predicate outcome
+            const bool dup = i > 0 && ok && vr[r][i - 1] && __float_as_uint(pr[r][i]) == __float_as_uint(pr[r][i - 1]);
+            const bool cand = ok && !dup;
+            cmask |= (cand ? 1u : 0u) << (4 * r + i);
+            bin[r][i] = cand ? (unsigned)phase_bin(pr[r][i]) : (unsigned)(kBins + tid);
+        }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) rank[r][i] = atomicAdd(&sh.cnt[bin[r][i]], 1u);
+    __syncthreads();
+    {
+        unsigned c[kPer], sum = 0;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { c[q] = sh.cnt[tid * kPer + q]; sum += c[q]; }
+        unsigned total;
+        unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);   // (its barrier: every counter has been read)
+#pragma unroll
+        for (int q = 0; q < kPer; q++) { bs[1 + tid * kPer + q] = (unsigned short)excl; excl += c[q]; }
+        if (tid == 0) { bs[0] = 0; bs[kBins + 1] = (unsigned short)total; bs[kBins + 2] = (unsigned short)total; }
+    }
+    __syncthreads();                                     // the counters are dead: their space becomes the pairs
+    float2 *const pk = reinterpret_cast<float2 *>(sh.pk2);
+    {
+        const unsigned total = bs[kBins + 1];
+        if (tid < 4) pk[total + tid] = make_float2(__builtin_nanf(""), __uint_as_float(0xFFFFFFFFu));   // sentinels
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool cand = ((cmask >> (4 * r + i)) & 1u) != 0;
+                const unsigned at = cand ? (unsigned)bs[1 + bin[r][i]] + rank[r][i] : (unsigned)N + 4u + (unsigned)(tid & 3);
+                pk[at] = make_float2(pr[r][i], __uint_as_float((unsigned)(k0[r] + i)));
+            }
+    }
+    __syncthreads();
+
+    // queries + triangulation, one run of 4 left pixels after the other
+    const char *const pkb = reinterpret_cast<const char *>(sh.pk2);
+#pragma unroll 1
+    for (int r = 0; r < 2; r++) {
+        const int kr = r * HALF + 4 * tid;               // (not k0[r]: a run-time index would put the array into scratch)
+        if (kr >= W) continue;                           // (no barrier behind this point)
+        float pl[4];
+        unsigned vl[4];
+        load_f32_blocked<4>(phaseL + base, kr, kr + 4, true, pl);
+        load_valid_blocked<4>(validL, base, kr, kr + 4, true, vl);
+        int best[4];
+        unsigned qa[4], qe[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool act = vl[i] && pl[i] == pl[i];
+            const int b = phase_bin(pl[i]);              // (a NaN lands in bin 0; its window is emptied below)
+            const unsigned i0 = bs[b], i1 = bs[b + 3];
+            qa[i] = (i0 & ~1u) * 8u;
+            qe[i] = act ? i1 * 8u : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            unsigned bk = 0xFFFFFFFFu;
+            const float p = pl[i];
+            bool wide = false;
+            if constexpr (X87) wide = __ballot(qa[i] < qe[i] && !(fabsf(p) >= 0.25f)) != 0ull;      // (see mf_match_lean_kernel: Sterbenz)
+            if (X87 && wide) {
+                const double pd = (double)p;
+                for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                    const unsigned h0 = fabs(pd - (double)c0.x) < 0.1 ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                    const unsigned h1 = fabs(pd - (double)c0.z) < 0.1 ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                    const unsigned h2 = fabs(pd - (double)c1.x) < 0.1 ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                    const unsigned h3 = fabs(pd - (double)c1.z) < 0.1 ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                    bk = min(min(bk, h0), min(h1, min(h2, h3)));
+                }
+            } else {
+                for (unsigned a = qa[i]; a < qe[i]; a += 32u) {
+                    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(pkb + a);
+                    const f32x4 c1 = *reinterpret_cast<const f32x4 *>(pkb + a + 16);
+                    const unsigned h0 = fabsf(p - c0.x) < 0.1f ? __float_as_uint(c0.y) : 0xFFFFFFFFu;
+                    const unsigned h1 = fabsf(p - c0.z) < 0.1f ? __float_as_uint(c0.w) : 0xFFFFFFFFu;
+                    const unsigned h2 = fabsf(p - c1.x) < 0.1f ? __float_as_uint(c1.y) : 0xFFFFFFFFu;
+                    const unsigned h3 = fabsf(p - c1.z) < 0.1f ? __float_as_uint(c1.w) : 0xFFFFFFFFu;
+                    bk = min(min(bk, h0), min(h1, min(h2, h3)));
+                }
+            }
+            best[i] = (int)bk;                           // 0xFFFFFFFF == -1: no match
+        }
+        float out[12];
+        unsigned hw;
+        k4_lean_tri4<HAS_T, X87>(best, true, trow, kr, kc, undL, undRx, out, hw);
+        const size_t o = base + kr;
+        f32x4 *d4 = reinterpret_cast<f32x4 *>(xyz + 3 * o);  // streaming output: non-temporal stores
+        const f32x4 v0 = {out[0], out[1], out[2], out[3]}, v1 = {out[4], out[5], out[6], out[7]}, v2 = {out[8], out[9], out[10], out[11]};
+        __builtin_nontemporal_store(v0, d4);
+        __builtin_nontemporal_store(v1, d4 + 1);
+        __builtin_nontemporal_store(v2, d4 + 2);
+        __builtin_nontemporal_store(hw, reinterpret_cast<unsigned *>(has + o));
+        if (match_k) *reinterpret_cast<int4 *>(match_k + o) = make_int4(best[0], best[1], best[2], best[3]);
+    }
+}
+
 template <int BLOCK, int IPT>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_sorted_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
@@ -1498,6 +1969,29 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return hipGetLastError();
             }
 #endif
+            if (W > 2048 && algo == 0 && nframes > 1 && !validL && !validR && !match_k && k4_stop == 0 && !tl_debug.no_ge_lean) {
+                // round 5: the grouped launch as a PERSISTENT kernel (two resident workgroups per CU walk the rows, the next row's
+                // phases prefetched); SLR_OPT_MF_MATCH_ALGO = 4, or SLR_OPT_DEBUG_FLAGS bit 2, keep the per-row launch for A/B runs
+                static DevSlots cus_of;
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                int cus = cus_of.get(dev);
+                if (!cus) {
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+                    cus_of.put(dev, cus);
+                }
+                const long long items = (long long)((H + 7) / 8) * 8 * nframes;
+                unsigned pg = (unsigned)(2 * cus) & ~7u;          // two 1024-thread workgroups per CU, whole groups of 8 (XCDs)
+                if ((long long)pg > items) pg = (unsigned)((items + 7) / 8 * 8);
+#define SLR_LEANP(T_, TAME_, X_) SLR_LAUNCH((mf_match_lean_persist_kernel<T_, TAME_, X_>), dim3(pg), dim3(1024), 0, s, phaseL, phaseR, W, H, row0, kc, \
+                                            undL4, undRx, xyz, has, nframes, frame_px)
+#define SLR_LEANP2(T_, TAME_) do { if (x87) SLR_LEANP(T_, TAME_, true); else SLR_LEANP(T_, TAME_, false); } while (0)
+                if (cal.has_T) { if (q_tame) SLR_LEANP2(true, true); else SLR_LEANP2(true, false); }
+                else { if (q_tame) SLR_LEANP2(false, true); else SLR_LEANP2(false, false); }
+#undef SLR_LEANP2
+#undef SLR_LEANP
+                return hipGetLastError();
+            }
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
 #define SLR_LEANX2(T_, TAME_, X_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_, X_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
                                       W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)
@@ -1523,6 +2017,18 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 #ifdef SLR_ALL_FORMS
         else if (algo == 2) SLR_SORTED(1024, 8);
 #endif
+        else if ((algo == 0) && (vec_ok & 1) && undL && undRx && cal.q_simple && W <= 8192 && (uintptr_t)undL % 16 == 0 &&
+                 ((size_t)W * sizeof(float2)) % 16 == 0) {   // rows of 4097 .. 8192 pixels (config 5): the whole right row in one index (round 5)
+            K4Lean kc;
+            kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
+            for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
+            const float4 *undL4 = (const float4 *)undL_xy;
+#define SLR_WIDE(T_, X_) SLR_LAUNCH((mf_match_wide_kernel<T_, X_>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0, kc, undL4, undRx, \
+                                    xyz, has, match_k)
+            if (cal.has_T) { if (cal.eval_x87) SLR_WIDE(true, true); else SLR_WIDE(true, false); }
+            else { if (cal.eval_x87) SLR_WIDE(false, true); else SLR_WIDE(false, false); }
+#undef SLR_WIDE
+        }
         else                                                 // wider rows: the right row in chunks of 4096 columns
             SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
                                cal, vec_ok, undL, undRx, xyz, has, match_k);

@@ -165,3 +165,78 @@ def test_hybrid_batch_grouped_on_the_verged_rig(slr, synth, oracle, rig, x87):
             assert torch.equal(h1[0], has[g]) and torch.equal(x1[0].view(torch.int32), xyz[g].view(torch.int32)), g
     finally:
         c.close()
+
+
+def test_config5_rectified_at_size_on_the_verged_rig(slr, synth, oracle):
+    """BASELINE config 5 as bench.py --mode mfn runs it, at its stated size: 8192x6000, 4 frequencies x 8 steps of fp16 planes,
+    a stereo head verged by 0.2 rad.  The shipped LDS-DMA rectified decode (mfn_rect_dma_kernel) of both cameras against the
+    per-pixel gather form on the WHOLE frame (bit for bit), against the fp64 remap + decode model on sampled rows (1e-4 relative
+    + the f32 floor, wrap flips counted), and the 8-GPU split: 8 rectified row bands, each decoded from a COPY of only the
+    source rows slr_rectify_source_rows names and matched with absolute rows (rows wider than 4096: the round-5 wide K4),
+    concatenated == the whole frame, decode and XYZ; the wide K4 against the oracle's literal search on sampled rows."""
+    W5, H5, F, N = 8192, 6000, 4, 8
+    np_ = 2 + F * N
+    dev = torch.device("cuda", 0)
+    rig5 = synth.make_verged_rig(W5, H5, 0.2, -0.15)
+    c = slr.Context(0)
+    try:
+        c.set_calibration(rig5["calib"])
+        synth.install_verged_maps(c, rig5, W5, H5)
+        st = synth.render_mfn_stack(W5, H5, F, N, noise=0.25, seed=5, device=dev)
+        torch.cuda.synchronize()
+        full = [c.mfn_rectify_decode(cam, st[cam], F, N, 40.0) for cam in range(2)]           # the shipped form
+        c.synchronize()
+        c.set_option(slr.capi.OPT_DEBUG_FLAGS, 1)                                             # the per-pixel gather form
+        for cam in range(2):
+            g = c.mfn_rectify_decode(cam, st[cam], F, N, 40.0)
+            c.synchronize()
+            assert torch.equal(g[1], full[cam][1]) and torch.equal(g[0].view(torch.int32), full[cam][0].view(torch.int32)), cam
+            del g
+        c.set_option(slr.capi.OPT_DEBUG_FLAGS, 0)
+        assert full[0][1].float().mean().item() > 0.3
+        # fp64 model, camera 0, sampled row ranges (top / band edges / middle / bottom: the keystone is strongest at the ends)
+        mx, mf = c.get_rectify_maps(0, W5, H5)
+        host = st[0].cpu().numpy()
+        for r0 in (0, 749, 2999, 5998):
+            exp, ev = oracle.mfn_rect_decode_f64(host, F, N, 40.0, mx, mf, rows=(r0, r0 + 2))
+            ph, v = np_of(full[0][0][r0:r0 + 2]), np_of(full[0][1][r0:r0 + 2])
+            exp, ev = exp[r0:r0 + 2], ev[r0:r0 + 2]
+            d = np.abs(ph.astype(np.float64) - exp)
+            tol = 2e-3 + 1e-4 * np.abs(exp)                                  # north_star: 1e-4 relative (+ f32 floor)
+            per = np.abs(d - 255.0 * np.round(d / 255.0))                    # wrap flips at an a > b decided in f32 vs f64
+            vd = v != ev
+            assert ((d > tol) & (per > tol) & ~vd).sum() == 0, r0
+            assert (d > tol).sum() <= 2e-3 * ph.size and vd.sum() <= 1e-4 * ph.size + 1, (r0, int((d > tol).sum()), int(vd.sum()))
+        del host, mx, mf
+        # the whole frame's match (wide K4) and sampled rows against the oracle's literal search
+        fx, fh, fk = c.mf_triangulate(full[0][0], full[0][1], full[1][0], full[1][1])
+        c.synchronize()
+        camL, camR, Q, T = calib_parts(oracle, rig5["calib"])
+        phL, vL, phR, vR = [np_of(t) for t in (full[0][0], full[0][1], full[1][0], full[1][1])]
+        for r in (0, 750, 3001, 5999):
+            exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T, rows=(r, r + 1))
+            assert bits_equal(np_of(fk[r]), emk[r]) and bits_equal(np_of(fh[r]), ehas[r]) and bits_equal(np_of(fx[r]), exyz[r]), r
+        assert fh.float().mean().item() > 0.05
+        del phL, vL, phR, vR
+        # 8 row bands from source windows
+        band = (H5 + 7) // 8
+        short = 0
+        for b in range(8):
+            r0, r1 = b * band, min(H5, (b + 1) * band)
+            dec = []
+            for cam in range(2):
+                s0, sn = c.rectify_source_rows(cam, r0, r1 - r0)
+                assert 0 <= s0 and s0 + sn <= H5 and sn >= 1
+                short += 1 if sn < H5 // 4 else 0
+                window = st[cam][:, s0:s0 + sn].clone()                      # what this GPU would hold of the frame
+                dec.append(c.mfn_rectify_decode(cam, window, F, N, 40.0, W=W5, H=H5, row0=r0, rows=r1 - r0, src_row0=s0))
+                c.synchronize()
+                del window
+                assert torch.equal(dec[cam][1], full[cam][1][r0:r1]), (b, cam)
+                assert torch.equal(dec[cam][0].view(torch.int32), full[cam][0][r0:r1].view(torch.int32)), (b, cam)
+            bx, bh, bk = c.mf_triangulate(dec[0][0], dec[0][1], dec[1][0], dec[1][1], row0=r0, image_h=H5)
+            c.synchronize()
+            assert torch.equal(bh, fh[r0:r1]) and torch.equal(bk, fk[r0:r1]) and torch.equal(bx.view(torch.int32), fx[r0:r1].view(torch.int32)), b
+        assert short == 16                                       # every band's window is a small part of the frame
+    finally:
+        c.close()
