@@ -92,7 +92,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * aligned, 513..1024 or 2049..4096 pixels wide and Q has cv::stereoRectify's pattern.  4 / 5 / 6 pin the lean variant's
  * shapes for rows of 2049..4096 pixels (0 picks 1024 threads x 4 pixels with the row's XYZ stored through LDS; 4 = the same
  * with per-thread stores, round 2; 5 / 6 = 512 threads x 8 pixels with two / three rows per CU: measured, not faster, `make FORMS=all` builds only)
- * and behave as 0 where the lean variant does not apply.  All give
+ * and behave as 0 where the lean variant does not apply; 7 = the grouped launches of slr_reconstruct_mf_batch as a persistent kernel
+ * with the next row's phases prefetched (round 5: measured slower, 105 against 77 us per frame; never picked by auto).  All give
  * identical results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */

@@ -541,9 +541,15 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
     float pr[IPT] = {0, 0, 0, 0}, pl[IPT] = {0, 0, 0, 0};
     unsigned vr[IPT] = {0, 0, 0, 0}, vl[IPT] = {0, 0, 0, 0};
     if (inrow) {
-        load_f32_blocked<IPT>(phaseR + base, k0, k0 + IPT, true, pr);
+#if defined(SLR_K4_ABL) && (SLR_K4_ABL & 8)
+        // ablation (round 5): the phases of 64 rows only, hot in L2 -- the match side of a fused decode -> match launch at best
+        const size_t lbase = (size_t)((brow & 63) + (H > 128 ? H / 2 - 32 : 0)) * W;   // (rows from the middle of the frame: the top rows of a verged rig are half empty)
+#else
+        const size_t lbase = base;
+#endif
+        load_f32_blocked<IPT>(phaseR + lbase, k0, k0 + IPT, true, pr);
         load_valid_blocked<IPT>(validR, base, k0, k0 + IPT, true, vr);
-        load_f32_blocked<IPT>(phaseL + base, k0, k0 + IPT, true, pl);
+        load_f32_blocked<IPT>(phaseL + lbase, k0, k0 + IPT, true, pl);
         load_valid_blocked<IPT>(validL, base, k0, k0 + IPT, true, vl);
     }
     const size_t trow = (size_t)row * W;
@@ -1895,7 +1901,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const float *xyz, const uint8_t *has, int W, const DevCalib &cal,
                              int algo, const float *undL_xy, const float *undRx, size_t frame_px)
 {
-    return (algo == 0 || algo == 4) && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
+    return (algo == 0 || algo == 4 || algo == 7) && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
            (uintptr_t)undL_xy % 16 == 0 && (uintptr_t)phaseL % 16 == 0 && (uintptr_t)phaseR % 16 == 0 && (uintptr_t)xyz % 16 == 0 &&
            (uintptr_t)has % 4 == 0 && frame_px % 4 == 0;
 }
@@ -1933,7 +1939,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                vec_ok, undL, undRx, xyz, has, match_k)
 #endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
-        if ((algo == 0 || (algo >= 4 && algo <= 6)) && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+        if ((algo == 0 || (algo >= 4 && algo <= 7)) && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
             K4Lean kc;
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
@@ -1969,9 +1975,10 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return hipGetLastError();
             }
 #endif
-            if (W > 2048 && algo == 0 && nframes > 1 && !validL && !validR && !match_k && k4_stop == 0 && !tl_debug.no_ge_lean) {
+            if (W > 2048 && algo == 7 && nframes > 1 && !validL && !validR && !match_k && k4_stop == 0) {
                 // round 5: the grouped launch as a PERSISTENT kernel (two resident workgroups per CU walk the rows, the next row's
-                // phases prefetched); SLR_OPT_MF_MATCH_ALGO = 4, or SLR_OPT_DEBUG_FLAGS bit 2, keep the per-row launch for A/B runs
+                // phases prefetched).  Measured (profiles/exp/r05/k4_persist_ab.txt): 105 us per frame against 77 for the per-row
+                // launch -- SLR_OPT_MF_MATCH_ALGO = 7 only, never picked by auto
                 static DevSlots cus_of;
                 int dev = 0;
                 (void)hipGetDevice(&dev);

@@ -24,7 +24,8 @@
 #include <stdlib.h>
 
 // Experiment switches.  The ablations and probes the measurements of DESIGN.md / LABNOTES.md were taken with -- SLR_DMA_ABL (1 no
-// source traffic, 2 no LDS tap reads, 3 no barriers, 4 neither reads nor blend, 5 reads without blend, 6 = 1 + 2), SLR_DMA_FORCE_MODE
+// source traffic, 2 no LDS tap reads, 3 no barriers, 4 neither reads nor blend, 5 reads without blend, 6 = 1 + 2,
+// 7 phases stored to an L2-resident window, 8 digests from an L2-resident set of tiles, 9 = 7 + 8), SLR_DMA_FORCE_MODE
 // (one read mode for every wave: wrong results, timing only) and SLR_DMA_CLOCKPROBE (per-workgroup timeline) -- compile only with
 // -DSLR_EXPERIMENTS (profiles/exp/ab/var_build.sh passes it); a production build that names one of them is an error, and every
 // other former switch (static priorities, computed weights, flush-now / safe Gray forms, the tunable pair counts) is gone: the
@@ -874,7 +875,13 @@ struct DmaDecode {
         for (int p = 0; p < PX / 4; p++) {
             const int row = out_ty * TH + (int)(oslot[p] >> 6), col = out_tx * TW + (int)(oslot[p] & 63u) * 4;
             const bool inb = row < H && col < W;                     // W % 16 == 0: a quad is whole inside or outside
+#if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 7 || SLR_DMA_ABL == 9)
+            // ablation (round 5): the phases go to a 1 MB window that stays in the XCD's L2 -- what a fused decode -> match launch
+            // with a per-XCD phase ring could save on the decode side at best (wrong results, timing only)
+            const unsigned m = ((unsigned)row * (unsigned)W + (unsigned)col) & 0x3FFFFu;
+#else
             const unsigned m = (unsigned)row * (unsigned)W + (unsigned)col;
+#endif
             if constexpr (HASVALID) {
                 const unsigned ok4 = (out_ok >> (4 * p)) & 0xFu;
                 __builtin_amdgcn_raw_buffer_store_b32(__umul24(ok4, 0x204081u) & 0x01010101u, rs_valid, inb ? m : kDmaInvalid, 0, 0);
@@ -904,6 +911,9 @@ struct DmaDecode {
     }
     __device__ __forceinline__ void issue_digest(unsigned tile, bool live) const
     {
+#if defined(SLR_DMA_ABL) && (SLR_DMA_ABL == 8 || SLR_DMA_ABL == 9)
+        tile = (tile & 63u) * 94u;       // ablation (round 5): 64 tiles' digests, hot in L2 = a map stream of zero bytes (timing only)
+#endif
 #pragma unroll
         for (int r = 0; r < PX / 4; r++) {
             const unsigned voff = live ? tile * (unsigned)DIG_BYTES + (threadIdx.x + (unsigned)(NT * r)) * 16u : kDmaInvalid;
