@@ -408,6 +408,46 @@ def test_mf_match_sweep_and_indexed_forms_agree(ctx, oracle, synth, slr, W):
     assert ehas[1].sum() > 0 and ehas[6].sum() > 0 and ehas[10].sum() == 0 and ehas[11].sum() == 0
 
 
+@pytest.mark.parametrize("W", [1024, 4096])
+def test_mf_match_fine_bin_edges(ctx, oracle, synth, slr, W):
+    """round 5 (written for a K4 with 1/16-wide bins over [-32, 288), measured slower and not kept -- the rows stay): phases on a
+    1/16 grid and one float beside it, pairs exactly 0.1 / 0.125 apart across bin borders, values piled up at -32, 288 and far
+    beyond, clusters spanning many bins, 4096 copies of one value, +-inf / NaN, values around zero; against the oracle and the
+    literal sweep"""
+    rng = np.random.default_rng(7 * W)
+    H = 12
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    f32 = np.float32
+    grid = (rng.integers(-40 * 16, 300 * 16, (H, W)) / 16.0).astype(f32)
+    phL = grid.copy(); phR = (rng.integers(-40 * 16, 300 * 16, (H, W)) / 16.0).astype(f32)
+    phR[0] = np.nextafter(phL[0][::-1].copy(), f32(1e9)); phL[0] = np.nextafter(phL[0], f32(-1e9))       # one float beside the grid
+    phR[1] = phL[1] + f32(0.1); phR[1, ::2] = phL[1, ::2] - f32(0.1)                                   # the threshold, across two bins
+    phR[2] = phL[2] + f32(0.125); phR[2, ::3] = np.nextafter(phL[2, ::3] + f32(0.1), f32(-1e9))
+    phL[3] = (-32 + rng.integers(-3, 4, W) / 16.0 + rng.random(W) * 0.01).astype(f32); phR[3] = (-32 + rng.integers(-3, 4, W) / 16.0).astype(f32)
+    phL[4] = (288 + rng.integers(-3, 4, W) / 16.0 - rng.random(W) * 0.01).astype(f32); phR[4] = (288 + rng.integers(-3, 4, W) / 16.0).astype(f32)
+    phL[5] = (rng.choice([-1e6, -500.0, -33.0, 300.0, 511.9, 4e5], W) + rng.random(W) * 0.2).astype(f32)
+    phR[5] = (rng.choice([-1e6, -500.0, -33.0, 300.0, 511.9, 4e5], W) + rng.random(W) * 0.2).astype(f32)
+    phL[6] = (100 + rng.random(W) * 0.75).astype(f32); phR[6] = (100 + rng.random(W) * 0.75).astype(f32)  # a cluster over 12 fine bins
+    phL[7] = f32(17.03125); phR[7] = f32(17.03125); phR[7, : W // 2] = f32(17.2)                            # one value, thousands of copies
+    phL[8] = np.sort((rng.random(W) * 255).astype(f32)); phR[8] = np.sort((rng.random(W) * 255).astype(f32))   # the reference's range, monotone
+    phR[9] = (rng.random(W) * 255).astype(f32); phL[9] = phR[9][rng.permutation(W)] + f32(0.0999)
+    phL[10] = np.where(rng.random(W) < 0.3, np.nan, phL[10]).astype(f32); phR[10] = np.where(rng.random(W) < 0.3, np.inf, phR[10]).astype(f32)
+    phL[11] = (rng.random(W) * 0.5 - 0.25).astype(f32); phR[11] = (rng.random(W) * 0.5 - 0.25).astype(f32)     # around zero (the x87 predicate's f64 path)
+    vL = (rng.random((H, W)) < 0.95).astype(np.uint8)
+    vR = (rng.random((H, W)) < 0.95).astype(np.uint8)
+    exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
+    for algo in (0, 1):
+        ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
+        xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
+        ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
+        assert bits_equal(mk, emk), "algo %d" % algo
+        assert bits_equal(has, ehas) and bits_equal(xyz, exyz), "algo %d" % algo
+    for r in (0, 1, 2, 3, 4, 6, 7, 8, 9, 11):
+        assert ehas[r].sum() > 0, r
+
+
 # ---------------------------------------------------------------------------------------------------------
 # K5
 # ---------------------------------------------------------------------------------------------------------
