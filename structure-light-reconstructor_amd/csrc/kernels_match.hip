@@ -17,7 +17,9 @@
 #include <rocprim/block/block_radix_sort.hpp>
 
 // stage ablation of the match kernels (profiles/k4_stages.sh): "leave after stage N, outputs are not written".  Only builds with
-// -DSLR_DEBUG_HOOKS contain the exits; the production kernels carry none of them.
+// -DSLR_DEBUG_HOOKS contain the exits; the production kernels carry none of them.  SLR_K4_ABL (timing only, wrong results): bit 0 no
+// output stores, 1 no table gathers, 2 no slow-path quotients (512 x 8 shapes), 3 the phases of 64 rows from the middle of the frame,
+// hot in L2 (round 5: what a fused decode -> match launch could save on the match side -- nothing, profiles/exp/r05/fusion_bounds.txt).
 #if !defined(SLR_EXPERIMENTS) && (defined(SLR_K4_ABL) || defined(SLR_DEBUG_HOOKS))
 #error "SLR_K4_ABL / SLR_DEBUG_HOOKS are experiment switches: build with -DSLR_EXPERIMENTS"
 #endif
