@@ -18,6 +18,9 @@
 
 #pragma clang diagnostic ignored "-Wpass-failed"   // the run-time (FS = NS = 0) variant cannot fully unroll its plane loops
 
+// SLR_MFN_ABL (timing only, wrong results; LABNOTES section 10 r4-h, section 11 r5-o): 1 no source traffic, 2 no tap reads / blend, 4 no output
+// stores, 8 no group barriers, 16 no per-tile box reduction (a fixed full-size box: more traffic than the real boxes, not a bound), 32 no
+// per-pixel set-up (what a per-pixel digest could save at best: 4.5 %, profiles/exp/r05/mfn_setup_abl.txt)
 #if !defined(SLR_EXPERIMENTS) && defined(SLR_MFN_ABL)
 #error "SLR_MFN_ABL is an experiment switch: build with -DSLR_EXPERIMENTS"
 #endif
@@ -743,6 +746,9 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
     };
     // the wave's share of the staged tile's bounding box -> red[wv]
     auto reduce_staged = [&](int t) {
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 16)
+        if (t != -12345) return;                          // (ablation, round 5: no per-tile box reduction -- a precomputed box table at best)
+#endif
         const bool on = t < ntiles;
         const int ty = on ? t / tiles_x : 0, tx = on ? t - ty * tiles_x : 0, col = tx * kTileW + lane;
         int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
@@ -765,7 +771,17 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
         }
         if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
     };
+    int abl_tile = 0;
     auto box_from_red = [&]() -> Box {
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 16)
+        {   // (ablation: the tile's own rectangle plus a margin, as if read from a table: wrong results, timing only)
+            const int ty = abl_tile < ntiles ? abl_tile / tiles_x : 0, tx = abl_tile < ntiles ? abl_tile - ty * tiles_x : 0;
+            Box b;
+            b.x0 = tx * kTileW > 8 ? tx * kTileW - 8 : 0; b.y0 = ty * kTileH + row0 > 2 ? ty * kTileH + row0 - 2 : 0;
+            b.bw = kBoxW - 2; b.bh = kBoxH - 2; b.fits = true; b.dma = abl_tile < ntiles;
+            return b;
+        }
+#endif
         int mnx = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mny = 0x7FFFFFFF, mxy = -0x7FFFFFFF;
 #pragma unroll
         for (int w = 0; w < kNW; w++) {
@@ -790,6 +806,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
     __syncthreads();
     reduce_staged(t);
     __syncthreads();
+    abl_tile = t;
     Box cur = box_from_red(), nxt = cur;
     unsigned cvo[kDPG], nvo[kDPG];
     chunk_offsets(cur, cvo);
@@ -834,6 +851,15 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
         h16x2 w0[kPX], w1[kPX];
 #pragma unroll
         for (int j = 0; j < kPX; j++) {
+#if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 32)
+            // (ablation, round 5: no per-pixel set-up -- one LDS dword per pixel as a digest would be, constant weights: timing only)
+            const unsigned dg = *reinterpret_cast<const unsigned *>(smem + kOffXy + 4 * ((wv + kNW * j) * kTileW + lane));
+            sx[j] = 0; sy[j] = 0; fr[j] = 0;
+            live[j] = ty * kTileH + wv + kNW * j < rows && col < W;
+            w0[j] = h16x2{(_Float16)512.0f, (_Float16)256.0f}; w1[j] = h16x2{(_Float16)128.0f, (_Float16)128.0f};
+            const unsigned b = ((unsigned)((wv + kNW * j + 1) * kBoxRowBytes + (lane + 4) * 2) + (dg & 2u)) & 0xFFFFu;
+            ta[j] = b & ~3u; tsh[j] = (b & 2u) * 8u;
+#else
             staged_px(j, sx[j], sy[j], fr[j]);
             live[j] = ty * kTileH + wv + kNW * j < rows && col < W;
             const unsigned fx = fr[j] & 31u, fy = fr[j] >> 5;
@@ -843,6 +869,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
             const unsigned b = touch && cur.fits ? (unsigned)((sy[j] - cur.y0) * kBoxRowBytes + (sx[j] - cur.x0) * 2) : 0u;
             ta[j] = b & ~3u; tsh[j] = (b & 2u) * 8u;
             if (!touch) { w0[j] = h16x2{(_Float16)0.0f, (_Float16)0.0f}; w1[j] = w0[j]; }       // every sample 0
+#endif
         }
         float out[kPX];
         unsigned okm = 0;                                 // bit j: pixel j valid
@@ -882,7 +909,7 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
             __syncthreads();                              // (ablation 8: no group barriers -- wrong results, timing only)
 #endif
             if (g == 1) issue_map(tn);                    // (before the step's group DMAs: the counted wait stays exact)
-            if (g == 5) { nxt = box_from_red(); chunk_offsets(nxt, nvo); }
+            if (g == 5) { abl_tile = tn; nxt = box_from_red(); chunk_offsets(nxt, nvo); }
             const int gi = g + R - 1;                     // the group to issue
             int slot = s0 + gi; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0; slot -= slot >= R ? R : 0;
             if (gi < 9) issue_group(cvo, gi == 0 ? 0 : 2 + 4 * (gi - 1), gi == 0 ? 2 : 4, slot);
