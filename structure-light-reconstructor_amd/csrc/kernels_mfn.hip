@@ -771,7 +771,8 @@ __global__ __launch_bounds__(NT, (NT / 64) * (R == 3 ? 3 : 2) / 4) void mfn_rect
         }
         if (lane == 0) { red[wv][0] = mnx; red[wv][1] = mxx; red[wv][2] = mny; red[wv][3] = mxy; }
     };
-    int abl_tile = 0;
+    int abl_tile = 0;                                       // (SLR_MFN_ABL & 16 only)
+    (void)abl_tile;
     auto box_from_red = [&]() -> Box {
 #if defined(SLR_MFN_ABL) && (SLR_MFN_ABL & 16)
         {   // (ablation: the tile's own rectangle plus a margin, as if read from a table: wrong results, timing only)
