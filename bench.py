@@ -305,7 +305,7 @@ def live_traffic(args, kernel_name, fpl=1.0):
                "--dma-depth", str(args.dma_depth), "--pitch-pad", str(args.pitch_pad), "--debug-flags", str(args.debug_flags),
                "--maps", args.maps, "--frames", str(args.frames), "--eval-model", args.eval_model]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=False)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=100, check=False)   # (a pass takes 15-25 s; a stuck profiler must not cost the bench line minutes)
             got = []
             for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(path) as f:
