@@ -247,3 +247,30 @@ def test_bench_two_ranks_with_a_collective_on_this_box():
             refused = [ln for ln in text.splitlines() if "uplicate GPU" in ln or "nvalid" in ln][:2]
             continue
         pytest.fail("bench.py --gpus 2 failed over gloo: rc %d\n%s" % (r.returncode, r.stderr[-1500:]))
+
+
+def test_bench_config5_two_row_bands_with_a_collective_on_this_box():
+    """bench.py --mode mfn as the driver launches it for N = 2 (BASELINE config 5's multi-GPU leg: ONE frame split into row bands,
+    every rank holding only the source rows its band's maps point into, one all-gather of the bands), both ranks on device 0, at a
+    small size.  RCCL first; gloo only if RCCL refuses two ranks on one device.  The ranks' assembled clouds must agree."""
+    env = dict(os.environ, SLR_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for backend, port in (("nccl", "29543"), ("gloo", "29544")):
+        env["SLR_BENCH_BACKEND"] = backend
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(ROOT, "bench.py"), "--mode", "mfn", "--gpus", "2", "--steps", "2", "--warmup", "1",
+               "--frames", "1", "--width", "2048", "--height", "500"]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+        if r.returncode == 0 and lines:
+            d = json.loads(lines[-1])
+            assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong" and d["config"]["mode"] == "mfn"
+            assert d["config"]["rows_of_this_rank"] == [0, 250] and "row bands" in d["config"]["parallelism"]
+            assert d["gather_proof"] == {"frames": 1, "all_ranks_agree": True} and d["final_allgather_ms"] > 0
+            print("config 5 row-band leg ran over %s" % backend)
+            return
+        if backend == "nccl":
+            text = r.stderr + r.stdout
+            assert any(k in text for k in ("Duplicate GPU", "duplicate GPU", "ncclInvalidUsage", "invalid usage")), \
+                "RCCL failed for a reason other than two ranks on one device:\n" + text[-1500:]
+            continue
+        pytest.fail("bench.py --mode mfn --gpus 2 failed over gloo: rc %d\n%s" % (r.returncode, r.stderr[-1500:]))
