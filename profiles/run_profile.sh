@@ -15,8 +15,9 @@ export TMPDIR=/tmp SLR_WHAT=$WHAT
 REPO=$PWD
 cd /tmp
 
-# 1. kernel trace + stats of the bench command itself (the numbers bench.py's roofline must agree with)
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-baseline 0 --host-io 0 --traffic off --map-sweep 0 \
+# 1. kernel trace + stats of the bench command itself (the numbers bench.py's roofline must agree with; --self-check 0: the self check and
+#    the first-call probe launch the same kernels one frame at a time, which would be averaged into the 8-frame launches' mean)
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/bench" -o bench -- python "$REPO/bench.py" --steps 10 --warmup 2 --cpu-baseline 0 --host-io 0 --traffic off --map-sweep 0 --self-check 0 \
     > "$OUT/bench_stdout.log" 2>&1
 cp "$OUT"/bench/*kernel_stats.csv "$SUM/${TAG}_bench_kernel_stats.csv" 2>/dev/null
 grep '^{"metric"' "$OUT/bench_stdout.log" | tail -1 > "$SUM/${TAG}_bench_line.json"
