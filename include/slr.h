@@ -93,7 +93,7 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * shapes for rows of 2049..4096 pixels (0 picks 1024 threads x 4 pixels with the row's XYZ stored through LDS; 4 = the same
  * with per-thread stores, round 2; 5 / 6 = 512 threads x 8 pixels with two / three rows per CU: measured, not faster, `make FORMS=all` builds only)
  * and behave as 0 where the lean variant does not apply; 7 = the grouped launches of slr_reconstruct_mf_batch as a persistent kernel
- * with the next row's phases prefetched (round 5: measured slower, 105 against 77 us per frame; never picked by auto).  All give
+ * with the next row's phases prefetched (round 5: measured slower, 105 against 77 us per frame; `make FORMS=all` builds only).  All give
  * identical results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
@@ -128,7 +128,7 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * 3 = 128x16 / 512 (default), 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
  * the decode, 1 (double buffer) or 2 (triple buffer, the default). */
-/* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2, 5, 6
+/* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2, 5, 6, 7
  * -- are compiled into the library with `make FORMS=all` only; a default build answers SLR_ERR_UNSUPPORTED to these values. */
 #define SLR_OPT_RECT_DMA_SHAPE 6
 #define SLR_OPT_RECT_DMA_DEPTH 7

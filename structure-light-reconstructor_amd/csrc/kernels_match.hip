@@ -812,6 +812,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
 // Workgroup w runs on XCD w % 8 and takes the items q = w / 8, w / 8 + G / 8, ... of that XCD: item q = (row (q / nframes) * 8 + xcd,
 // frame q % nframes) -- a row of all frames on the same XCD, close in time, as in the per-row form.
 // ------------------------------------------------------------------------------------------------------
+#ifdef SLR_ALL_FORMS   // (measured: 105 against 76 us per frame; SLR_OPT_MF_MATCH_ALGO 7 exists in `make FORMS=all` builds only)
 template <bool HAS_T, bool TAME, bool X87>
 __global__ __launch_bounds__(1024, 8) void mf_match_lean_persist_kernel(const float *__restrict__ phaseL0, const float *__restrict__ phaseR0,
                                                                         int W, int H, int row0, K4Lean kc,
@@ -1064,6 +1065,8 @@ __global__ __launch_bounds__(1024, 8) void mf_match_lean_persist_kernel(const fl
 }
 
 #ifdef SLR_ALL_FORMS   // (measured, not faster than the 1024 x 4 form: SLR_OPT_MF_MATCH_ALGO 5 / 6 exist in `make FORMS=all` builds only)
+#endif  // SLR_ALL_FORMS
+
 // ------------------------------------------------------------------------------------------------------
 // K4 (exact indexed form, lean, round 4): the same index as mf_match_lean_kernel -- hash dedup, representatives counting-sorted
 // into 0.25-wide bins, exact predicate on the window's pairs -- cut for instruction-level instead of wave-level parallelism:
@@ -1977,6 +1980,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                 return hipGetLastError();
             }
 #endif
+#ifdef SLR_ALL_FORMS
             if (W > 2048 && algo == 7 && nframes > 1 && !validL && !validR && !match_k && k4_stop == 0) {
                 // round 5: the grouped launch as a PERSISTENT kernel (two resident workgroups per CU walk the rows, the next row's
                 // phases prefetched).  Measured (profiles/exp/r05/k4_persist_ab.txt): 105 us per frame against 77 for the per-row
@@ -2001,6 +2005,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 #undef SLR_LEANP
                 return hipGetLastError();
             }
+#endif
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
 #define SLR_LEANX2(T_, TAME_, X_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_, X_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
                                       W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)

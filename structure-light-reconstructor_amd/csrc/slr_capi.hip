@@ -1903,6 +1903,7 @@ int slr_set_option(slr_ctx *c, int option, int value)
 #ifndef SLR_ALL_FORMS
             if (value == 2) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 2 (sorted form) is compiled with -DSLR_ALL_FORMS only");
             if (value == 5 || value == 6) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 5 / 6 (512 x 8 shapes) are compiled with -DSLR_ALL_FORMS only");
+            if (value == 7) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 7 (persistent grouped K4) is compiled with -DSLR_ALL_FORMS only");
 #endif
             c->opt_mf_match_algo = value;
             return SLR_OK;
