@@ -110,6 +110,11 @@ def parse_args():
                     help="N>1: RCCL all-gather of the point cloud: once per job right after the timed steps, timed separately "
                          "(after, default), once per job inside the timed region (final), "
                          "after every step (overlapped with the next step's compute), or never")
+    ap.add_argument("--impl", choices=["ranks", "one-process"], default="ranks",
+                    help="N > 1: ranks = one process per GPU, torch.distributed over RCCL (this script spawns its own ranks under "
+                         "torch.distributed.run when it is started bare); one-process = N contexts on N devices driven by ONE host "
+                         "thread through the C ABI's multi-GPU entries (slr_reconstruct_mf_multi + slr_allgather_clouds / "
+                         "slr_reconstruct_mf_allgather_ex: direct one-hop peer copies over the xGMI mesh) -- what a Qt/C++ host calls")
     ap.add_argument("--profile", type=int, default=1, help="bracket kernels with HIP events (roofline)")
     ap.add_argument("--profile-stride", type=int, default=4,
                     help="bracket every n-th launch of a kernel inside the timed region (two event records per launch cost ~2.5 %% "
@@ -406,6 +411,235 @@ def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
     return out
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher: run N ranks of this script under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1 at a free port) and pass their output and exit status through.  On a box with fewer than N GPUs the
+    ranks are refused unless SLR_BENCH_ONE_DEVICE=1 (all ranks on device 0: a dry run of the N > 1 code path)."""
+    import socket
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus and not os.environ.get("SLR_BENCH_ONE_DEVICE"):
+        raise SystemExit("bench.py --gpus %d: this box has %d GPU(s) (SLR_BENCH_ONE_DEVICE=1 puts every rank on device 0: a dry run)" %
+                         (args.gpus, have))
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    _trace("no launcher: spawning %d ranks under torch.distributed.run (port %d)" % (args.gpus, port))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def hbm_footprint(torch, dev, items):
+    """what one GPU holds for the job, by part (bytes), beside what the allocator and the driver report"""
+    out = {k: int(v) for k, v in items.items()}
+    out["sum_of_parts"] = int(sum(items.values()))
+    try:
+        free, total = torch.cuda.mem_get_info(dev)
+        out.update({"torch_max_allocated": int(torch.cuda.max_memory_allocated(dev)), "device_in_use_now": int(total - free),
+                    "device_total": int(total)})
+    except Exception as e:                                   # pragma: no cover
+        out["error"] = repr(e)
+    return out
+
+
+def main_one_process(args):
+    """--impl one-process: the multi-GPU leg as a C++ host drives it -- ONE process, one slr_ctx per device, frames sharded "blocked"
+    (context k owns frames [k F, (k + 1) F) of the job) and computed straight into their slots of every context's own assembled
+    arrays by slr_reconstruct_mf_multi (no assembly inside the timed steps), then ONE exchange: slr_allgather_clouds -- every
+    source pushes its shard to its n - 1 peers by hipMemcpyPeerAsync on per-destination streams, one hop over the point-to-point
+    xGMI mesh, no ring, no staging -- timed on its own as final_allgather_ms (--gather after), or inside the timed
+    region as the last step's slr_reconstruct_mf_allgather_ex (--gather final).  The exchange proves itself: every context's
+    checksums of its LOCAL frames taken before the exchange must be reproduced by every device's assembled copy
+    (slr_cloud_checksums on each device; slr_verify_assembled compares the devices with each other)."""
+    import numpy as np  # noqa: F401
+    import torch
+    if args.mode != "mf":
+        raise SystemExit("--impl one-process runs the MF path (the C ABI's multi-GPU entries are slr_reconstruct_mf_*)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    N = max(1, args.gpus)
+    one_dev = bool(os.environ.get("SLR_BENCH_ONE_DEVICE"))
+    have = torch.cuda.device_count()
+    if have < N and not one_dev:
+        raise SystemExit("bench.py --impl one-process --gpus %d: this box has %d GPU(s) (SLR_BENCH_ONE_DEVICE=1: every context on device 0)" % (N, have))
+    devs = [0 if one_dev else k for k in range(N)]
+    slr = importlib.import_module("structure-light-reconstructor_amd")
+    synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+    W, H = args.width, args.height
+    F = args.frames if args.frames > 0 else 8
+    PASSES = max(1, args.passes)
+    rectify = bool(args.rectify)
+    ctxs = [slr.Context(d) for d in devs]
+    rig = rig_desc = None
+    calib, _ = synth.make_calibration(W, H)
+    if rectify and args.maps.startswith("verged"):
+        parts = args.maps.split(":")
+        rig_theta = float(parts[1]) if len(parts) > 1 else 0.2
+        rig_k1 = float(parts[2]) if len(parts) > 2 else -0.15
+        rig = synth.make_verged_rig(W, H, rig_theta, rig_k1)
+        calib = rig["calib"]
+        rig_desc = "verged stereo head: %.2f rad of toe-in in total, k1 %.2f (stereoRectify + slr_init_rectify_maps)" % (rig_theta, rig_k1)
+    elif rectify and args.maps != "near-identity":
+        raise SystemExit("--maps: verged[:theta:k1] or near-identity")
+    pitch = W + max(0, args.pitch_pad)
+    stacks, xyz_all, has_all = [], [], []
+    for k, c_ in enumerate(ctxs):
+        dev = torch.device("cuda", devs[k])
+        with torch.cuda.device(dev):
+            c_.set_calibration(calib)
+            if args.match_group:
+                c_.set_option(slr.capi.OPT_MF_BATCH_GROUP, args.match_group)
+            if args.decode_group:
+                c_.set_option(slr.capi.OPT_MF_BATCH_DECODE_GROUP, args.decode_group)
+            if args.eval_model == "x87":
+                c_.set_option(slr.capi.OPT_EVAL_MODEL, 1)
+            if rectify:
+                if rig is not None:
+                    synth.install_verged_maps(c_, rig, W, H)
+                else:
+                    for cam in range(2):
+                        mxy, mfr = synth.make_rectify_maps(W, H, cam, device=dev)
+                        c_.set_rectify_maps(cam, mxy, mfr)
+            st_ = torch.zeros((F, 2, 14, H, pitch), dtype=torch.uint8, device=dev)
+            for f in range(F):                              # job frame k F + f: the seeds of the ranks path (1234 + F rank + f)
+                st_[f, :, :, :, :W] = synth.render_mf_stack(W, H, seed=1234 + F * k + f, noise=2, device=dev)
+            stacks.append(st_)
+            xyz_all.append(torch.empty((N * F, H, W, 3), dtype=torch.float32, device=dev))
+            has_all.append(torch.empty((N * F, H, W), dtype=torch.uint8, device=dev))
+    for d in set(devs):
+        torch.cuda.synchronize(d)
+    _trace("one-process: %d contexts, frames rendered" % N)
+    # context k's shard, in place in ITS assembled arrays (blocked); slr_reconstruct_mf_multi's own labelling of the frames is
+    # cyclic, which only matters when it assembles -- it does not here (gather_ctx = -1)
+    xyz_loc = [xyz_all[k][k * F:(k + 1) * F] for k in range(N)]
+    has_loc = [has_all[k][k * F:(k + 1) * F] for k in range(N)]
+    final_gather = args.gather == "final" and N > 1
+    after_gather = args.gather in ("after", "step") and N > 1
+
+    def sync_all():
+        for d in set(devs):
+            torch.cuda.synchronize(d)
+
+    def compute():
+        # (frame f of multi's job = stacks[f % N][f // N]: with N * F frames every context gets its F)
+        slr.capi.reconstruct_mf_multi(ctxs, stacks, BLACK_THR, rectify, W=W, gather_ctx=-1, xyz=xyz_loc, has=has_loc)
+
+    def step(i, last=False):
+        for p_ in range(PASSES):
+            if last and final_gather and p_ == PASSES - 1:
+                slr.capi.reconstruct_mf_allgather(ctxs, stacks, BLACK_THR, rectify, W=W, assignment=slr.capi.ASSIGN_BLOCKED,
+                                                  out=(xyz_all, has_all))
+            else:
+                compute()
+
+    for i in range(args.warmup):
+        step(i)
+    sync_all()
+    if args.profile:
+        for c_ in ctxs:
+            c_.set_option(slr.capi.OPT_PROFILE_STRIDE, max(1, args.profile_stride))
+            c_.profile_enable(True)
+            c_.profile_reset()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, last=(i == args.steps - 1))
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _trace("one-process: timed region done")
+    prof = {}
+    if args.profile:
+        for c_ in ctxs:
+            for name, (ms, n) in c_.profile().items():
+                a = prof.get(name, (0.0, 0))
+                prof[name] = (a[0] + ms, a[1] + n)
+            c_.profile_enable(False)
+    gather_ms, proof, peer_direct = None, None, None
+    if N > 1:
+        # the owners' words: every context's LOCAL slots (before the exchange; with --gather final the pushes have already run, but
+        # nothing ever writes a context's own slots except its own kernels)
+        mine = [ctxs[k].cloud_checksums(xyz_loc[k], has_loc[k]) for k in range(N)]
+        if after_gather:
+            sync_all()
+            tg = time.perf_counter()
+            peer_direct = slr.capi.allgather_clouds(ctxs, xyz_all, has_all, assignment=slr.capi.ASSIGN_BLOCKED)
+            sync_all()
+            gather_ms = (time.perf_counter() - tg) * 1e3
+        owner = [int(w) for k in range(N) for w in mine[k]]
+        bad = []
+        for k in range(N):                                  # every device's whole assembled copy against the owners' words
+            got = ctxs[k].cloud_checksums(xyz_all[k], has_all[k])
+            bad += [(k, f) for f in range(N * F) if int(got[f]) != owner[f]]
+        mism = slr.capi.verify_assembled(ctxs, xyz_all, has_all)
+        proof = {"frames_verified_on_every_rank": N * F if not bad else 0, "all_ranks_ok": not bad and mism == 0,
+                 "error": None if not bad else "context/frame pairs that differ from their owner's word: %s" % bad[:8],
+                 "slr_verify_assembled_mismatches": mism,
+                 "how": "slr_cloud_checksums of every context's LOCAL frames before the exchange vs the same words of every device's "
+                        "assembled copy afterwards, + slr_verify_assembled (devices against each other)"}
+        if not proof["all_ranks_ok"]:
+            raise SystemExit("bench.py --impl one-process: the assembled point cloud does not match its owners' checksums: %s" % (proof["error"],))
+    npix = float(W) * H
+    value = N * npix * F * PASSES * args.steps / elapsed / 1e6
+    kernels, roofline = [], None
+    for name, (ms, n) in sorted(prof.items(), key=lambda kv: -kv[1][0]):
+        avg_ms = ms / n
+        fpl = frames_per_launch(args, "mf", rectify, F, name)
+        entry = {"name": name, "launches": int(round(n / fpl)), "frames_per_launch": fpl, "avg_launch_us": round(avg_ms * fpl * 1e3, 2),
+                 "avg_us": round(avg_ms * 1e3, 2), "total_ms": round(ms, 3)}
+        if name in ALG_BYTES:
+            gbs = ALG_BYTES[name] * npix / (avg_ms * 1e-3) / 1e9
+            entry.update({"alg_bytes_per_px": ALG_BYTES[name], "achieved_GBs": round(gbs, 1), "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        kernels.append(entry)
+    if kernels and kernels[0].get("achieved_GBs"):
+        k0 = kernels[0]
+        roofline = {"kernel": k0["name"], "bound": "hbm", "achieved": k0["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": k0["frac_hbm_peak"], "traffic": None, "traffic_source": "not collected in --impl one-process (see the N = 1 line)",
+                    "frames_per_launch": k0["frames_per_launch"], "us_per_frame": k0["avg_us"], "avg_launch_us": k0["avg_launch_us"],
+                    "alg_bytes_per_launch": ALG_BYTES[k0["name"]] * npix * k0["frames_per_launch"],
+                    "note": "mean over all %d contexts' launches (HIP events on each context's own stream)" % N}
+    uu = []
+    for d in devs:
+        try:
+            uu.append(str(torch.cuda.get_device_properties(d).uuid))
+        except Exception:
+            uu.append("device%d" % d)
+    print(json.dumps({
+        "metric": "Mpixels/s decode+unwrap+triangulate, 4096x3000 stereo, 1/2/4/8 GPU",
+        "value": round(value, 2), "unit": "Mpix/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8 in, f32 phase/XYZ (f64 undistort + Q reprojection)", "data": "synthetic",
+        "ms_per_frame": round(elapsed / args.steps / (F * PASSES) * 1e3, 4),
+        "config": {"workload": "%dx%d stereo, 3-freq x 4-step (14 planes/camera): rectify+decode+unwrap+match+triangulate; a step = %d passes "
+                               "over %d distinct HBM-resident frames per GPU (%d frames; every pass re-reads its input from HBM)" % (W, H, PASSES, F, PASSES * F),
+                   "maps": rig_desc or ("synthetic near-identity rectification maps" if rectify else None), "mode": "mf", "impl": "one-process",
+                   "frames_per_gpu_per_step": F * PASSES, "distinct_frames": F, "passes_per_step": PASSES, "rectify": rectify,
+                   "parallelism": "ONE process, %d slr_ctx on %d device(s), frames sharded blocked over the contexts (slr_reconstruct_mf_multi, "
+                                  "no assembly inside the steps)%s" % (N, len(set(devs)), "" if N == 1 else (
+                                      ", the last step's last pass is slr_reconstruct_mf_allgather_ex (compute + peer pushes, inside the timed region)"
+                                      if final_gather else ", one slr_allgather_clouds right after the timed steps (final_allgather_ms)"))},
+        "device": _device_info(torch, devs[0]),
+        "collective_backend": None if N == 1 else "peer", "collective_ranks": None if N == 1 else N,
+        "collective": None if N == 1 else {"backend": "peer", "ranks": N, "devices": [{"rank": k, "local_device": devs[k], "uuid": uu[k]} for k in range(N)],
+                                           "distinct_devices": len(set(uu)), "peer_direct": peer_direct,
+                                           "how": "hipMemcpyPeerAsync on per-destination streams of each source context (slr_allgather_clouds)"},
+        "final_allgather_ms": None if gather_ms is None else round(gather_ms, 3),
+        "gather_inclusive_value": (round(N * npix * F * PASSES * args.steps / (elapsed + gather_ms * 1e-3) / 1e6, 2) if gather_ms is not None
+                                   else (round(value, 2) if final_gather else None)),
+        "gather_proof": proof,
+        "final_allgather_bytes_per_rank_out": None if N == 1 else int((N - 1) * F * H * W * 13),
+        "hbm_footprint_per_gpu": hbm_footprint(torch, devs[0], {
+            "input_stack": stacks[0].numel(), "assembled_xyz_and_mask": xyz_all[0].numel() * 4 + has_all[0].numel(),
+            "phase_scratch_of_a_group": 8 * W * H * min(F, args.match_group or 8), "undistortion_tables": 12 * W * H,
+            "maps_and_tile_tables_both_cameras": 2 * (6 + 4) * W * H if rectify else 0}),
+        "eval_model": args.eval_model, "roofline": roofline, "kernels": kernels, "cpu_baseline": None}))
+    for c_ in ctxs:
+        c_.close()
+
+
 def main_mfn(args):
     """BASELINE config 5: one 8192x6000 stereo frame per step unit, 4 x 8 fp16 planes per camera (6.7 GB per frame), raw camera
     images through the rectification (slr_mfn_rectify_decode), then the match + triangulation of the 8192-pixel rows (chunked K4).
@@ -562,6 +796,10 @@ def _trace(what):
 
 def main():
     args = parse_args()
+    if args.impl == "one-process":
+        return main_one_process(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # started bare: be our own launcher (one rank per GPU)
+        return self_spawn(args)
     if args.mode == "mfn":
         return main_mfn(args)
     import numpy as np
@@ -572,9 +810,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." %
-                         (args.gpus, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d inside a torch.distributed job of %d rank(s): the two must agree" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     if os.environ.get("SLR_BENCH_ONE_DEVICE"):       # dry-run of the N>1 code path on a 1-GPU box (with gloo)
@@ -961,7 +1198,7 @@ def main():
             maps_info = [ctx.rectify_info(cam) for cam in range(2)]
         except Exception as e:
             maps_info = {"error": repr(e)}
-    if rank == 0 and args.profile and rectify and mode == "mf" and args.map_sweep and not args.pmc_child:
+    if rank == 0 and world == 1 and args.profile and rectify and mode == "mf" and args.map_sweep and not args.pmc_child:
         sweep = [("near-identity", None, None), ("verged", 0.1, -0.10), ("verged", 0.2, -0.15), ("verged", 0.3, -0.20)]
         for kind, theta, k1 in sweep:
             if kind == "verged" and rig is not None and abs(theta - rig_theta) < 1e-9 and abs(k1 - rig_k1) < 1e-9:
@@ -1076,6 +1313,14 @@ def main():
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
             "eval_model": args.eval_model, "self_check": self_check, "first_call_after_idle": first_call,
+            # what ONE GPU holds for the job (every rank holds the same shapes); config 4 at N = 8: 2.75 GB of input, the assembled
+            # cloud of all 64 frames (10.2 GB) once per output buffer
+            "hbm_footprint_per_gpu": hbm_footprint(torch, dev, {
+                "input_stack": stack.numel(),
+                "xyz_and_mask_buffers": sum(t.numel() * t.element_size() for t in ((g_xyz + g_has) if (do_gather or final_gather or after_gather) else (xyz + has))),
+                "phase_scratch_of_a_group": (8 * W * H * min(F, args.match_group or 8)) if mode in ("mf", "hybrid") else 0,
+                "undistortion_tables": 12 * W * H if mode != "gray" else 0,
+                "maps_and_tile_tables_both_cameras": 2 * (6 + 4) * W * H if rectify else 0}),
             "roofline": roofline,
             # the kernel north_star's ">= 60 % of the HBM roofline" target names: the UNFUSED phase-decode + unwrap kernel
             # (K2, 19 B/cam-px), measured live right after the timed region on the same frame and stream (10 launches)

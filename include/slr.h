@@ -437,6 +437,27 @@ int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, 
                                  int H, int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all,
                                  int require_peer, int *peer_direct);
 
+/* The same with the frame -> context assignment chosen by the caller, and the exchange step on its own.
+ *   SLR_ASSIGN_CYCLIC   frame f -> ctxs[f % n_ctx], shard slot f / n_ctx (what slr_reconstruct_mf_multi / _allgather use);
+ *   SLR_ASSIGN_BLOCKED  frame f -> ctxs[f / S], S = ceil(n_frames / n_ctx): a context's shard (stacks[k] = its frames in job
+ *                       order) is ONE contiguous piece of the assembled arrays, computed in place by the batch entry in groups of
+ *                       frames (one fused-decode and one match launch per group, SLR_OPT_MF_BATCH_GROUP) and pushed as one copy per
+ *                       destination and group.  The faster of the two; config 4 (64 frames, 8 GPUs) is one group per GPU.
+ * A source's pushes to its n_ctx - 1 peers run on per-destination streams (one point-to-point xGMI link each, side by side) behind
+ * the group that produced them and beside the next group's kernels.
+ * slr_allgather_clouds is the exchange alone: every ctxs[k] already holds ITS frames in their slots of its own xyz_all[k] /
+ * has_all[k] (e.g. slr_reconstruct_mf_multi with gather_ctx = -1 and xyz[k] pointing at its shard's place in xyz_all[k]; any work
+ * queued on ctxs[k]'s stream is waited for) and pushes them to every other device; it returns when every copy has landed.
+ * No reference counterpart (the reference is single-threaded, single-device); north_star: "RCCL all-gather over xGMI
+ * only to assemble the final point cloud" -- this is that step for a host that drives all GPUs from one process. */
+#define SLR_ASSIGN_CYCLIC 0
+#define SLR_ASSIGN_BLOCKED 1
+int slr_reconstruct_mf_allgather_ex(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W,
+                                    int H, int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all,
+                                    int assignment, int require_peer, int *peer_direct);
+int slr_allgather_clouds(slr_ctx *const *ctxs, int n_ctx, int n_frames, int W, int H, float *const *xyz_all,
+                         uint8_t *const *has_all, int assignment, int require_peer, int *peer_direct);
+
 /* Ordered prefix index of a u8 flag image [h][w] (nonzero = flagged), enumerated row-major (column_major = 0) or in the
  * column-outer / row-inner order in which MeshCreator numbers the vertices of a PointCloudImage (meshcreator.cpp:21-33,
  * 71-84): index[j][i] = first + (flagged elements before (i, j) in that order), or `none` where the flag is 0; *total = the

@@ -46,7 +46,7 @@ SYMBOLS = [
     "slr_mf_rectify_decode", "slr_mf_rectify_decode_pair", "slr_gray_decode", "slr_gray_rectify_decode", "slr_mf_triangulate",
     "slr_mf_triangulate_rows",
     "slr_ge_triangulate", "slr_ray_triangulate", "slr_line_line_intersections", "slr_pointcloud_from_grid", "slr_pointcloud_get",
-    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
+    "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_reconstruct_mf_allgather_ex", "slr_allgather_clouds", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
     "slr_prefix_index", "slr_compact_points", "slr_cloud_checksums", "slr_verify_assembled",
     "slr_host_alloc", "slr_host_free",
     "slr_timer_begin", "slr_timer_end", "slr_stream_copy", "slr_profile_enable", "slr_profile_reset",
@@ -77,6 +77,7 @@ class RectifyInfo(C.Structure):
 
 
 MODE_GRAY, MODE_GE, MODE_MF = 0, 1, 2
+ASSIGN_CYCLIC, ASSIGN_BLOCKED = 0, 1          # frame -> context assignment of the one-process multi-GPU entries (slr.h)
 
 
 class Calib(C.Structure):
@@ -711,32 +712,48 @@ def _sync_devices(tensors):
         torch.cuda.synchronize(d)
 
 
-def _multi_args(ctxs, stacks):
+def _share(nf, n, k, assignment):
+    """frames of context k of n: their count (cyclic: f % n == k; blocked: [k S, (k + 1) S), S = ceil(nf / n))"""
+    if assignment == ASSIGN_BLOCKED:
+        S = (nf + n - 1) // n
+        return max(0, min(nf, (k + 1) * S) - min(nf, k * S))
+    return (nf - k + n - 1) // n
+
+
+def _multi_args(ctxs, stacks, assignment=ASSIGN_CYCLIC):
     n = len(ctxs)
     nf = sum(int(s.shape[0]) for s in stacks)
     _, two, npl, H, pitch = stacks[0].shape
     assert two == 2 and npl == MF_PLANES and len(stacks) == n
     for k, s in enumerate(stacks):
-        assert s.is_cuda and s.is_contiguous() and int(s.shape[0]) == (nf - k + n - 1) // n
+        assert s.is_cuda and s.is_contiguous() and int(s.shape[0]) == _share(nf, n, k, assignment)
         assert s.device.index == ctxs[k].device_id, "stacks[k] must live on ctxs[k]'s device"
     return n, nf, H, pitch
 
 
-def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0):
+def reconstruct_mf_multi(ctxs, stacks, black_thr, rectify, W=None, gather_ctx=0, xyz=None, has=None):
     """slr_reconstruct_mf_multi: one Context per device (or several on one device), stacks[k] = torch.cuda u8
     [frames of k][2][14][H][pitch] on ctxs[k]'s device; frame f of the job is stacks[f % n][f // n].
+    xyz / has (optional): per-context output tensors [frames of k][H][W][3] / [frames of k][H][W] on ctxs[k]'s device -- e.g.
+    views of each context's assembled arrays, so that slr_allgather_clouds can exchange them in place afterwards.
     Returns (xyz_all, has_all) on ctxs[gather_ctx]'s device (or the per-ctx lists when gather_ctx < 0)."""
     import torch
     n, nf, H, pitch = _multi_args(ctxs, stacks)
     W = pitch if W is None else W
-    xyz = [_empty((int(s.shape[0]), H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
-    has = [_empty((int(s.shape[0]), H, W), dtype=torch.uint8, device=s.device) for s in stacks]
+    if xyz is None:
+        xyz = [_empty((int(s.shape[0]), H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
+    if has is None:
+        has = [_empty((int(s.shape[0]), H, W), dtype=torch.uint8, device=s.device) for s in stacks]
+    for k, s in enumerate(stacks):
+        assert tuple(xyz[k].shape) == (int(s.shape[0]), H, W, 3) and xyz[k].dtype == torch.float32 and xyz[k].is_contiguous()
+        assert tuple(has[k].shape) == (int(s.shape[0]), H, W) and has[k].dtype == torch.uint8 and has[k].is_contiguous()
+        assert xyz[k].device == s.device and has[k].device == s.device
     xa = ha = None
     if gather_ctx >= 0:
         gdev = stacks[gather_ctx].device
         xa = _empty((nf, H, W, 3), dtype=torch.float32, device=gdev)
         ha = _empty((nf, H, W), dtype=torch.uint8, device=gdev)
-    _sync_devices(list(stacks) + xyz + has + [xa, ha])
+    _sync_devices(list(stacks) + list(xyz) + list(has) + [xa, ha])
     arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
     arr_s = (C.c_void_p * n)(*[s.data_ptr() for s in stacks])
     arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xyz])
@@ -762,22 +779,54 @@ def verify_assembled(ctxs, xyz_all, has_all):
     return mism.value
 
 
-def reconstruct_mf_allgather(ctxs, stacks, black_thr, rectify, W=None, require_peer=False):
-    """slr_reconstruct_mf_allgather: as reconstruct_mf_multi, but EVERY device ends with the assembled cloud.
+def reconstruct_mf_allgather(ctxs, stacks, black_thr, rectify, W=None, require_peer=False, assignment=None, out=None):
+    """slr_reconstruct_mf_allgather (assignment None: frame f -> ctxs[f % n]) / slr_reconstruct_mf_allgather_ex (ASSIGN_CYCLIC or
+    ASSIGN_BLOCKED: stacks[k] = the frames [k S, (k + 1) S) of the job, computed in groups and pushed as one copy per destination
+    and group): as reconstruct_mf_multi, but EVERY device ends with the assembled cloud.  out = (xyz_all list, has_all list) to
+    reuse caller-owned assembled arrays.
     Returns (xyz_all[k], has_all[k], peer_direct): per-ctx lists of [n_frames][H][W][3] / [n_frames][H][W] tensors."""
     import torch
-    n, nf, H, pitch = _multi_args(ctxs, stacks)
+    n, nf, H, pitch = _multi_args(ctxs, stacks, ASSIGN_CYCLIC if assignment is None else assignment)
     W = pitch if W is None else W
-    xa = [_empty((nf, H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
-    ha = [_empty((nf, H, W), dtype=torch.uint8, device=s.device) for s in stacks]
-    _sync_devices(list(stacks) + xa + ha)
+    if out is None:
+        xa = [_empty((nf, H, W, 3), dtype=torch.float32, device=s.device) for s in stacks]
+        ha = [_empty((nf, H, W), dtype=torch.uint8, device=s.device) for s in stacks]
+    else:
+        xa, ha = out
+        for k, s in enumerate(stacks):
+            assert tuple(xa[k].shape) == (nf, H, W, 3) and tuple(ha[k].shape) == (nf, H, W) and xa[k].is_contiguous() and ha[k].is_contiguous()
+            assert xa[k].device == s.device and ha[k].device == s.device
+    _sync_devices(list(stacks) + list(xa) + list(ha))
     arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
     arr_s = (C.c_void_p * n)(*[s.data_ptr() for s in stacks])
     arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xa])
     arr_h = (C.c_void_p * n)(*[t.data_ptr() for t in ha])
     direct = C.c_int(-1)
-    st = ctxs[0].lib.slr_reconstruct_mf_allgather(arr_c, C.c_int(n), C.c_int(nf), arr_s, C.c_int(pitch), C.c_int(W), C.c_int(H),
-                                                  C.c_int(black_thr), C.c_int(1 if rectify else 0), arr_x, arr_h,
-                                                  C.c_int(1 if require_peer else 0), C.byref(direct))
+    if assignment is None:
+        st = ctxs[0].lib.slr_reconstruct_mf_allgather(arr_c, C.c_int(n), C.c_int(nf), arr_s, C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                                      C.c_int(black_thr), C.c_int(1 if rectify else 0), arr_x, arr_h,
+                                                      C.c_int(1 if require_peer else 0), C.byref(direct))
+    else:
+        st = ctxs[0].lib.slr_reconstruct_mf_allgather_ex(arr_c, C.c_int(n), C.c_int(nf), arr_s, C.c_int(pitch), C.c_int(W), C.c_int(H),
+                                                         C.c_int(black_thr), C.c_int(1 if rectify else 0), arr_x, arr_h,
+                                                         C.c_int(assignment), C.c_int(1 if require_peer else 0), C.byref(direct))
     ctxs[0]._chk(st)
     return xa, ha, direct.value
+
+
+def allgather_clouds(ctxs, xyz_all, has_all, assignment=ASSIGN_BLOCKED, require_peer=False):
+    """slr_allgather_clouds: the exchange alone.  xyz_all[k] / has_all[k] = context k's assembled arrays ([n_frames][H][W][3] /
+    [n_frames][H][W] on its device) which already hold ITS frames in their slots; returns peer_direct."""
+    n = len(ctxs)
+    nf, H, W = has_all[0].shape
+    for k in range(n):
+        assert tuple(xyz_all[k].shape) == (nf, H, W, 3) and tuple(has_all[k].shape) == (nf, H, W)
+        assert xyz_all[k].is_contiguous() and has_all[k].is_contiguous() and xyz_all[k].device.index == ctxs[k].device_id
+    _sync_devices(list(xyz_all) + list(has_all))
+    arr_c = (C.c_void_p * n)(*[c.h.value for c in ctxs])
+    arr_x = (C.c_void_p * n)(*[t.data_ptr() for t in xyz_all])
+    arr_h = (C.c_void_p * n)(*[t.data_ptr() for t in has_all])
+    direct = C.c_int(-1)
+    ctxs[0]._chk(ctxs[0].lib.slr_allgather_clouds(arr_c, C.c_int(n), C.c_int(nf), C.c_int(W), C.c_int(H), arr_x, arr_h,
+                                                   C.c_int(assignment), C.c_int(1 if require_peer else 0), C.byref(direct)))
+    return direct.value

@@ -81,6 +81,11 @@ struct slr_ctx {
     hipStream_t pipe = nullptr;                 // the second stream of that pipeline
     hipEvent_t ev_pipe[2] = {nullptr, nullptr};
     hipEvent_t mid_event = nullptr;             // recorded by core_ray between a GRAY_ONLY frame's two halves (the pipeline's skew)
+    // one-process multi-GPU exchange: one push stream per DESTINATION context (the copies of one source to its n - 1 peers run
+    // side by side, one per point-to-point xGMI link, instead of one after the other on the compute stream)
+    std::vector<hipStream_t> push_streams;
+    std::vector<hipEvent_t> push_done;
+    hipEvent_t ev_computed = nullptr;           // recorded on `stream` when a group of frames is ready to be pushed
     // profiler
     bool profiling = false;
     std::vector<ProfRec> pending;
@@ -581,6 +586,9 @@ int slr_destroy(slr_ctx *c)
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->pipe) { (void)hipStreamSynchronize(c->pipe); (void)hipStreamDestroy(c->pipe); }
     for (int k = 0; k < 2; k++) if (c->ev_pipe[k]) (void)hipEventDestroy(c->ev_pipe[k]);
+    for (auto ps : c->push_streams) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
+    for (auto e : c->push_done) (void)hipEventDestroy(e);
+    if (c->ev_computed) (void)hipEventDestroy(c->ev_computed);
     for (int i = 0; i < 2 * S_COUNT; i++) if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < 2; k++) { if (c->d_map_xy[k]) (void)hipFree(c->d_map_xy[k]); if (c->d_map_frac[k]) (void)hipFree(c->d_map_frac[k]); if (c->d_tile_box[k]) (void)hipFree(c->d_tile_box[k]); if (c->d_dma_tiles[k]) (void)hipFree(c->d_dma_tiles[k]); }
     if (c->d_lut) (void)hipFree(c->d_lut);
@@ -1720,21 +1728,44 @@ int slr_reconstruct_mf_multi(slr_ctx *const *ctxs, int n_ctx, int n_frames, cons
     return SLR_OK;
 }
 
-// north_star's exchange step from one process: EVERY device ends with the assembled cloud.  ctxs[k] computes its frames straight
-// into their slots of its own xyz_all[k] / has_all[k] ([n_frames][H][W][3] / [n_frames][H][W] on its device) and its stream then
-// pushes each of them into the same slot on every other device -- n_ctx - 1 concurrent one-hop copies per frame over the
-// point-to-point xGMI mesh, no staging buffer and no ring.  *peer_direct (may be NULL) = 1 when every destination was directly
-// addressable from every source (same device or peer access), 0 when the runtime had to stage at least one pair through the
-// host; require_peer != 0 turns that case into SLR_ERR_UNSUPPORTED before any work is enqueued.
-int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
-                                 int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all, int require_peer,
-                                 int *peer_direct_out)
+// ---- north_star's exchange step from one process: EVERY device ends with the assembled cloud -------------------------------------
+// Which context owns which frames of the job: SLR_ASSIGN_CYCLIC frame f -> ctxs[f % n] (shard slot f / n), SLR_ASSIGN_BLOCKED
+// frame f -> ctxs[f / S] with S = ceil(n_frames / n): a context's shard is then ONE contiguous piece of the assembled arrays, the
+// batch entry fills it in place in groups of frames (one fused-decode and one match launch per group) and a push is one copy per
+// destination and group instead of one per frame.
+namespace {
+
+struct Share { int first, count, step; };                   // frames first, first + step, ... (count of them)
+Share share_of(int n_frames, int n_ctx, int k, int assignment)
 {
-    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
-    slr_ctx *c0 = ctxs[0];
-    if (!stacks || !xyz_all || !has_all || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
-    SLR_TRY(multi_check(ctxs, n_ctx, n_frames, stacks, pitch, W, H, rectify));
-    for (int k = 0; k < n_ctx; k++) if (!xyz_all[k] || !has_all[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null destination");
+    if (assignment == SLR_ASSIGN_BLOCKED) {
+        const int S = (n_frames + n_ctx - 1) / n_ctx;
+        const int a = k * S < n_frames ? k * S : n_frames, b = (k + 1) * S < n_frames ? (k + 1) * S : n_frames;
+        return {a, b - a, 1};
+    }
+    return {k, multi_share(n_frames, n_ctx, k), n_ctx};
+}
+
+// the push streams (one per destination) and events of context c on its device; idempotent
+int push_streams_of(slr_ctx *c, int n_dst)
+{
+    SLR_HIP(c, hipSetDevice(c->device));
+    if (!c->ev_computed) SLR_HIP(c, hipEventCreateWithFlags(&c->ev_computed, hipEventDisableTiming));
+    while ((int)c->push_streams.size() < n_dst) {
+        hipStream_t s = nullptr;
+        SLR_HIP(c, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        c->push_streams.push_back(s);
+    }
+    while ((int)c->push_done.size() < n_dst) {
+        hipEvent_t e = nullptr;
+        SLR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->push_done.push_back(e);
+    }
+    return SLR_OK;
+}
+
+int peer_matrix(slr_ctx *const *ctxs, int n_ctx, int require_peer, int *peer_direct_out)
+{
     bool all_direct = true;
     for (int k = 0; k < n_ctx; k++)
         for (int j = 0; j < n_ctx; j++) {
@@ -1743,22 +1774,37 @@ int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, 
             all_direct = all_direct && d;
         }
     if (peer_direct_out) *peer_direct_out = all_direct ? 1 : 0;
-    if (!all_direct && require_peer) return fail(c0, SLR_ERR_UNSUPPORTED, "peer access between two of the devices is not available");
-    const size_t n = (size_t)W * H, plane = (size_t)pitch * H;
+    if (!all_direct && require_peer) return fail(ctxs[0], SLR_ERR_UNSUPPORTED, "peer access between two of the devices is not available");
+    return SLR_OK;
+}
+
+// frames [f0, f0 + g) (consecutive, or g == 1) of source k -> the same slots of every other context's arrays, behind whatever
+// c->stream holds now; destination d's copies go to c's push stream d (n - 1 one-hop copies side by side)
+int push_frames(slr_ctx *const *ctxs, int n_ctx, int k, size_t f0, int g, size_t n, float *const *xyz_all, uint8_t *const *has_all)
+{
+    slr_ctx *c = ctxs[k];
+    SLR_MULTI_HIP(c, hipSetDevice(c->device));
+    SLR_MULTI_HIP(c, hipEventRecord(c->ev_computed, c->stream));
+    for (int d = 0; d < n_ctx; d++) {
+        if (d == k || (xyz_all[d] == xyz_all[k] && ctxs[d]->device == c->device)) continue;
+        hipStream_t ps = c->push_streams[(size_t)d];
+        SLR_MULTI_HIP(c, hipStreamWaitEvent(ps, c->ev_computed, 0));
+        SLR_MULTI_HIP(c, hipMemcpyPeerAsync(xyz_all[d] + f0 * n * 3, ctxs[d]->device, xyz_all[k] + f0 * n * 3, c->device, (size_t)g * n * 12, ps));
+        SLR_MULTI_HIP(c, hipMemcpyPeerAsync(has_all[d] + f0 * n, ctxs[d]->device, has_all[k] + f0 * n, c->device, (size_t)g * n, ps));
+    }
+    return SLR_OK;
+}
+
+// every context's stream waits for its own pushes, then the call waits for every stream: the assembled clouds are complete
+int finish_exchange(slr_ctx *const *ctxs, int n_ctx)
+{
     for (int k = 0; k < n_ctx; k++) {
-        const int share = multi_share(n_frames, n_ctx, k);
         slr_ctx *c = ctxs[k];
-        for (int j = 0; j < share; j++) {
-            const size_t f = (size_t)j * n_ctx + k;
-            // frame f of the job = frame j of this shard, computed in place
-            const int st = slr_reconstruct_mf_batch(c, 1, stacks[k] + (size_t)j * 2 * SLR_MF_PLANES * plane, pitch, W, H, black_thr, rectify,
-                                                    xyz_all[k] + f * n * 3, has_all[k] + f * n);
-            if (st != SLR_OK) { if (c != c0) fail(c0, st, "shard failed", slr_last_error(c)); multi_drain(ctxs, n_ctx); return st; }
-            for (int d = 0; d < n_ctx; d++) {
-                if (d == k || (xyz_all[d] == xyz_all[k] && ctxs[d]->device == c->device)) continue;
-                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(xyz_all[d] + f * n * 3, ctxs[d]->device, xyz_all[k] + f * n * 3, c->device, n * 12, c->stream));
-                SLR_MULTI_HIP(c, hipMemcpyPeerAsync(has_all[d] + f * n, ctxs[d]->device, has_all[k] + f * n, c->device, n, c->stream));
-            }
+        SLR_MULTI_HIP(c, hipSetDevice(c->device));
+        for (int d = 0; d < n_ctx && d < (int)c->push_streams.size(); d++) {
+            if (d == k) continue;
+            SLR_MULTI_HIP(c, hipEventRecord(c->push_done[(size_t)d], c->push_streams[(size_t)d]));
+            SLR_MULTI_HIP(c, hipStreamWaitEvent(c->stream, c->push_done[(size_t)d], 0));
         }
     }
     for (int k = 0; k < n_ctx; k++) {
@@ -1766,6 +1812,113 @@ int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, 
         SLR_MULTI_HIP(ctxs[k], hipStreamSynchronize(ctxs[k]->stream));
     }
     return SLR_OK;
+}
+
+int drain_pushes_then(slr_ctx *const *ctxs, int n_ctx, int st)     // an error in the middle: nothing may still be copying
+{
+    for (int k = 0; k < n_ctx; k++) {
+        if (hipSetDevice(ctxs[k]->device) != hipSuccess) continue;
+        for (auto ps : ctxs[k]->push_streams) (void)hipStreamSynchronize(ps);
+    }
+    multi_drain(ctxs, n_ctx);
+    return st;
+}
+
+}  // namespace
+
+// The exchange alone: every context already holds ITS frames in their slots of its own assembled arrays (e.g. written there by
+// slr_reconstruct_mf_multi with xyz[k] pointing into xyz_all[k], or by any other producer on ctxs[k]'s stream) and pushes them
+// to every other device.
+int slr_allgather_clouds(slr_ctx *const *ctxs, int n_ctx, int n_frames, int W, int H, float *const *xyz_all, uint8_t *const *has_all,
+                         int assignment, int require_peer, int *peer_direct_out)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c0 = ctxs[0];
+    if (!xyz_all || !has_all || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
+    if (assignment != SLR_ASSIGN_CYCLIC && assignment != SLR_ASSIGN_BLOCKED) return fail(c0, SLR_ERR_INVALID_ARG, "assignment must be SLR_ASSIGN_CYCLIC or SLR_ASSIGN_BLOCKED");
+    for (int k = 0; k < n_ctx; k++) {
+        if (!ctxs[k] || !xyz_all[k] || !has_all[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null context or array");
+        SLR_TRY(check_dims(ctxs[k], W, H, W));
+    }
+    SLR_TRY(peer_matrix(ctxs, n_ctx, require_peer, peer_direct_out));
+    for (int k = 0; k < n_ctx; k++) {
+        const int st = push_streams_of(ctxs[k], n_ctx);
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "a context failed", slr_last_error(ctxs[k])); return st; }
+    }
+    const size_t n = (size_t)W * H;
+    for (int k = 0; k < n_ctx; k++) {
+        const Share sh = share_of(n_frames, n_ctx, k, assignment);
+        if (sh.count <= 0) continue;
+        if (sh.step == 1) { const int st = push_frames(ctxs, n_ctx, k, (size_t)sh.first, sh.count, n, xyz_all, has_all); if (st != SLR_OK) return drain_pushes_then(ctxs, n_ctx, st); }
+        else
+            for (int j = 0; j < sh.count; j++) {
+                const int st = push_frames(ctxs, n_ctx, k, (size_t)sh.first + (size_t)j * sh.step, 1, n, xyz_all, has_all);
+                if (st != SLR_OK) return drain_pushes_then(ctxs, n_ctx, st);
+            }
+    }
+    const int st = finish_exchange(ctxs, n_ctx);
+    return st == SLR_OK ? SLR_OK : drain_pushes_then(ctxs, n_ctx, st);
+}
+
+// Compute + exchange.  ctxs[k] computes its frames straight into their slots of its own xyz_all[k] / has_all[k] ([n_frames][H][W][3]
+// / [n_frames][H][W] on its device) and pushes each finished frame (cyclic) or group of frames (blocked) into the same slots on
+// every other device -- n_ctx - 1 concurrent one-hop copies over the point-to-point xGMI mesh on per-destination streams, no
+// staging buffer and no ring, overlapping the next group's kernels.  *peer_direct (may be NULL) = 1 when every destination was
+// directly addressable from every source (same device or peer access), 0 when the runtime had to stage at least one pair through
+// the host; require_peer != 0 turns that case into SLR_ERR_UNSUPPORTED before any work is enqueued.
+int slr_reconstruct_mf_allgather_ex(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
+                                    int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all, int assignment,
+                                    int require_peer, int *peer_direct_out)
+{
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return SLR_ERR_INVALID_ARG;
+    slr_ctx *c0 = ctxs[0];
+    if (!stacks || !xyz_all || !has_all || n_frames < 0) return fail(c0, SLR_ERR_INVALID_ARG, "bad argument");
+    if (assignment != SLR_ASSIGN_CYCLIC && assignment != SLR_ASSIGN_BLOCKED) return fail(c0, SLR_ERR_INVALID_ARG, "assignment must be SLR_ASSIGN_CYCLIC or SLR_ASSIGN_BLOCKED");
+    for (int k = 0; k < n_ctx; k++) {                        // (multi_check's shard test, for either assignment)
+        if (!ctxs[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null context");
+        if (share_of(n_frames, n_ctx, k, assignment).count > 0 && !stacks[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null shard");
+        const int st = mf_batch_check(ctxs[k], pitch, W, H, rectify);
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "a context refused the job", slr_last_error(ctxs[k])); return st; }
+    }
+    for (int k = 0; k < n_ctx; k++) if (!xyz_all[k] || !has_all[k]) return fail(c0, SLR_ERR_INVALID_ARG, "null destination");
+    SLR_TRY(peer_matrix(ctxs, n_ctx, require_peer, peer_direct_out));
+    for (int k = 0; k < n_ctx; k++) {
+        const int st = push_streams_of(ctxs[k], n_ctx);
+        if (st != SLR_OK) { if (ctxs[k] != c0) fail(c0, st, "a context failed", slr_last_error(ctxs[k])); return st; }
+    }
+    const size_t n = (size_t)W * H, frame = (size_t)2 * SLR_MF_PLANES * pitch * H;
+    // group by group, round robin over the contexts: every device gets its first group before any gets its second
+    int gmax = 1, rounds = 0;
+    for (int k = 0; k < n_ctx; k++) {
+        const Share sh = share_of(n_frames, n_ctx, k, assignment);
+        const int g = sh.step == 1 ? mf_batch_group_of(ctxs[k], W, rectify) : 1;
+        gmax = g > gmax ? g : gmax;
+    }
+    for (int k = 0; k < n_ctx; k++) { const int cnt = share_of(n_frames, n_ctx, k, assignment).count; rounds = (cnt + gmax - 1) / gmax > rounds ? (cnt + gmax - 1) / gmax : rounds; }
+    for (int r = 0; r < rounds; r++)
+        for (int k = 0; k < n_ctx; k++) {
+            const Share sh = share_of(n_frames, n_ctx, k, assignment);
+            const int j0 = r * gmax;
+            if (j0 >= sh.count) continue;
+            const int g = sh.count - j0 < gmax ? sh.count - j0 : gmax;
+            slr_ctx *c = ctxs[k];
+            const size_t f0 = (size_t)sh.first + (size_t)j0 * sh.step;
+            // frames f0 .. of the job = frames j0 .. of this shard, computed in place
+            int st = slr_reconstruct_mf_batch(c, g, stacks[k] + (size_t)j0 * frame, pitch, W, H, black_thr, rectify, xyz_all[k] + f0 * n * 3, has_all[k] + f0 * n);
+            if (st != SLR_OK) { if (c != c0) fail(c0, st, "shard failed", slr_last_error(c)); return drain_pushes_then(ctxs, n_ctx, st); }
+            st = push_frames(ctxs, n_ctx, k, f0, g, n, xyz_all, has_all);
+            if (st != SLR_OK) return drain_pushes_then(ctxs, n_ctx, st);
+        }
+    const int st = finish_exchange(ctxs, n_ctx);
+    return st == SLR_OK ? SLR_OK : drain_pushes_then(ctxs, n_ctx, st);
+}
+
+int slr_reconstruct_mf_allgather(slr_ctx *const *ctxs, int n_ctx, int n_frames, const uint8_t *const *stacks, int pitch, int W, int H,
+                                 int black_thr, int rectify, float *const *xyz_all, uint8_t *const *has_all, int require_peer,
+                                 int *peer_direct_out)
+{
+    return slr_reconstruct_mf_allgather_ex(ctxs, n_ctx, n_frames, stacks, pitch, W, H, black_thr, rectify, xyz_all, has_all,
+                                           SLR_ASSIGN_CYCLIC, require_peer, peer_direct_out);
 }
 
 // One checksum per frame of a device-resident cloud; and the proof of an exchange: every context checksums the assembled arrays

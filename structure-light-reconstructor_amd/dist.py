@@ -5,6 +5,8 @@ assembly of the final point cloud: one RCCL all-gather (torch.distributed backen
 per-frame XYZ + mask.  No collective happens inside the decode / match kernels.  On CPU test rigs the same code
 runs over gloo (tests/test_dist_gloo.py, world_size 2), with the reconstruction step injected.
 """
+import inspect
+
 import torch
 import torch.distributed as dist
 
@@ -104,15 +106,19 @@ def frame_checksums(xyz, has):
     w = torch.arange(1, H + 1, dtype=torch.int64, device=xyz.device)
     out = torch.empty(n, dtype=torch.int64, device=xyz.device)
     wx = wh = None
+    R = 256                                                  # rows per block: the int64 temporaries stay at 8 x a block, not 8 x a frame
     for f in range(n):
         bx = xyz[f].contiguous().view(torch.int32).view(H, -1)
         bh = has[f].contiguous().view(H, -1)
         if wx is None:
             wx = torch.arange(bx.shape[1], dtype=torch.int64, device=xyz.device) % 65521 + 1
             wh = torch.arange(bh.shape[1], dtype=torch.int64, device=xyz.device) % 65521 + 1
-        rx = (bx.to(torch.int64) * wx).sum(dim=1)
-        rh = (bh.to(torch.int64) * wh).sum(dim=1)
-        out[f] = (rx * w).sum() * 1000003 + (rh * w).sum()
+        sx = torch.zeros((), dtype=torch.int64, device=xyz.device)
+        sh = torch.zeros((), dtype=torch.int64, device=xyz.device)
+        for r0 in range(0, H, R):
+            sx += ((bx[r0:r0 + R].to(torch.int64) * wx).sum(dim=1) * w[r0:r0 + R]).sum()
+            sh += ((bh[r0:r0 + R].to(torch.int64) * wh).sum(dim=1) * w[r0:r0 + R]).sum()
+        out[f] = sx * 1000003 + sh
     return out
 
 
@@ -148,6 +154,13 @@ def reconstruct_sharded(n_frames, H, W, load_frame, reconstruct, device, group=N
     assembled arrays, so nothing is copied between the kernels and the collective.
     verify=True: prove the assembled cloud with per-frame checksums (verify_gathered).
     """
+    try:                                                     # the callback's arity, checked up front (round 4 changed the signature)
+        inspect.signature(reconstruct).bind(None, None, None)
+    except TypeError as e:
+        raise TypeError("reconstruct_sharded: `reconstruct` must take (frame, xyz_out, has_out) and write the frame's cloud into "
+                        "the two views (not the old reconstruct(frame) -> (xyz, has))") from e
+    except ValueError:                                       # a callable without an introspectable signature: let the call speak
+        pass
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     S = frames_per_rank(n_frames, world)
@@ -155,13 +168,7 @@ def reconstruct_sharded(n_frames, H, W, load_frame, reconstruct, device, group=N
     g_has = torch.zeros((S * world, H, W), dtype=torch.uint8, device=device)
     loc_xyz, loc_has = local_slots(g_xyz, rank, world, assignment), local_slots(g_has, rank, world, assignment)
     for s, f in enumerate(shard_frames(n_frames, rank, world, assignment)):
-        try:
-            reconstruct(load_frame(f), loc_xyz[s], loc_has[s])
-        except TypeError as e:
-            if "positional argument" in str(e):              # a callback of the old signature reconstruct(frame) -> (xyz, has)
-                raise TypeError("reconstruct_sharded: `reconstruct` must take (frame, xyz_out, has_out) and write the frame's cloud "
-                                "into the two views (round 4 changed the signature from reconstruct(frame) -> (xyz, has))") from e
-            raise
+        reconstruct(load_frame(f), loc_xyz[s], loc_has[s])
     mine = frame_checksums(loc_xyz, loc_has) if verify else None              # before the (in-place) gather touches anything
     xyz, has = gather_point_clouds(loc_xyz, loc_has, n_frames, group, out=(g_xyz, g_has), assignment=assignment)
     if verify:

@@ -216,3 +216,81 @@ def test_row_band_sharding_of_one_frame(tmp_path):
         assert np.array_equal(xyz.view(np.uint32), exyz.view(np.uint32))
     assert [sdist.shard_rows(6000, r, 8) for r in (0, 7)] == [(0, 750), (5250, 6000)]
     assert sdist.shard_rows(5, 3, 4) == (5, 5)                        # empty band
+
+
+# ---- BASELINE config 4's shape: 64 frames over 8 ranks (small frames), the exchange bench.py runs, proof on ----------------
+def _worker8(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+    sdist = importlib.import_module("structure-light-reconstructor_amd.dist")
+    import oracle as O
+    from util import calib_parts
+
+    def reconstruct(f, xyz_out, has_out):
+        xyz, has = _frame_result(synth, O, calib_parts, f)
+        xyz_out.copy_(torch.from_numpy(xyz))
+        has_out.copy_(torch.from_numpy(has))
+
+    own = sdist.shard_frames(n_frames, rank, world, "blocked")
+    assert own == list(range(rank * (n_frames // world), (rank + 1) * (n_frames // world)))
+    # as on RCCL: the backend reports "nccl", every collective must arrive in NCCL's in-place form, the exchange runs over gloo
+    real_gather, seen = dist.all_gather_into_tensor, []
+
+    def checked_gather(out, src, group=None):
+        kind = sdist._alias(out, src, dist.get_rank(group))
+        seen.append(kind)
+        assert kind in ("inplace", "disjoint")
+        return real_gather(out, src.clone(), group=group)
+
+    sdist.dist.get_backend, keep_backend = (lambda group=None: "nccl"), sdist.dist.get_backend
+    sdist.dist.all_gather_into_tensor = checked_gather
+    try:
+        xyz, has = sdist.reconstruct_sharded(n_frames, H, W, lambda f: f, reconstruct, torch.device("cpu"), verify=True,
+                                             assignment="blocked")
+    finally:
+        sdist.dist.get_backend, sdist.dist.all_gather_into_tensor = keep_backend, real_gather
+    assert seen.count("inplace") == 2 and len(seen) == 3     # XYZ and mask in place, one per array; the proof's words on their own
+    assert xyz.shape == (n_frames, H, W, 3) and has.shape == (n_frames, H, W)
+    np.save(os.path.join(out_dir, "words_%d.npy" % rank), sdist.frame_checksums(xyz, has).numpy())
+    if rank in (0, world - 1):
+        np.save(os.path.join(out_dir, "has8_%d.npy" % rank), has.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_shape_64_frames_over_8_ranks(tmp_path):
+    """64 frames sharded blocked over 8 gloo ranks (8 per rank, what bench.py --gpus 8 runs per step at 4096x3000), one in-place
+    all-gather per array, the checksum proof on every rank; every rank's assembled cloud == the oracle run frame by frame"""
+    world, n_frames = 8, 64
+    mp.spawn(_worker8, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    synth = importlib.import_module("structure-light-reconstructor_amd.synth")
+    sdist = importlib.import_module("structure-light-reconstructor_amd.dist")
+    import oracle as O
+    from util import calib_parts
+    exp = [_frame_result(synth, O, calib_parts, f) for f in range(n_frames)]
+    ex = torch.from_numpy(np.stack([e[0] for e in exp]))
+    eh = torch.from_numpy(np.stack([e[1] for e in exp]))
+    words = sdist.frame_checksums(ex, eh).numpy()
+    assert len(set(words.tolist())) == n_frames               # 64 distinct frames
+    for rank in range(world):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "words_%d.npy" % rank)), words), rank
+    for rank in (0, world - 1):
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "has8_%d.npy" % rank)), eh.numpy())
+
+
+def test_reconstruct_sharded_reports_a_wrong_callback_signature_up_front():
+    sdist = importlib.import_module("structure-light-reconstructor_amd.dist")
+    import pytest
+    with pytest.raises(TypeError, match="must take"):
+        sdist.reconstruct_sharded(1, H, W, lambda f: f, lambda frame: None, torch.device("cpu"))
+
+    def inner_bug(frame, xyz_out, has_out):                  # a TypeError INSIDE a well-formed callback stays what it is
+        return len(5)
+    with pytest.raises(TypeError, match="has no len"):
+        sdist.reconstruct_sharded(1, H, W, lambda f: f, inner_bug, torch.device("cpu"))

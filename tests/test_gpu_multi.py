@@ -274,3 +274,133 @@ def test_bench_config5_two_row_bands_with_a_collective_on_this_box():
                 "RCCL failed for a reason other than two ranks on one device:\n" + text[-1500:]
             continue
         pytest.fail("bench.py --mode mfn --gpus 2 failed over gloo: rc %d\n%s" % (r.returncode, r.stderr[-1500:]))
+
+
+# ---- round 6: the blocked assignment, the exchange on its own, bench.py as its own launcher, --impl one-process -----------------
+def _blocked_job(slr, synth, n_ctx, n_frames, W=320, H=64):
+    calib, _ = synth.make_calibration(W, H, with_T=True)
+    maps = [synth.make_rectify_maps(W, H, cam) for cam in range(2)]
+    ctxs = [slr.Context(0) for _ in range(n_ctx)]
+    for c in ctxs:
+        c.set_calibration(calib)
+        for cam in range(2):
+            c.set_rectify_maps(cam, maps[cam][0].numpy(), maps[cam][1].numpy())
+    frames = torch.stack([synth.render_mf_stack(W, H, seed=900 + f, noise=2) for f in range(n_frames)]).cuda()
+    S = (n_frames + n_ctx - 1) // n_ctx
+    stacks = [frames[min(n_frames, k * S):min(n_frames, (k + 1) * S)].contiguous() for k in range(n_ctx)]
+    return ctxs, stacks, frames
+
+
+@pytest.mark.parametrize("n_ctx,n_frames,group", [(3, 7, 0), (2, 5, 2), (3, 2, 0), (1, 3, 0), (4, 21, 3)])
+def test_allgather_ex_blocked_equals_the_batch_entry(slr, synth, n_ctx, n_frames, group):
+    """slr_reconstruct_mf_allgather_ex(SLR_ASSIGN_BLOCKED): context k owns frames [k S, (k + 1) S) (ragged and empty shards included),
+    computed in groups in place and pushed per group on per-destination streams == slr_reconstruct_mf_batch of all frames on one
+    context; the cyclic assignment through the same entry == the old entry; the exchange alone (slr_allgather_clouds) after
+    slr_reconstruct_mf_multi wrote the shards in place gives the same arrays"""
+    ctxs, stacks, frames = _blocked_job(slr, synth, n_ctx, n_frames)
+    try:
+        if group:
+            for c in ctxs:
+                c.set_option(slr.capi.OPT_MF_BATCH_GROUP, group)
+        ex, eh = ctxs[0].reconstruct_mf_batch(frames, BLACK, True)
+        ctxs[0].synchronize()
+        xs, hs, direct = slr.capi.reconstruct_mf_allgather(ctxs, stacks, BLACK, True, require_peer=True, assignment=slr.capi.ASSIGN_BLOCKED)
+        assert direct == 1
+        for k in range(n_ctx):
+            assert torch.equal(hs[k], eh) and torch.equal(xs[k], ex), k
+        assert slr.capi.verify_assembled(ctxs, xs, hs) == 0
+        # the exchange on its own: poisoned assembled arrays, every context's shard written in place, then pushed
+        S = (n_frames + n_ctx - 1) // n_ctx
+        if n_frames == n_ctx * S:                           # (slr_reconstruct_mf_multi's shares are cyclic counts: equal shards only)
+            xa = [torch.full((n_frames, 64, 320, 3), 7.0, dtype=torch.float32, device="cuda") for _ in range(n_ctx)]
+            ha = [torch.full((n_frames, 64, 320), 9, dtype=torch.uint8, device="cuda") for _ in range(n_ctx)]
+            slr.capi.reconstruct_mf_multi(ctxs, stacks, BLACK, True, gather_ctx=-1, xyz=[xa[k][k * S:(k + 1) * S] for k in range(n_ctx)],
+                                          has=[ha[k][k * S:(k + 1) * S] for k in range(n_ctx)])
+            for k in range(n_ctx):                           # nothing but the own shard is written before the exchange
+                others = [f for f in range(n_frames) if not k * S <= f < (k + 1) * S]
+                assert all(bool((ha[k][f] == 9).all()) for f in others)
+            assert slr.capi.allgather_clouds(ctxs, xa, ha, assignment=slr.capi.ASSIGN_BLOCKED, require_peer=True) == 1
+            for k in range(n_ctx):
+                assert torch.equal(ha[k], eh) and torch.equal(xa[k], ex), k
+        # cyclic through the _ex entry == the round-2 entry
+        cyc = [frames[k::n_ctx].contiguous() for k in range(n_ctx)]
+        xc, hc, _ = slr.capi.reconstruct_mf_allgather(ctxs, cyc, BLACK, True, assignment=slr.capi.ASSIGN_CYCLIC)
+        xo, ho, _ = slr.capi.reconstruct_mf_allgather(ctxs, cyc, BLACK, True)
+        for k in range(n_ctx):
+            assert torch.equal(hc[k], eh) and torch.equal(xc[k], ex) and torch.equal(ho[k], eh) and torch.equal(xo[k], ex)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_allgather_ex_refuses_a_bad_assignment(slr, synth):
+    ctxs, stacks, _ = _blocked_job(slr, synth, 2, 4)
+    try:
+        with pytest.raises(slr.capi.SlrError) as e:
+            slr.capi.reconstruct_mf_allgather(ctxs, stacks, BLACK, True, assignment=2)
+        assert e.value.status == slr.capi.ERR_INVALID_ARG and "assignment" in str(e.value)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def _bench_line(cmd, env, timeout=900):
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, (json.loads(lines[-1]) if r.returncode == 0 and lines else None)
+
+
+def test_bench_started_bare_spawns_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher (the way the driver starts --gpus 1): the script re-executes itself under
+    torch.distributed.run, one rank per "GPU" (both on device 0 here), and prints the one line.  RCCL first; gloo only on RCCL's
+    two-ranks-on-one-device refusal."""
+    env = dict(os.environ, SLR_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for backend in ("nccl", "gloo"):
+        env["SLR_BENCH_BACKEND"] = backend
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "2", "--width", "1024",
+               "--height", "512", "--traffic", "off", "--cpu-baseline", "0"]
+        r, d = _bench_line(cmd, env)
+        if d is not None:
+            assert d["n_gpus"] == 2 and d["collective_backend"] == backend and d["collective_ranks"] == 2
+            assert d["gather_proof"]["all_ranks_ok"] and d["gather_proof"]["frames_verified_on_every_rank"] == 4
+            assert d["final_allgather_ms"] > 0 and d["hbm_footprint_per_gpu"]["sum_of_parts"] > 0
+            assert d["realistic_maps"] == [] and d["cpu_baseline"] is None and d["host_buffers_pcie_inclusive"] is None   # N > 1: no extras
+            print("bare --gpus 2 ran over %s" % backend)
+            return
+        if backend == "nccl":
+            text = r.stderr + r.stdout
+            assert any(k in text for k in ("Duplicate GPU", "duplicate GPU", "ncclInvalidUsage", "invalid usage")), \
+                "RCCL failed for a reason other than two ranks on one device:\n" + text[-1500:]
+            continue
+        pytest.fail("bare bench.py --gpus 2 failed over gloo: rc %d\n%s" % (r.returncode, r.stderr[-1500:]))
+
+
+def test_bench_bare_refuses_more_ranks_than_gpus_without_the_dry_run_switch():
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU box runs this for real")
+    env = {k: v for k, v in os.environ.items() if k not in ("SLR_BENCH_ONE_DEVICE", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "this box has" in r.stderr and '{"metric"' not in r.stdout
+
+
+@pytest.mark.parametrize("gather", ["after", "final"])
+def test_bench_one_process_three_contexts(gather):
+    """--impl one-process: what a C++ host calls -- N contexts from one process, slr_reconstruct_mf_multi in place + ONE
+    slr_allgather_clouds (or slr_reconstruct_mf_allgather_ex inside the timed region), the same line with collective_backend "peer" """
+    env = dict(os.environ, SLR_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--impl", "one-process", "--gpus", "3", "--steps", "2", "--warmup", "1", "--frames", "3",
+           "--width", "1024", "--height", "512", "--gather", gather, "--passes", "2"]
+    r, d = _bench_line(cmd, env)
+    assert d is not None, "rc %d\n%s" % (r.returncode, r.stderr[-2000:])
+    assert d["n_gpus"] == 3 and d["collective_backend"] == "peer" and d["collective_ranks"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["impl"] == "one-process" and d["config"]["distinct_frames"] == 3 and d["value"] > 0
+    assert d["gather_proof"]["all_ranks_ok"] and d["gather_proof"]["frames_verified_on_every_rank"] == 9
+    assert d["gather_proof"]["slr_verify_assembled_mismatches"] == 0
+    assert (d["final_allgather_ms"] > 0) == (gather == "after") and d["gather_inclusive_value"] is not None
+    assert d["roofline"]["kernel"] in ("slr_mf_rectify_decode_pair", "slr_mf_match_triangulate")
+    assert d["hbm_footprint_per_gpu"]["assembled_xyz_and_mask"] == 9 * 1024 * 512 * 13
