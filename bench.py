@@ -158,6 +158,8 @@ def parse_args():
     ap.add_argument("--eval-model", choices=["strict", "x87"], default="strict",
                     help="SLR_OPT_EVAL_MODEL: strict IEEE (the default) or the reference's own MSVC2010 x87 / fp:precise evaluation "
                          "(same kernels, x87 heterodyne tail / match predicate / disparity; DESIGN.md section 2)")
+    ap.add_argument("--both-models", type=int, default=1,
+                    help="1: after the timed region, a short leg of the same steps under the OTHER evaluation model; the line's `models` carries both")
     ap.add_argument("--self-check", type=int, default=1,
                     help="after the timed region: the batch output of every distinct frame against the single-frame entry (checksums)")
     ap.add_argument("--host-io", type=int, default=1,
@@ -334,9 +336,12 @@ def live_traffic(args, kernel_name, fpl=1.0):
 
 
 def copy_ceiling(torch, dev, ctx):
-    """The box's streaming rate as MI355X_MICROARCH.md measures it: a float4 non-temporal copy kernel over 1 GiB
-    (slr_stream_copy on the ctx stream, settled clocks), read + written bytes / time.  Returns (GB/s of the copy kernel, GB/s of
-    torch's copy_ for the record: a library memcpy is not a ceiling)."""
+    """The box's streaming rates as MI355X_MICROARCH.md measures them: float4 non-temporal kernels, ONE 16-byte word per
+    thread (the launch shape profiles/exp/r05/bw.txt found fastest), settled clocks, read + written bytes / time:
+      copy      slr_stream_copy over 1 GiB (1 : 1);
+      read mix  slr_stream_mix with the fused MF decode's 20 : 4 read : write ratio (5 words read from 5 streams per word written,
+                256 MiB out / 1.25 GiB in) -- the ceiling a kernel with the decode's traffic shape has on this box.
+    Returns (copy GB/s, read-mix GB/s, GB/s of torch's copy_ for the record: a library memcpy is not a ceiling)."""
     n = 1 << 30
     a = torch.zeros(n, dtype=torch.uint8, device=dev)
     b = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -354,7 +359,22 @@ def copy_ceiling(torch, dev, ctx):
         b.copy_(a)
     e1.record()
     e1.synchronize()
-    return kern, 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    memcpy = 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    mix = None
+    try:
+        m = 1 << 28
+        src = torch.zeros(5 * m + 0, dtype=torch.uint8, device=dev)
+        dst = b[:m]
+        torch.cuda.synchronize()
+        for _ in range(20):
+            ctx.stream_mix(dst, src, 5)
+        ctx.timer_begin()
+        for _ in range(10):
+            ctx.stream_mix(dst, src, 5)
+        mix = 6.0 * m * 10 / (ctx.timer_end() * 1e-3) / 1e9
+    except Exception:                                        # never break the bench line
+        mix = None
+    return kern, mix, memcpy
 
 
 def host_io_rate(np, torch, ctx, stack, W, H, rectify, slr_mod, calib_obj):
@@ -927,6 +947,7 @@ def main():
         del rendered
     torch.cuda.synchronize()
 
+    npix_ = float(W) * H
     nbuf = 2 if S == 1 else S
     oh, ow = (scan_h, scan_w) if mode == "gray" else (H, W)
     do_gather = world > 1 and args.gather == "step"
@@ -1115,6 +1136,67 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # BOTH evaluation models in the one line (strict IEEE is the default, x87 is the model more likely to be the
+    # reference's shipped Windows binary): the model of the timed region from the timed region itself, the other one from a short
+    # leg of the same steps right here (same frames, same buffers, clocks still up), each with the single-frame entry's settled time
+    models = None
+    if mode == "mf" and world == 1 and rank == 0 and S == 1 and not args.pmc_child and args.both_models:
+        models = {}
+        timed_flag = 1 if args.eval_model == "x87" else 0
+        for name_, flag in (("strict", 0), ("x87", 1)):
+            try:
+                ctx.set_option(slr.capi.OPT_EVAL_MODEL, flag)
+                n_leg = args.steps if flag == timed_flag else max(3, min(args.steps, 8))
+                for i in range(2):
+                    step(i)
+                ctx.set_option(slr.capi.OPT_PROFILE_STRIDE, max(1, args.profile_stride))
+                ctx.profile_enable(True); ctx.profile_reset()
+                sync_all()
+                tl = time.perf_counter()
+                for i in range(n_leg):
+                    step(i)
+                sync_all()
+                leg = time.perf_counter() - tl
+                pr = ctx.profile()
+                ctx.profile_enable(False)
+                b = (n_leg - 1) % nbuf
+                wb = ctx.cloud_checksums(xyz[b][:F], has[b][:F])
+                x1 = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+                h1 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+                ws = []
+                for f in range(F):
+                    ctx.reconstruct_mf(stack[f, 0], stack[f, 1], BLACK_THR, rectify, W=W, xyz=x1, has=h1)
+                    ws.append(int(ctx.cloud_checksums(x1[None], h1[None])[0]))
+                for _ in range(24):
+                    ctx.reconstruct_mf(stack[0, 0], stack[0, 1], BLACK_THR, rectify, W=W, xyz=x1, has=h1)
+                ctx.timer_begin()
+                for _ in range(8):
+                    ctx.reconstruct_mf(stack[0, 0], stack[0, 1], BLACK_THR, rectify, W=W, xyz=x1, has=h1)
+                single_us = ctx.timer_end() * 1e3 / 8
+                del x1, h1
+                ent = {"value": round(npix_ * F * PASSES * n_leg / leg / 1e6, 2), "ms_per_frame": round(leg / n_leg / (F * PASSES) * 1e3, 4),
+                       "steps": n_leg, "single_frame_call_settled_us": round(single_us, 1),
+                       "batch_equals_single_frame_calls": all(int(wb[f]) == ws[f] for f in range(F)),
+                       "cloud_word_frame0": "%016x" % (int(wb[0]) & 0xFFFFFFFFFFFFFFFF)}
+                for kn, short in (("slr_mf_rectify_decode_pair", "decode_us_per_frame"), ("slr_mf_match_triangulate", "match_us_per_frame")):
+                    if kn in pr and pr[kn][1]:
+                        ent[short] = round(pr[kn][0] / pr[kn][1] * 1e3, 2)
+                if flag == timed_flag:
+                    ent["timed_region"] = {"value": round(npix_ * F * PASSES * args.steps / elapsed / 1e6, 2),
+                                           "ms_per_frame": round(elapsed / args.steps / (F * PASSES) * 1e3, 4)}
+                models[name_] = ent
+            except Exception as e:                          # never break the bench line
+                models[name_] = {"error": repr(e)}
+        try:
+            ctx.set_option(slr.capi.OPT_EVAL_MODEL, timed_flag)
+        except Exception:
+            pass
+        if all("cloud_word_frame0" in m for m in models.values()):
+            models["clouds_differ_between_models"] = models["strict"]["cloud_word_frame0"] != models["x87"]["cloud_word_frame0"]
+        models["note"] = ("`value` / `ms_per_step` of this line are the timed region under --eval-model %s; the other model ran the same steps "
+                          "right after it (fewer of them).  A host that must match the reference's shipped MSVC2010 x87 binary sets "
+                          "SLR_OPT_EVAL_MODEL = 1 (slr.h)" % args.eval_model)
+
     if args.pmc_child:
         for c_ in ctxs:
             c_.close()
@@ -1257,13 +1339,18 @@ def main():
     ceiling = hostio = None
     if rank == 0:
         try:
-            ceiling, memcpy_rate = copy_ceiling(torch, dev, ctx)
+            ceiling, mix_rate, memcpy_rate = copy_ceiling(torch, dev, ctx)
         except Exception as e:                              # never break the bench line
-            ceiling, memcpy_rate = None, repr(e)
+            ceiling, mix_rate, memcpy_rate = None, None, repr(e)
         if roofline and roofline.get("achieved") and ceiling:
-            roofline["stream_copy_this_box"] = round(ceiling, 1)    # float4 non-temporal copy kernel, 1 GiB (the guide's 6.29 TB/s figure)
+            roofline["stream_copy_this_box"] = round(ceiling, 1)    # float4 non-temporal copy kernel, one word per thread, 1 GiB (the guide's 6.29 TB/s figure)
             roofline["frac_of_stream_copy_this_box"] = round(roofline["achieved"] / ceiling, 4)
+            if mix_rate:                                    # the same kernel with the decode's 20 : 4 read : write mix
+                roofline["read_mix_20_4_this_box"] = round(mix_rate, 1)
+                roofline["frac_of_read_mix_this_box"] = round(roofline["achieved"] / mix_rate, 4)
             roofline["library_memcpy_this_box"] = round(memcpy_rate, 1) if isinstance(memcpy_rate, float) else memcpy_rate
+            roofline["what_bounds_it"] = ("co-limited, not at the copy rate: VALU 73-76 % busy (~127 lane-instructions per camera pixel) beside a "
+                                          "fetch side that would take ~0.9 of the kernel's time at the read-mix rate; see DESIGN.md section 4")
         if world == 1 and args.host_io and mode == "mf":
             hostio = host_io_rate(np, torch, ctx, stack, W, H, rectify, slr, calib)
 
@@ -1312,7 +1399,7 @@ def main():
             "gather_proof": gather_proof,
             "final_allgather_bytes_per_rank_out": None if gather_ms is None else int(world * F * oh * ow * 13),
             "stream_event_ms_per_step": round(ev_ms / args.steps, 4) if ev_ms == ev_ms else None,
-            "eval_model": args.eval_model, "self_check": self_check, "first_call_after_idle": first_call,
+            "eval_model": args.eval_model, "models": models, "self_check": self_check, "first_call_after_idle": first_call,
             # what ONE GPU holds for the job (every rank holds the same shapes); config 4 at N = 8: 2.75 GB of input, the assembled
             # cloud of all 64 frames (10.2 GB) once per output buffer
             "hbm_footprint_per_gpu": hbm_footprint(torch, dev, {

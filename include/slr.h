@@ -127,7 +127,8 @@ const char  *slr_last_error(const slr_ctx *ctx);
 /* SLR_OPT_RECT_DMA_SHAPE: destination tile / workgroup size of form 7: 0 = 256x16 / 512 threads, 1 = 256x8 / 512, 2 = 256x8 / 256,
  * 3 = 128x16 / 512 (default), 4 = 128x8 / 256, 5 = 256x4 / 256, 6 = 128x16 / 256 (identical results; the tile tables of the installed maps
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
- * the decode, 1 (double buffer) or 2 (triple buffer, the default). */
+ * the decode, 1 (double buffer) or 2 (triple buffer, the default).  Under SLR_OPT_EVAL_MODEL = 1 the multi-frequency decode exists at
+ * distance 2 only: the option is ignored there and slr_get_rectify_info reports the effective value (2). */
 /* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2, 5, 6, 7
  * -- are compiled into the library with `make FORMS=all` only; a default build answers SLR_ERR_UNSUPPORTED to these values. */
 #define SLR_OPT_RECT_DMA_SHAPE 6
@@ -187,7 +188,10 @@ const char  *slr_last_error(const slr_ctx *ctx);
  *       (tests/test_gpu_timed_path.py).  GRAY_ONLY (slr_ray_triangulate / slr_reconstruct_gray / slr_line_line_intersections):
  *       normalize, pixelToImageSpace and line_lineIntersection (utilities.cpp:19-28, 47-56, 399-425) keep their 53-bit
  *       intermediates under mode 1 as well (the unit-ray tables are rebuilt when the mode changes); GRAY_EPI is integer work up to
- *       the f64 Q reprojection and is the same under both. */
+ *       the f64 Q reprojection and is the same under both.
+ *   WHICH TO SET: a host that replaces the loop inside the reference's own Windows build (Duke.pro: MSVC2010, 32-bit, x87) and must
+ *   reproduce that binary's clouds sets 1; a host built for x64 / SSE2 (any 64-bit MSVC, gcc or clang build of the same sources,
+ *   where float expressions round per operation) sets 0, the default.  bench.py's line carries both (`models`). */
 #define SLR_OPT_EVAL_MODEL 14
 int          slr_set_option(slr_ctx *ctx, int option, int value);
 
@@ -483,9 +487,13 @@ int slr_host_free(void *ptr);
 /* ---- measurement hooks (bench.py): HIP-event timing on the ctx stream ------------------------------ */
 int slr_timer_begin(slr_ctx *ctx);                 /* records an event on the ctx stream */
 int slr_timer_end(slr_ctx *ctx, float *ms);        /* records + synchronises, returns elapsed ms */
-/* the box's streaming rate as MI355X_MICROARCH.md measures it: a float4 non-temporal copy of `bytes` (a multiple of 16; both
+/* the box's streaming rate as MI355X_MICROARCH.md measures it: a float4 non-temporal copy (one word per thread) of `bytes` (a multiple of 16; both
  * device pointers 16-byte aligned) on the ctx stream, asynchronous -- bracket it with slr_timer_begin / _end */
 int slr_stream_copy(slr_ctx *ctx, void *dst, const void *src, size_t bytes);
+/* ... and with a kernel's read : write mix: every 16-byte word of dst is the sum of `reads` (1..8) words read from `reads`
+ * consecutive streams of bytes_out bytes each (src holds reads * bytes_out bytes); reads = 5 is the fused MF decode's 20 bytes read
+ * per 4 written.  Same conditions as slr_stream_copy (one 16-byte word per thread, non-temporal; bench.py's read-mix ceiling). */
+int slr_stream_mix(slr_ctx *ctx, void *dst, const void *src, size_t bytes_out, int reads);
 /* per-kernel profiler: when enabled every kernel launch is bracketed by two HIP events on the ctx stream */
 int          slr_profile_enable(slr_ctx *ctx, int on);
 int          slr_profile_reset(slr_ctx *ctx);

@@ -49,7 +49,7 @@ SYMBOLS = [
     "slr_reconstruct_mf", "slr_reconstruct_ge", "slr_reconstruct_gray", "slr_reconstruct_mf_batch", "slr_reconstruct_batch", "slr_reconstruct_mf_cloud", "slr_reconstruct_mf_multi", "slr_reconstruct_mf_allgather", "slr_reconstruct_mf_allgather_ex", "slr_allgather_clouds", "slr_hybrid_rectify_decode_pair", "slr_reconstruct_hybrid_batch",
     "slr_prefix_index", "slr_compact_points", "slr_cloud_checksums", "slr_verify_assembled",
     "slr_host_alloc", "slr_host_free",
-    "slr_timer_begin", "slr_timer_end", "slr_stream_copy", "slr_profile_enable", "slr_profile_reset",
+    "slr_timer_begin", "slr_timer_end", "slr_stream_copy", "slr_stream_mix", "slr_profile_enable", "slr_profile_reset",
     "slr_profile_kernel_count", "slr_profile_kernel_name", "slr_profile_get",
 ]
 
@@ -678,6 +678,13 @@ class Context:
         assert dst.numel() * dst.element_size() == nbytes
         self._mem([dst, src])
         self._chk(self.lib.slr_stream_copy(self.h, _ptr(dst), _ptr(src), C.c_size_t(nbytes)))
+
+    def stream_mix(self, dst, src, reads):
+        """the copy kernel with a read : write mix: src holds `reads` streams of dst's size, every 16-byte word of dst = their sum"""
+        nbytes = dst.numel() * dst.element_size()
+        assert src.numel() * src.element_size() == reads * nbytes
+        self._mem([dst, src])
+        self._chk(self.lib.slr_stream_mix(self.h, _ptr(dst), _ptr(src), C.c_size_t(nbytes), C.c_int(reads)))
 
     def timer_begin(self):
         self._chk(self.lib.slr_timer_begin(self.h))

@@ -158,25 +158,63 @@ hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_fr
 
 // ------------------------------------------------------------------------------------------------------
 // The box's streaming rate, measured the way MI355X_MICROARCH.md quotes it ("float4 copy": 6.29 TB/s): 16 bytes per lane,
-// non-temporal both ways, a grid of a few workgroups per CU striding over the buffer.  bench.py reports the decode's rate against
-// this figure next to the 8 TB/s peak (a library memcpy is NOT a ceiling: torch's copy_ ran at 5.1 TB/s where the fused decode's
-// own unfused form streams 5.5).
+// non-temporal both ways, ONE float4 per thread (round 6: the launch shape profiles/exp/r05/bw.txt found fastest on this part --
+// 6.6 TB/s where a 2048-workgroup grid-stride loop copies at 5.2-5.5) -- and the same with the fused decode's read : write mix
+// (stream_mix_kernel: `reads` 16-byte words read from `reads` streams per 16-byte word written; reads = 5 is the MF decode's
+// 20 : 4 bytes per camera pixel).  bench.py reports the decode's rate against both figures next to the 8 TB/s peak (a library
+// memcpy is NOT a ceiling: torch's copy_ ran at 5.1 TB/s where the fused decode's own unfused form streams 5.5).
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n16)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4_t *__restrict__ s4, f32x4_t *__restrict__ d4, size_t n16)
 {
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    const f32x4_t *s4 = reinterpret_cast<const f32x4_t *>(src);
-    f32x4_t *d4 = reinterpret_cast<f32x4_t *>(dst);
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u)
-        __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) __builtin_nontemporal_store(__builtin_nontemporal_load(s4 + i), d4 + i);
+}
+
+template <int READS>
+__global__ __launch_bounds__(256) void stream_mix_kernel(const f32x4_t *__restrict__ s4, f32x4_t *__restrict__ d4, size_t n16)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n16) return;
+    f32x4_t v[READS];
+#pragma unroll
+    for (int r = 0; r < READS; r++) v[r] = __builtin_nontemporal_load(s4 + (size_t)r * n16 + i);     // all loads in flight, then the sum
+    f32x4_t a = v[0];
+#pragma unroll
+    for (int r = 1; r < READS; r++) a += v[r];
+    __builtin_nontemporal_store(a, d4 + i);
 }
 
 hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes, hipStream_t s)
 {
     const size_t n16 = bytes / 16;
-    const size_t want = (n16 + 255) / 256;
-    const unsigned grid = (unsigned)(want < 256u * 8u ? (want ? want : 1) : 256u * 8u);      // 8 workgroups of 4 waves per CU
-    SLR_LAUNCH(stream_copy_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(dst), n16);
+    const size_t grid = (n16 + 255) / 256;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    SLR_LAUNCH(stream_copy_kernel, dim3((unsigned)grid), dim3(256), 0, s, reinterpret_cast<const f32x4_t *>(src), reinterpret_cast<f32x4_t *>(dst), n16);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_mix(const void *src, void *dst, size_t bytes_out, int reads, hipStream_t s)
+{
+    const size_t n16 = bytes_out / 16;
+    const size_t grid = (n16 + 255) / 256;
+    if (grid == 0) return hipSuccess;
+    if (grid > 0x7fffffffu) return hipErrorInvalidValue;
+    const f32x4_t *s4 = reinterpret_cast<const f32x4_t *>(src);
+    f32x4_t *d4 = reinterpret_cast<f32x4_t *>(dst);
+    switch (reads) {
+        case 1: SLR_LAUNCH(stream_mix_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 2: SLR_LAUNCH(stream_mix_kernel<2>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 3: SLR_LAUNCH(stream_mix_kernel<3>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 4: SLR_LAUNCH(stream_mix_kernel<4>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 5: SLR_LAUNCH(stream_mix_kernel<5>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 6: SLR_LAUNCH(stream_mix_kernel<6>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 7: SLR_LAUNCH(stream_mix_kernel<7>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        case 8: SLR_LAUNCH(stream_mix_kernel<8>, dim3((unsigned)grid), dim3(256), 0, s, s4, d4, n16); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

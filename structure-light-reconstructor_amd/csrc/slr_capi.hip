@@ -745,7 +745,8 @@ int slr_get_rectify_info(slr_ctx *c, int cam, slr_rectify_info *out)
     // (SLR_OPT_EVAL_MODEL = 1 has the LDS-DMA form and the per-pixel gather only: round 1's register-staged forms 2..6 are strict-model kernels)
     out->mf_form = dma ? 7 : c->opt_rect_algo == 7 ? -1 : c->debug.eval_x87 ? 1
                  : (c->opt_rect_algo != 0 ? c->opt_rect_algo : mf_rect_algo(c, cam, cam));
-    out->dma_shape = c->opt_dma_shape; out->dma_depth = c->opt_dma_depth;
+    out->dma_shape = c->opt_dma_shape;
+    out->dma_depth = c->debug.eval_x87 ? 2 : c->opt_dma_depth;   // (the x87 form of the MF decode exists at the default distance only)
     if (c->d_dma_tiles[cam] && c->dma_shape_built[cam] == c->opt_dma_shape) {
         const unsigned *st = c->dma_stats[cam];
         out->dma_tiles = (unsigned)dma_tile_count_of(c->map_w, c->map_h, c->opt_dma_shape);
@@ -2188,6 +2189,16 @@ int slr_stream_copy(slr_ctx *c, void *dst, const void *src, size_t bytes)
     if (bytes % 16 != 0 || (uintptr_t)dst % 16 != 0 || (uintptr_t)src % 16 != 0) return fail(c, SLR_ERR_INVALID_ARG, "slr_stream_copy: 16-byte granularity");
     SLR_TRY(use_device(c));
     SLR_HIP(c, launch_stream_copy(src, dst, bytes, c->stream));
+    return SLR_OK;
+}
+
+int slr_stream_mix(slr_ctx *c, void *dst, const void *src, size_t bytes_out, int reads)
+{
+    if (!c || !dst || !src) return fail(c, SLR_ERR_INVALID_ARG, "null argument");
+    if (reads < 1 || reads > 8) return fail(c, SLR_ERR_INVALID_ARG, "slr_stream_mix: reads must be 1..8");
+    if (bytes_out % 16 != 0 || (uintptr_t)dst % 16 != 0 || (uintptr_t)src % 16 != 0) return fail(c, SLR_ERR_INVALID_ARG, "slr_stream_mix: 16-byte granularity");
+    SLR_TRY(use_device(c));
+    SLR_HIP(c, launch_stream_mix(src, dst, bytes_out, reads, c->stream));
     return SLR_OK;
 }
 

@@ -187,6 +187,8 @@ hipError_t launch_mfn_decode(const uint16_t *const *planes, int n_freq, int n_st
                              float *phase, uint8_t *valid, hipStream_t s);
 hipError_t launch_cloud_checksums(const float *xyz, const uint8_t *has, int n_frames, size_t n_px, unsigned long long *d_out, hipStream_t s);
 hipError_t launch_stream_copy(const void *src, void *dst, size_t bytes /* multiple of 16, both 16-byte aligned */, hipStream_t s);
+// `reads` (1..8) consecutive streams of bytes_out bytes each read from src per bytes_out written to dst (the fused decode's read : write mix)
+hipError_t launch_stream_mix(const void *src, void *dst, size_t bytes_out, int reads, hipStream_t s);
 hipError_t launch_mfn_rect_decode(const uint16_t *const *planes, int n_freq, int n_step, int pitch, int W, int H, float black_thr,
                                   const int16_t *map_xy, const uint16_t *map_frac, int row0, int rows, int src_row0, int src_rows,
                                   float *phase, uint8_t *valid, hipStream_t s);
