@@ -137,7 +137,7 @@ def parse_args():
                          "(profiles/exp/r04/ramp.py: 225-250 us per frame in the first batches, 190 after 40): with the driver's --warmup 5 a "
                          "step of ONE batch starts the timed region 8 ms into that ramp")
     ap.add_argument("--decode-group", type=int, default=0, help="SLR_OPT_MF_BATCH_DECODE_GROUP (0 = the library's default, 8; 1 = one fused-decode launch per frame)")
-    ap.add_argument("--match-algo", type=int, default=0, help="SLR_OPT_MF_MATCH_ALGO (tuning: 0 auto, 4 lean K4 with per-thread stores, 5 / 6 512 x 8 shapes, 7 persistent grouped K4: FORMS=all builds)")
+    ap.add_argument("--match-algo", type=int, default=0, help="SLR_OPT_MF_MATCH_ALGO (tuning: 0 auto, 4 lean K4 with per-thread stores, 5 / 6 512 x 8 shapes, 7 persistent grouped K4: FORMS=all builds, 8 lean K4 with the hash dedup = round 5's kernel)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
     ap.add_argument("--debug-flags", type=int, default=0,
@@ -285,7 +285,7 @@ def frames_per_launch(args, mode, rectify, F, kernel_name):
         return 1.0
     g = min(args.match_group or 8, F)
     groups = [g] * (F // g) + ([F % g] if F % g else [])
-    if kernel_name == "slr_mf_match_triangulate" and g >= 2 and args.match_algo in (0, 4):
+    if kernel_name == "slr_mf_match_triangulate" and g >= 2 and args.match_algo in (0, 4, 8):
         return F / float(len(groups))
     dg = args.decode_group or 8
     if kernel_name == "slr_mf_rectify_decode_pair" and g >= 2 and dg >= 2 and rectify and args.rect_algo in (0, 7):

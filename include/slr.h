@@ -93,8 +93,11 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * shapes for rows of 2049..4096 pixels (0 picks 1024 threads x 4 pixels with the row's XYZ stored through LDS; 4 = the same
  * with per-thread stores, round 2; 5 / 6 = 512 threads x 8 pixels with two / three rows per CU: measured, not faster, `make FORMS=all` builds only)
  * and behave as 0 where the lean variant does not apply; 7 = the grouped launches of slr_reconstruct_mf_batch as a persistent kernel
- * with the next row's phases prefetched (round 5: measured slower, 105 against 77 us per frame; `make FORMS=all` builds only).  All give
- * identical results. */
+ * with the next row's phases prefetched (round 5: measured slower, 105 against 77 us per frame; `make FORMS=all` builds only); 8 = 0's
+ * lean kernel by name (its index dedups equal right phases through an LDS hash table); 9 = the same index WITHOUT the dedup, rows with
+ * an overfull bin rebuilt with it inside the kernel (round 6: measured slower on the reference's phases, 90 against 81 us -- its
+ * integer-quotient atan leaves ~1500 distinct values in a row of 4064 valid pixels; `make FORMS=all` builds only).  All give identical
+ * results. */
 #define SLR_OPT_MF_MATCH_ALGO 1
 /* SLR_OPT_MF_DECODE_VEC: pixels per thread of the unfused K2 kernel: 0 = auto, 4, 8 or 16 (identical results) */
 #define SLR_OPT_MF_DECODE_VEC 2
@@ -129,7 +132,7 @@ const char  *slr_last_error(const slr_ctx *ctx);
  * are rebuilt).  SLR_OPT_RECT_DMA_DEPTH: phases of LDS-DMA in flight ahead of
  * the decode, 1 (double buffer) or 2 (triple buffer, the default).  Under SLR_OPT_EVAL_MODEL = 1 the multi-frequency decode exists at
  * distance 2 only: the option is ignored there and slr_get_rectify_info reports the effective value (2). */
-/* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2, 5, 6, 7
+/* Forms that lost their measurements -- SLR_OPT_RECT_DECODE_ALGO 2, 3, 4, SLR_OPT_RECT_DMA_SHAPE 2, 4, 5, 6, SLR_OPT_MF_MATCH_ALGO 2, 5, 6, 7, 9
  * -- are compiled into the library with `make FORMS=all` only; a default build answers SLR_ERR_UNSUPPORTED to these values. */
 #define SLR_OPT_RECT_DMA_SHAPE 6
 #define SLR_OPT_RECT_DMA_DEPTH 7

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libslr_hip.so")
 MF_PLANES = 14
 MAX_GRAY_BITS = 16
 MEM_HOST, MEM_DEVICE = 0, 1
-OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort), 4/5/6 lean shapes (1024x4, 512x8 two rows per CU, 512x8 three rows per CU), 7 persistent grouped K4 (FORMS=all builds only)
+OPT_MF_MATCH_ALGO = 1          # 0 auto, 1 linear sweep, 2 indexed (radix-sorted distinct phases), 3 indexed (counting sort), 4/5/6 lean shapes (1024x4, 512x8 two rows per CU, 512x8 three rows per CU), 7 persistent grouped K4 (FORMS=all builds only), 8 = the lean kernel auto picks, 9 = its index without the hash dedup (FORMS=all builds only)
 OPT_RECT_DECODE_ALGO = 3       # fused rectify+decode: 0 auto (5, else 6), 1 direct gather, 2 LDS tiles 64x16, 3 sliding LDS
                                # window down tile columns, 4 tiles 128x8 / 256 threads, 5 tiles 128x8 / 512 threads,
                                # 6 tiles 64x8 / 256 threads

@@ -495,7 +495,14 @@ struct K4Lean {
 // evaluates differently -- the predicate sees the EXACT difference of the two phases (f64: the difference of two floats of this
 // range is exact in 53 bits) and the disparity reaches the double unrounded.  The index is the same: its bins only have to
 // hold every pair closer than 0.1 + rounding, which a 0.25-wide bin and its neighbours do under either predicate.
-template <int BLOCK, bool HAS_T, bool XCHG = false, bool TAME = false, bool X87 = false>
+// NOHASH (round 6): the index WITHOUT the hash dedup.  The dedup never changes a result -- the query takes the smallest matching column
+// whatever else is in its window -- it only bounds the bins of rows with many equal phases.  So every valid right pixel (minus an
+// in-thread left neighbour of the same value) goes straight into the counting sort: no 64 KB table to clear, no CAS / atomicMin probes
+// (the random-slot LDS traffic behind the kernel's bank conflicts), two barriers fewer per row.  A row in which some bin ends up with
+// more than kHeavyBin entries (flat or saturated regions) is rebuilt with the hash dedup in the same workgroup: bit-equal either way.
+// MEASURED SLOWER on the reference's own phases (see the launch site): SLR_OPT_MF_MATCH_ALGO = 9 in FORMS=all builds only.
+constexpr unsigned kHeavyBin = 32;
+template <int BLOCK, bool HAS_T, bool XCHG = false, bool TAME = false, bool X87 = false, bool NOHASH = false>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                               const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
                                                               int W, int H, int row0, K4Lean kc, int stop,
@@ -555,20 +562,10 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         load_valid_blocked<IPT>(validL, base, k0, k0 + IPT, true, vl);
     }
     const size_t trow = (size_t)row * W;
-    {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
-        u32x4 *const t4 = reinterpret_cast<u32x4 *>(sh.t.key);   // (key and mink are adjacent: the whole table in 16-byte stores)
-#pragma unroll
-        for (int q = 0; q < 2 * TS / 4 / BLOCK; q++) t4[tid + q * BLOCK] = e4;
-    }
-    __syncthreads();
-    SLR_K4_STOP_AT(1);
-
-    // A. distinct values and their smallest column (as mf_match_binned_kernel; the four first probes are independent LDS
-    //    atomics in flight together, a collision continues in the loop)
+    unsigned *const cnt = kCntInKey ? sh.t.key : sh.c.cnt;
     unsigned slot[IPT], bits[IPT], old[IPT];             // hash slot of this pixel's value; kEmpty = not a candidate
     bool cand[IPT];
+    unsigned repmask = 0;
 #pragma unroll
     for (int i = 0; i < IPT; i++) {
         bits[i] = __float_as_uint(pr[i]);
@@ -577,55 +574,88 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 1024 ? 8 : 4)) void mf_match_lean_
         const bool dup = i > 0 && ok && vr[i - 1] && bits[i] == bits[i - 1];
         cand[i] = ok && !dup;
         slot[i] = (bits[i] * 2654435761u) >> (32 - __builtin_ctz(TS));
+        if (NOHASH && cand[i]) repmask |= 1u << i;       // without the dedup every candidate is a representative
     }
+    // A. (hash form, or a heavy row of the NOHASH form) distinct values and their smallest column, as mf_match_binned_kernel; the four
+    //    first probes are independent LDS atomics in flight together, a collision continues in the loop.  Leaves repmask and the
+    //    zeroed bin counters behind a barrier.
+    auto hash_dedup = [&]() {
+        {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 e4 = {kEmpty, kEmpty, kEmpty, kEmpty};
+            u32x4 *const t4 = reinterpret_cast<u32x4 *>(sh.t.key);   // (key and mink are adjacent: the whole table in 16-byte stores)
 #pragma unroll
-    for (int i = 0; i < IPT; i++) old[i] = cand[i] ? atomicCAS(&sh.t.key[slot[i]], kEmpty, bits[i]) : kEmpty;
-#pragma unroll
-    for (int i = 0; i < IPT; i++) {
-        if (cand[i]) {
-            unsigned h = slot[i], o = old[i];
-            while (o != kEmpty && o != bits[i]) {
-                h = (h + 1) & (TS - 1);
-                o = atomicCAS(&sh.t.key[h], kEmpty, bits[i]);
-            }
-            atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
-            slot[i] = h;
+            for (int q = 0; q < 2 * TS / 4 / BLOCK; q++) t4[tid + q * BLOCK] = e4;
         }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; i++) old[i] = cand[i] ? atomicCAS(&sh.t.key[slot[i]], kEmpty, bits[i]) : kEmpty;
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            if (cand[i]) {
+                unsigned h = slot[i], o = old[i];
+                while (o != kEmpty && o != bits[i]) {
+                    h = (h + 1) & (TS - 1);
+                    o = atomicCAS(&sh.t.key[h], kEmpty, bits[i]);
+                }
+                atomicMin(&sh.t.mink[h], (unsigned)(k0 + i));
+                slot[i] = h;
+            }
+        }
+        __syncthreads();
+        // representatives: the pixels that are their value's smallest column.  The key half of the table is dead already and
+        // becomes the bin counters (cnt[kBins + tid] = a sink for the thread's non-representatives: the atomics below are
+        // unconditional and independent, and never pile up on one address)
+        repmask = 0;
+        unsigned mk4[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) mk4[i] = sh.t.mink[slot[i]];
+#pragma unroll
+        for (int q = 0; q < kPer; q++) cnt[tid + q * BLOCK] = 0u;
+#pragma unroll
+        for (int i = 0; i < IPT; i++)
+            if (cand[i] && mk4[i] == (unsigned)(k0 + i)) repmask |= 1u << i;
+        __syncthreads();                                 // the whole table is dead from here on
+    };
+    if constexpr (NOHASH) {
+#pragma unroll
+        for (int q = 0; q < kPer; q++) cnt[tid + q * BLOCK] = 0u;
+        __syncthreads();
+        SLR_K4_STOP_AT(1);
+    } else {
+        SLR_K4_STOP_AT(1);                               // (debug-hook builds: before the table clear since round 6)
+        hash_dedup();
     }
-    __syncthreads();
-    // representatives: the pixels that are their value's smallest column.  The key half of the table is dead already and
-    // becomes the bin counters (cnt[kBins + tid] = a sink for the thread's non-representatives: the atomics below are
-    // unconditional and independent, and never pile up on one address)
-    unsigned *const cnt = kCntInKey ? sh.t.key : sh.c.cnt;
-    unsigned repmask = 0;
-    unsigned mk4[IPT];
-#pragma unroll
-    for (int i = 0; i < IPT; i++) mk4[i] = sh.t.mink[slot[i]];
-#pragma unroll
-    for (int q = 0; q < kPer; q++) cnt[tid + q * BLOCK] = 0u;
-#pragma unroll
-    for (int i = 0; i < IPT; i++)
-        if (cand[i] && mk4[i] == (unsigned)(k0 + i)) repmask |= 1u << i;
-    __syncthreads();                                     // the whole table is dead from here on
     SLR_K4_STOP_AT(2);
 
     // B. counting sort of the representatives by phase bin
     unsigned bin[IPT], rank[IPT];
-#pragma unroll
-    for (int i = 0; i < IPT; i++) bin[i] = (repmask >> i) & 1u ? (unsigned)phase_bin(pr[i]) : (unsigned)(kBins + tid);
-#pragma unroll
-    for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&cnt[bin[i]], 1u);
-    __syncthreads();
     float2 *const pk = reinterpret_cast<float2 *>(sh.b.pk2);
-    {
+#pragma unroll 1
+    for (int pass = 0;; pass++) {
+#pragma unroll
+        for (int i = 0; i < IPT; i++) bin[i] = (repmask >> i) & 1u ? (unsigned)phase_bin(pr[i]) : (unsigned)(kBins + tid);
+#pragma unroll
+        for (int i = 0; i < IPT; i++) rank[i] = atomicAdd(&cnt[bin[i]], 1u);
+        __syncthreads();
         unsigned c[kPer], sum = 0;
 #pragma unroll
-        for (int q = 0; q < kPer; q++) { c[q] = cnt[tid * kPer + q]; sum += c[q]; }
+        for (int q = 0; q < kPer; q++) {
+            c[q] = cnt[tid * kPer + q]; sum += c[q];
+            if (NOHASH && c[q] > kHeavyBin) sum += 0x10000u;          // (the row's counts stay below 2^16: the heavy-bin count rides above them)
+        }
         unsigned total;
         unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);   // (its barrier: every thread has read its counters)
+        if (NOHASH && pass == 0 && (total >> 16) != 0u) {             // workgroup-uniform: some bin is heavy -> this row takes the dedup
+            __syncthreads();
+            hash_dedup();
+            continue;
+        }
+        excl &= 0xFFFFu; total &= 0xFFFFu;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { sh.b.bs[1 + tid * kPer + q] = excl; excl += c[q]; }   // bs lies in the mink half
         if (tid == 0) { sh.b.bs[0] = 0u; sh.b.bs[kBins + 1] = total; sh.b.bs[kBins + 2] = total; }
+        break;
     }
     __syncthreads();
     {
@@ -1906,7 +1936,7 @@ hipError_t launch_undistort_tables(const DevCalib &cal, int W, int H, float *und
 bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const float *xyz, const uint8_t *has, int W, const DevCalib &cal,
                              int algo, const float *undL_xy, const float *undRx, size_t frame_px)
 {
-    return (algo == 0 || algo == 4 || algo == 7) && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
+    return (algo == 0 || algo == 4 || algo == 7 || algo == 8 || algo == 9) && undL_xy && undRx && cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 &&
            (uintptr_t)undL_xy % 16 == 0 && (uintptr_t)phaseL % 16 == 0 && (uintptr_t)phaseR % 16 == 0 && (uintptr_t)xyz % 16 == 0 &&
            (uintptr_t)has % 4 == 0 && frame_px % 4 == 0;
 }
@@ -1944,7 +1974,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                vec_ok, undL, undRx, xyz, has, match_k)
 #endif
         // the usual call (aligned rows of 513..1024 or 2049..4096 pixels, tables, stereoRectify's Q): the lean kernel
-        if ((algo == 0 || (algo >= 4 && algo <= 7)) && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
+        if ((algo == 0 || (algo >= 4 && algo <= 9)) && (vec_ok & 1) && undL && undRx && cal.q_simple && ((W > 512 && W <= 1024) || (W > 2048 && W <= 4096)) &&
             (uintptr_t)undL % 16 == 0 && ((size_t)W * sizeof(float2)) % 16 == 0) {
             K4Lean kc;
             kc.q3 = cal.Q[3]; kc.q7 = cal.Q[7]; kc.q11 = cal.Q[11]; kc.q14 = cal.Q[14]; kc.q15 = cal.Q[15];
@@ -2007,13 +2037,29 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             }
 #endif
             if (W > 2048 && algo != 4) {                     // 1024 x 4 with the row's XYZ stored through LDS (round 4)
-#define SLR_LEANX2(T_, TAME_, X_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_, X_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
+                // round 6: SLR_OPT_MF_MATCH_ALGO 9 (FORMS=all builds) = the index WITHOUT the hash dedup (heavy rows rebuilt with it inside the
+                // kernel).  Measured on the bench's frames: 90 us against 81 with the dedup -- the reference's integer-quotient atan
+                // quantises the phases so hard that a row of 4064 valid pixels holds ~1500 distinct values, some of them 100-300 times
+                // (profiles/exp/r06/k4_nohash.txt): every row is "heavy", the dedup is doing real work.  Kept for phases that are not
+                // quantised like that; never picked by auto.
+#ifdef SLR_ALL_FORMS
+                const bool nohash = algo == 9;
+#else
+                constexpr bool nohash = false;
+#endif
+#define SLR_LEANX3(T_, TAME_, X_, N_) SLR_LAUNCH((mf_match_lean_kernel<1024, T_, true, TAME_, X_, N_>), dim3(grid), dim3(1024), 0, s, phaseL, validL, phaseR, validR, \
                                       W, H, row0, kc, k4_stop, undL4, undRx, xyz, has, match_k, nframes, frame_px)
+#ifdef SLR_ALL_FORMS
+#define SLR_LEANX2(T_, TAME_, X_) do { if (nohash) SLR_LEANX3(T_, TAME_, X_, true); else SLR_LEANX3(T_, TAME_, X_, false); } while (0)
+#else
+#define SLR_LEANX2(T_, TAME_, X_) do { (void)nohash; SLR_LEANX3(T_, TAME_, X_, false); } while (0)
+#endif
 #define SLR_LEANX(T_, TAME_) do { if (x87) SLR_LEANX2(T_, TAME_, true); else SLR_LEANX2(T_, TAME_, false); } while (0)
                 if (cal.has_T) { if (q_tame) SLR_LEANX(true, true); else SLR_LEANX(true, false); }
                 else { if (q_tame) SLR_LEANX(false, true); else SLR_LEANX(false, false); }
 #undef SLR_LEANX
 #undef SLR_LEANX2
+#undef SLR_LEANX3
                 return hipGetLastError();
             }
             if (W <= 1024) SLR_LEAN(256); else SLR_LEAN(1024);

@@ -1183,7 +1183,7 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
 // else no more than one fused-decode launch serves (SLR_OPT_MF_BATCH_DECODE_GROUP, when the LDS-DMA form applies), else 1.
 static int mf_batch_group_of(const slr_ctx *c, int W, int rectify)
 {
-    const bool match_groups = (c->opt_mf_match_algo == 0 || c->opt_mf_match_algo == 4 || c->opt_mf_match_algo == 7) && c->cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0;
+    const bool match_groups = (c->opt_mf_match_algo == 0 || c->opt_mf_match_algo == 4 || c->opt_mf_match_algo == 7 || c->opt_mf_match_algo == 8 || c->opt_mf_match_algo == 9) && c->cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0;
     if (match_groups) return c->opt_mf_batch_group;
     const int dg = rectify && dma_form_wanted(c, 0, 1) ? c->opt_mf_decode_group : 1;
     return dg < c->opt_mf_batch_group ? dg : c->opt_mf_batch_group;
@@ -2053,11 +2053,12 @@ int slr_set_option(slr_ctx *c, int option, int value)
     if (!c) return SLR_ERR_INVALID_ARG;
     switch (option) {
         case SLR_OPT_MF_MATCH_ALGO:
-            if (value < 0 || value > 7) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..7");
+            if (value < 0 || value > 9) return fail(c, SLR_ERR_INVALID_ARG, "SLR_OPT_MF_MATCH_ALGO must be 0..9");
 #ifndef SLR_ALL_FORMS
             if (value == 2) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 2 (sorted form) is compiled with -DSLR_ALL_FORMS only");
             if (value == 5 || value == 6) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 5 / 6 (512 x 8 shapes) are compiled with -DSLR_ALL_FORMS only");
             if (value == 7) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 7 (persistent grouped K4) is compiled with -DSLR_ALL_FORMS only");
+            if (value == 9) return fail(c, SLR_ERR_UNSUPPORTED, "SLR_OPT_MF_MATCH_ALGO = 9 (lean K4 without the hash dedup) is compiled with -DSLR_ALL_FORMS only");
 #endif
             c->opt_mf_match_algo = value;
             return SLR_OK;

@@ -34,13 +34,53 @@ def test_k4_lean_vs_general_and_oracle(ctx, slr, oracle, synth, W, H, with_T, q)
     phL[1 % H, 9] = np.nan; phR[1 % H, 11] = np.nan
     exyz, ehas, emk = oracle.mf_triangulate(phL, vL, phR, vR, camL, camR, Q, T)
     try:
-        for algo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 3, 2, 4, 5, 6), required=(0, 3, 4)):   # lean (auto), general binned, sorted (FORMS=all), the lean shapes
+        for algo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 3, 2, 4, 5, 6, 8, 9), required=(0, 3, 4, 8)):   # lean (auto), general binned, sorted (FORMS=all), the lean shapes, 8 = lean with the hash dedup (= auto), 9 = without it (FORMS=all)
             ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
             xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
             assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz), (W, algo)
     finally:
         ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
     assert ehas.sum() > 0
+
+
+@pytest.mark.parametrize("W,with_T,x87", [(4096, False, False), (2052, True, False), (4096, True, True)])
+def test_k4_lean_index_without_the_hash_light_and_heavy_rows(ctx, slr, oracle, synth, W, with_T, x87):
+    """round 6: the lean K4's index with and without the hash dedup (SLR_OPT_MF_MATCH_ALGO 9, FORMS=all builds).  Rows whose fullest
+    0.25-wide bin holds exactly 32 / 33 / many more right pixels (the no-hash form's in-kernel switch to the dedup is at > 32),
+    duplicates that are not neighbours, duplicates across thread boundaries, an all-equal row, an empty row: every form == the
+    general binned kernel == the oracle, bit for bit"""
+    rng = np.random.default_rng(W)
+    H = 8
+    calib, _ = synth.make_calibration(max(W, 8), 8, with_T=with_T)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    base = (np.arange(W, dtype=np.float32) * np.float32(0.0625) + np.float32(3.0)).astype(np.float32)   # 4 pixels per bin: a light row
+    phR = np.tile(base, (H, 1)); phL = np.tile(base + np.float32(0.03), (H, 1))
+    # row 1: one bin with exactly 32 entries of distinct values (light), row 2: 33 (heavy), the rest spread out
+    for r, n in ((1, 32), (2, 33)):
+        phR[r] = base * np.float32(4.0)                                  # one pixel per bin ...
+        cols = rng.choice(W, n, replace=False)
+        phR[r, cols] = np.float32(700.0) + np.arange(n, dtype=np.float32) * np.float32(0.005)   # ... and n of them in the clamped top bin
+        phL[r] = phR[r][::-1].copy()
+    phR[3] = np.float32(12.5); phL[3] = np.float32(12.55)               # all equal: one value, column 0 wins everywhere
+    phR[4, :] = rng.choice(np.float32([5.0, 5.05, 5.1, 5.2, 90.0]), W)   # five values, thousands of non-adjacent duplicates
+    phL[4, :] = rng.choice(np.float32([5.0, 5.12, 5.3, 89.95, 40.0]), W)
+    phR[5, 3:-1:4] = phR[5, 4::4]                                        # equal pairs across the 4-pixel thread boundary
+    vL = np.ones((H, W), np.uint8); vR = np.ones((H, W), np.uint8)
+    vR[6] = 0                                                             # nothing to match against
+    vL[7] = (rng.random(W) < 0.5); vR[7] = (rng.random(W) < 0.5)
+    if x87:
+        ctx.set_option(slr.capi.OPT_EVAL_MODEL, 1)
+    try:
+        exyz, ehas, emk = oracle.mf_triangulate_ev(phL, vL, phR, vR, camL, camR, Q, x87, T)
+        for algo in forms(ctx, slr, slr.capi.OPT_MF_MATCH_ALGO, (0, 8, 3, 9), required=(0, 8, 3)):
+            ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, algo)
+            xyz, has, mk = ctx.mf_triangulate(phL, vL, phR, vR)
+            assert bits_equal(mk, emk) and bits_equal(has, ehas) and bits_equal(xyz, exyz), (W, algo)
+        assert ehas[3].all() and (emk[3] == 0).all() and ehas[6].sum() == 0 and ehas[1].sum() > 0 and ehas[2].sum() > 0
+    finally:
+        ctx.set_option(slr.capi.OPT_MF_MATCH_ALGO, 0)
+        ctx.set_option(slr.capi.OPT_EVAL_MODEL, 0)
 
 
 # ---------------------------------------------------------------------------------------------------------
