@@ -1403,21 +1403,24 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
                                                                    int W, int H, int row0, DevCalib cal, int vec_ok,
                                                                    const float2 *__restrict__ undL, const float *__restrict__ undRx,
                                                                    float *__restrict__ xyz,
-                                                                   uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+                                                                   uint8_t *__restrict__ has, int32_t *__restrict__ match_k,
+                                                                   const int *__restrict__ defer = nullptr /* defer[0] rows listed behind it: only those */)
 {
     constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT;
     constexpr int TS = 2 * N;
     constexpr int kPer = kBins / BLOCK;
     constexpr unsigned kEmpty = 0xFFFFFFFFu;
     constexpr unsigned kOpen = 0xFFFFu, kNever = 0xFFFEu;
+    if (defer && (int)blockIdx.x >= defer[0]) return;    // (the rows mf_match_wide_kernel left to this kernel: usually none)
+    const int brow = defer ? defer[1 + blockIdx.x] : (int)blockIdx.x;
     __shared__ union {
         struct { unsigned key[TS]; unsigned mink[TS]; } t;
         struct { float2 pk[N]; unsigned binstart[kBins + 1]; } b;
     } sh;
     __shared__ unsigned scan_tmp[BLOCK / 64];
 
-    const int row = blockIdx.x + row0, tid = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * W;
+    const int row = brow + row0, tid = threadIdx.x;
+    const size_t base = (size_t)brow * W;
     const bool vec = (vec_ok & 1) != 0;
     const int nch = (W + N - 1) / N;
 
@@ -1616,12 +1619,14 @@ __device__ __forceinline__ void k4_lean_tri4(const int best[4], bool inrun, size
     }
 }
 
+constexpr unsigned kWideHeavyBin = 96;                   // pairs in one 0.25-wide bin beyond which mf_match_wide_kernel hands the row over
 template <bool HAS_T, bool X87>
 __global__ __launch_bounds__(1024, 8) void mf_match_wide_kernel(const float *__restrict__ phaseL, const uint8_t *__restrict__ validL,
                                                                 const float *__restrict__ phaseR, const uint8_t *__restrict__ validR,
                                                                 int W, int H, int row0, K4Lean kc,
                                                                 const float4 *__restrict__ undL, const float *__restrict__ undRx,
-                                                                float *__restrict__ xyz, uint8_t *__restrict__ has, int32_t *__restrict__ match_k)
+                                                                float *__restrict__ xyz, uint8_t *__restrict__ has, int32_t *__restrict__ match_k,
+                                                                int *__restrict__ defer /* null, or [0] = count (zeroed), [1..] = rows left to the chunked kernel */)
 {
     constexpr int BLOCK = 1024, HALF = 4096, N = 2 * HALF;
     constexpr int kPer = kBins / BLOCK;
@@ -1672,9 +1677,20 @@ __global__ __launch_bounds__(1024, 8) void mf_match_wide_kernel(const float *__r
     {
         unsigned c[kPer], sum = 0;
 #pragma unroll
-        for (int q = 0; q < kPer; q++) { c[q] = sh.cnt[tid * kPer + q]; sum += c[q]; }
+        for (int q = 0; q < kPer; q++) {
+            c[q] = sh.cnt[tid * kPer + q]; sum += c[q];
+            if (c[q] > kWideHeavyBin) sum += 0x10000u;   // (a row's counts stay below 2^14: the number of overfull bins rides above them)
+        }
         unsigned total;
         unsigned excl = wg_exclusive_scan<BLOCK>(sum, 0u, [](unsigned a, unsigned b) { return a + b; }, scan_tmp, &total);   // (its barrier: every counter has been read)
+        // This index has no dedup of equal phases: a flat or saturated row would put thousands of pairs into one bin and every query
+        // of that window would scan them all -- O(W^2) per row.  Such a row is left to the chunked kernel (hash dedup,
+        // O(W)), which the host launches behind this one on the listed rows; workgroup-uniform, nothing of the row is written here.
+        if (defer && (total >> 16) != 0u) {
+            if (tid == 0) defer[1 + atomicAdd(defer, 1)] = (int)blockIdx.x;
+            return;
+        }
+        excl &= 0xFFFFu; total &= 0xFFFFu;
 #pragma unroll
         for (int q = 0; q < kPer; q++) { bs[1 + tid * kPer + q] = (unsigned short)excl; excl += c[q]; }
         if (tid == 0) { bs[0] = 0; bs[kBins + 1] = (unsigned short)total; bs[kBins + 2] = (unsigned short)total; }
@@ -1943,7 +1959,7 @@ bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const flo
 
 hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const float *phaseR, const uint8_t *validR,
                            int W, int H, int row0, const DevCalib &cal, float *xyz, uint8_t *has, int32_t *match_k,
-                           int algo, const float *undL_xy, const float *undRx, hipStream_t s, int nframes, size_t frame_px)
+                           int algo, const float *undL_xy, const float *undRx, hipStream_t s, int nframes, size_t frame_px, int *defer)
 {
     if (nframes > 1 && (validL || validR || match_k || !mf_match_batches_frames(phaseL, phaseR, xyz, has, W, cal, algo, undL_xy, undRx, frame_px)))
         return hipErrorInvalidValue;                     // (the caller asks mf_match_batches_frames first)
@@ -2084,10 +2100,14 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
             for (int i = 0; i < 12; i++) kc.T[i] = (double)cal.T[i];
             const float4 *undL4 = (const float4 *)undL_xy;
 #define SLR_WIDE(T_, X_) SLR_LAUNCH((mf_match_wide_kernel<T_, X_>), dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0, kc, undL4, undRx, \
-                                    xyz, has, match_k)
+                                    xyz, has, match_k, defer)
+            if (defer) { const hipError_t e = hipMemsetAsync(defer, 0, sizeof(int), s); if (e != hipSuccess) return e; }
             if (cal.has_T) { if (cal.eval_x87) SLR_WIDE(true, true); else SLR_WIDE(true, false); }
             else { if (cal.eval_x87) SLR_WIDE(false, true); else SLR_WIDE(false, false); }
 #undef SLR_WIDE
+            if (defer)                                   // the rows with an overfull bin (flat / saturated regions), usually none: workgroups beyond the count leave at once
+                SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
+                                   cal, vec_ok, undL, undRx, xyz, has, match_k, defer);
         }
         else                                                 // wider rows: the right row in chunks of 4096 columns
             SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,

@@ -31,7 +31,7 @@ enum Slot {
     S_PHASE_L = 16, S_VALID_L, S_PHASE_R, S_VALID_R,
     S_CODEX_L, S_CODEY_L, S_CODEX_R, S_CODEY_R,
     S_RAY_CELL, S_RAY_CELL2, S_RAY_RANK, S_RAY_CNT, S_RAY_OFFS, S_RAY_ITEMS, S_RAY_LIST, S_SCAN_TMP,
-    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R, S_RAYS_L, S_RAYS_R, S_FLAGSCAN, S_COMPACT,
+    S_XYZ, S_HAS, S_COLOR, S_UND_L, S_UND_R, S_RAYS_L, S_RAYS_R, S_FLAGSCAN, S_COMPACT, S_K4_DEFER,
     S_COUNT
 };
 
@@ -376,10 +376,12 @@ int core_mf_match(slr_ctx *c, const float *phL, const uint8_t *vL, const float *
                    mf_match_batches_frames(phL, phR, xyz, has, W, c->cal, c->opt_mf_match_algo, undL, undR, frame_px);
         if (!*batched) return SLR_OK;
     }
+    void *defer = nullptr;                                // rows of 4097..8192 pixels: the list of rows the wide kernel hands to the chunked one
+    if (W > 4096 && W <= 8192) SLR_TRY(get_scratch(c, S_K4_DEFER, sizeof(int) * ((size_t)rows + 1), &defer));
     ProfScope ps(c, K_MF_MATCH, true);
     ps.r.units = nframes;
     SLR_HIP(c, launch_mf_match(phL, vL, phR, vR, W, rows, row0, c->cal, xyz, has, match_k, c->opt_mf_match_algo, undL, undR,
-                               c->stream, nframes, frame_px));
+                               c->stream, nframes, frame_px, (int *)defer));
     return SLR_OK;
 }
 
@@ -1181,9 +1183,12 @@ static int reconstruct_mf_dev(slr_ctx *c, const uint8_t *const *pL, const uint8_
 // the default 8), so a group is only as large as it pays: SLR_OPT_MF_BATCH_GROUP frames when ONE match launch can take them (the
 // lean K4: stereoRectify's Q, rows of 2049..4096 pixels, W % 4 == 0 -- the pointer-independent part of mf_match_batches_frames),
 // else no more than one fused-decode launch serves (SLR_OPT_MF_BATCH_DECODE_GROUP, when the LDS-DMA form applies), else 1.
-static int mf_batch_group_of(const slr_ctx *c, int W, int rectify)
+static int mf_batch_group_of(const slr_ctx *c, int W, int rectify, int H = 0, const float *xyz = nullptr, const uint8_t *has = nullptr)
 {
-    const bool match_groups = (c->opt_mf_match_algo == 0 || c->opt_mf_match_algo == 4 || c->opt_mf_match_algo == 7 || c->opt_mf_match_algo == 8 || c->opt_mf_match_algo == 9) && c->cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0;
+    // (the pointer-dependent half of mf_match_batches_frames too, when the caller's outputs are known: a group whose match launch
+    //  would be refused must not cost a group's phase scratch -- 0.8 GB at the default group, kept for the context's lifetime)
+    const bool outs_ok = !xyz || ((uintptr_t)xyz % 16 == 0 && (uintptr_t)has % 4 == 0 && ((size_t)W * (size_t)H) % 4 == 0);
+    const bool match_groups = (c->opt_mf_match_algo == 0 || c->opt_mf_match_algo == 4 || c->opt_mf_match_algo == 7 || c->opt_mf_match_algo == 8 || c->opt_mf_match_algo == 9) && c->cal.q_simple && W > 2048 && W <= 4096 && W % 4 == 0 && outs_ok;
     if (match_groups) return c->opt_mf_batch_group;
     const int dg = rectify && dma_form_wanted(c, 0, 1) ? c->opt_mf_decode_group : 1;
     return dg < c->opt_mf_batch_group ? dg : c->opt_mf_batch_group;
@@ -1286,7 +1291,7 @@ int slr_reconstruct_mf_batch(slr_ctx *c, int n_frames, const uint8_t *stack, int
     // K4 reads 12 bytes of per-CALIBRATION undistortion tables per pixel (a third of its traffic): the frames of a batch are decoded
     // into a phase scratch of `group` frames and matched by ONE launch whose workgroups take a row of all those frames one after the
     // other on the same XCD -- the tables come from HBM once per group (SLR_OPT_MF_BATCH_GROUP, default 8; 1 = frame by frame)
-    const int gmax = mf_batch_group_of(c, W, rectify);
+    const int gmax = mf_batch_group_of(c, W, rectify, H, xyz, has);
     for (int f0 = 0; f0 < n_frames;) {
         const int g = n_frames - f0 < gmax ? n_frames - f0 : gmax;
         void *phL = nullptr, *phR = nullptr;
@@ -1430,7 +1435,7 @@ int slr_reconstruct_hybrid_batch(slr_ctx *c, int n_frames, const uint8_t *stack,
     void *phL, *phR, *cxs = nullptr;
     if (!code_x) SLR_TRY(get_scratch(c, S_CODEX_L, n * 8, &cxs));      // nobody wants the codes: one scratch pair for every frame
     // as slr_reconstruct_mf_batch: the phases of a group of frames, ONE match launch per group (the undistortion tables once per group)
-    const int gmax = mf_batch_group_of(c, W, 1);
+    const int gmax = mf_batch_group_of(c, W, 1, H, xyz, has);
     for (int f0 = 0; f0 < n_frames;) {
         const int g = n_frames - f0 < gmax ? n_frames - f0 : gmax;
         SLR_TRY(get_scratch(c, S_PHASE_L, (size_t)g * n * 4, &phL));

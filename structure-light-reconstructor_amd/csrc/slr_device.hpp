@@ -171,7 +171,9 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                            float *xyz, uint8_t *has, int32_t *match_k, int algo,
                            const float *undL_xy /* [H][W][2] or null */, const float *undRx /* [H][W] or null */,
                            hipStream_t s, int nframes = 1 /* > 1: that many frames, frame_px pixels apart in every array (ask
-                           mf_match_batches_frames first; no valid bytes, no match_k) */, size_t frame_px = 0);
+                           mf_match_batches_frames first; no valid bytes, no match_k) */, size_t frame_px = 0,
+                           int *defer = nullptr /* (H + 1) ints of device scratch: rows of 4097..8192 pixels whose index would hold an
+                           overfull bin are listed there by the wide kernel and matched by the chunked kernel behind it; null: no such guard */);
 bool mf_match_batches_frames(const float *phaseL, const float *phaseR, const float *xyz, const uint8_t *has, int W, const DevCalib &cal,
                              int algo, const float *undL_xy, const float *undRx, size_t frame_px);
 // per-pixel Utilities::undistortPoints tables for a (calibration, W, H): left (x,y), right x

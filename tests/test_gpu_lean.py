@@ -83,6 +83,45 @@ def test_k4_lean_index_without_the_hash_light_and_heavy_rows(ctx, slr, oracle, s
         ctx.set_option(slr.capi.OPT_EVAL_MODEL, 0)
 
 
+def test_k4_wide_rows_flat_phases_are_not_quadratic(ctx, slr, oracle, synth):
+    """rows of 4097..8192 pixels take mf_match_wide_kernel, whose index has no dedup of equal phases -- a flat or saturated
+    row would make every query scan the whole row.  Rows with an overfull bin are now listed by that kernel and matched by the chunked
+    kernel (hash dedup) behind it: a frame of constant-phase rows must cost about what a frame of distinct phases costs (not W / 8
+    times more), and equal the oracle bit for bit on sampled rows."""
+    W, H = 8192, 1024
+    calib, _ = synth.make_calibration(W, H, with_T=False)
+    ctx.set_calibration(calib)
+    camL, camR, Q, T = calib_parts(oracle, calib)
+    ramp = (np.arange(W, dtype=np.float32) * np.float32(0.03) + np.float32(1.0))
+    distinct = [torch.from_numpy(np.tile(ramp, (H, 1))).cuda(), torch.from_numpy(np.tile(ramp + np.float32(0.01), (H, 1))).cuda()]
+    flatL = np.full((H, W), 12.55, np.float32); flatR = np.full((H, W), 12.5, np.float32)
+    flatR[1::2, ::2] = np.float32(77.0)                  # odd rows: two values, alternating columns (no equal neighbours inside a thread)
+    flatL[1::2, 1::3] = np.float32(77.05)
+    flat = [torch.from_numpy(flatL).cuda(), torch.from_numpy(flatR).cuda()]
+    ones = torch.ones((H, W), dtype=torch.uint8, device="cuda")
+
+    def timed(ph):
+        for _ in range(2):
+            out = ctx.mf_triangulate(ph[0], ones, ph[1], ones, want_match=True)
+        ctx.synchronize()
+        ctx.timer_begin()
+        for _ in range(3):
+            out = ctx.mf_triangulate(ph[0], ones, ph[1], ones, want_match=True)
+        return ctx.timer_end() / 3, out
+
+    t_distinct, _ = timed(distinct)
+    t_flat, (xyz, has, mk) = timed(flat)
+    print("wide K4, %d rows of %d: distinct phases %.3f ms, flat rows %.3f ms" % (H, W, t_distinct, t_flat))
+    assert t_flat < 6 * t_distinct + 0.5, (t_flat, t_distinct)
+    rows = [0, 1, 2, 511, 1023]
+    exyz, ehas, emk = oracle.mf_triangulate(flatL[rows], np.ones((len(rows), W), np.uint8), flatR[rows], np.ones((len(rows), W), np.uint8),
+                                            camL, camR, Q, T)
+    # (the oracle's rows are image rows 0..4 of its own frame: compare the match columns and masks; XYZ on row 0, which is row 0 in both)
+    assert bits_equal(np_of(mk)[rows], emk) and bits_equal(np_of(has)[rows], ehas)
+    assert bits_equal(np_of(xyz)[0], exyz[0])
+    assert (emk[0] == 0).all() and ehas[1].sum() > 0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # K5 lean
 # ---------------------------------------------------------------------------------------------------------

@@ -257,7 +257,11 @@ def test_gray_dma_counted_wait_form_equals_the_drained_form_and_the_oracle(dma_c
             for depth in (2, 1):
                 _opts(ctx, slr, 0, shape, depth)
                 ctx.set_rectify_maps(cam, mxn, mfn)
-                assert ctx.rectify_info(cam)["mf_form"] in (7, 5, 6)
+                # the maps of every case admit the LDS-DMA form (a fallback kernel would make the depth comparison vacuous); the
+                # counted-wait variant (A = 2) takes stacks of >= 4 phases, the (256, 40, 4) case is the explicit short-stack fallback
+                info = ctx.rectify_info(cam)
+                assert info["mf_form"] == 7 and info["dma_depth"] == depth, info
+                assert (1 + ncol + nrow >= 4) == ((W, H, scan_w) != (256, 40, 4))
                 cx, cy, v = ctx.gray_decode(dev, ncol, nrow, BLACK, 3, scan_w, scan_h, rectify_cam=cam)
                 ctx.synchronize()
                 assert bits_equal(np_of(v), ev) and bits_equal(np_of(cx), ex), (shape, depth, cam)
