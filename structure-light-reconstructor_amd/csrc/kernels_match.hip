@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(1024, 8) void mf_match_chunked_kernel(const float *
                                                                    const float2 *__restrict__ undL, const float *__restrict__ undRx,
                                                                    float *__restrict__ xyz,
                                                                    uint8_t *__restrict__ has, int32_t *__restrict__ match_k,
-                                                                   const int *__restrict__ defer = nullptr /* defer[0] rows listed behind it: only those */)
+                                                                   const int *__restrict__ defer /* null, or defer[0] rows listed behind it: only those */)
 {
     constexpr int BLOCK = 1024, IPT = 4, N = BLOCK * IPT;
     constexpr int TS = 2 * N;
@@ -2107,11 +2107,11 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
 #undef SLR_WIDE
             if (defer)                                   // the rows with an overfull bin (flat / saturated regions), usually none: workgroups beyond the count leave at once
                 SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
-                                   cal, vec_ok, undL, undRx, xyz, has, match_k, defer);
+                                   cal, vec_ok, undL, undRx, xyz, has, match_k, (const int *)defer);
         }
         else                                                 // wider rows: the right row in chunks of 4096 columns
             SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
-                               cal, vec_ok, undL, undRx, xyz, has, match_k);
+                               cal, vec_ok, undL, undRx, xyz, has, match_k, (const int *)nullptr);
 #undef SLR_SORTED
         return hipGetLastError();
     }
@@ -2120,7 +2120,7 @@ hipError_t launch_mf_match(const float *phaseL, const uint8_t *validL, const flo
                            ((uintptr_t)validL % 4 == 0) && ((uintptr_t)validR % 4 == 0) && ((uintptr_t)xyz % 16 == 0) &&
                            ((uintptr_t)has % 4 == 0) && (!match_k || (uintptr_t)match_k % 16 == 0));
         SLR_LAUNCH(mf_match_chunked_kernel, dim3(H), dim3(1024), 0, s, phaseL, validL, phaseR, validR, W, H, row0,
-                           cal, vec_ok, undL, undRx, xyz, has, match_k);
+                           cal, vec_ok, undL, undRx, xyz, has, match_k, (const int *)nullptr);
         return hipGetLastError();
     }
     const size_t lds = (size_t)((W + 3) & ~3) * sizeof(float);
