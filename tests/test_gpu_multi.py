@@ -256,9 +256,11 @@ def test_bench_config5_two_row_bands_with_a_collective_on_this_box():
     env = dict(os.environ, SLR_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for backend, port in (("nccl", "29543"), ("gloo", "29544")):
         env["SLR_BENCH_BACKEND"] = backend
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", port, os.path.join(ROOT, "bench.py"), "--mode", "mfn", "--gpus", "2", "--steps", "2", "--warmup", "1",
+        # (round 6: started BARE -- bench.py spawns its own two ranks under torch.distributed.run, --mode mfn included)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "mfn", "--gpus", "2", "--steps", "2", "--warmup", "1",
                "--frames", "1", "--width", "2048", "--height", "500"]
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
         if r.returncode == 0 and lines:
