@@ -195,6 +195,10 @@ public:
     std::string imgSuffix = ".png";
     std::string lastError;
     bool camerasLoaded = false;
+    // which GPU this reconstructor's contexts live on (set before the first run; default 0), and the share of the process's CPU
+    // budget its loader pool may take (1 / loaderShare: n reconstructors of a multi-GPU series divide the decoder threads)
+    int device = 0;
+    unsigned loaderShare = 1;
     slr_ctx *context() const { return ctx; }             // (for MeshCreator: export on the device the scan ran on)
 private:
     bool loadCameras();

@@ -2,8 +2,11 @@
 // the body of slr_cli.  duke_run_project mirrors MainWindow::startreconstruct (Duke/mainwindow.cpp:562-652).
 #include <string.h>
 
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "duke.hpp"
@@ -113,6 +116,70 @@ int duke_run_series(const char *project, int sn_first, int n_scans, int scan_w, 
     });
     set_err(err, err_len, ok ? "" : mfr.lastError);
     return done;
+    DUKE_GUARD_END(0, err, err_len)
+}
+
+// The same series over SEVERAL GPUs of the node from one process (SURVEY 8e + 8f-1: frames are independent, so a scan directory
+// shards by scan): scan sn_first + i runs on devices[i % n_devices] (device ordinals; an ordinal may repeat -- two pipelines on one
+// GPU).  One MFReconstruct per entry of `devices`, each on its own host thread with its own two contexts, page-locked slots and
+// 1 / n_devices of the decoder threads: every GPU has its own PCIe link, and the host-buffer path is PCIe-bound,
+// so n GPUs take n scans in the time one takes one -- as long as the CPUs inflate that fast.  Results land in the scan's slot of
+// pc_sum / pc_count and in <ply_prefix><sn>.ply exactly as duke_run_series writes them.  Returns the number of scans completed
+// (all devices together); on a failure `err` names the first one and the other pipelines finish the scans they already started.
+int duke_run_series_multi(const char *project, int sn_first, int n_scans, int scan_w, int scan_h, int cam_w, int cam_h, int black_thr,
+                          int white_thr, const char *suffix, const char *ply_prefix, const int *devices, int n_devices, float *pc_sum,
+                          uint8_t *pc_count, char *err, int err_len)
+{
+    DUKE_GUARD_BEGIN
+    if (!project || n_scans < 0 || cam_w <= 0 || cam_h <= 0 || scan_w <= 0 || scan_h <= 0 || (long long)cam_w * cam_h > (1ll << 28) ||
+        !devices || n_devices < 1 || n_devices > 64) {
+        set_err(err, err_len, "bad argument");
+        return 0;
+    }
+    for (int k = 0; k < n_devices; k++) if (devices[k] < 0) { set_err(err, err_len, "bad device ordinal"); return 0; }
+    const size_t cells = (size_t)scan_w * scan_h;
+    std::atomic<int> done(0);
+    std::mutex em;
+    std::string first_err;
+    auto pipeline = [&](int k) {
+        std::string my_err;
+        try {
+            MFReconstruct mfr;
+            mfr.device = devices[k];
+            mfr.loaderShare = (unsigned)n_devices;
+            if (suffix && *suffix) mfr.imgSuffix = suffix;
+            mfr.getParameters(sn_first, scan_w, scan_h, cam_w, cam_h, black_thr, white_thr, project);
+            std::vector<int> sns;
+            for (int i = k; i < n_scans; i += n_devices) sns.push_back(sn_first + i);
+            if (!mfr.camerasLoaded) my_err = "Load Calibration files failed.";
+            else if (!sns.empty()) {
+                slr_ctx *numbering = nullptr;                // the mesh export's vertex numbering runs on this pipeline's device too
+                if (ply_prefix && *ply_prefix && slr_create(devices[k], &numbering) != SLR_OK) numbering = nullptr;
+                const bool ok = mfr.runReconstructionSeries(sns, [&](int sn, PointCloudImage *pc) {
+                    std::unique_ptr<PointCloudImage> own(pc);
+                    const size_t i = (size_t)(sn - sn_first);
+                    if (pc_sum) memcpy(pc_sum + i * cells * 3, pc->points.data(), cells * 12);
+                    if (pc_count) memcpy(pc_count + i * cells, pc->numOfPointsForPixel.data(), cells);
+                    if (ply_prefix && *ply_prefix) {
+                        if (!numbering) return false;
+                        MeshCreator mc(pc, numbering);
+                        if (!mc.exportPlyMesh(std::string(ply_prefix) + std::to_string(sn) + ".ply")) return false;
+                    }
+                    done++;
+                    return true;
+                });
+                if (numbering) slr_destroy(numbering);
+                if (!ok) my_err = mfr.lastError.empty() ? "series stopped" : mfr.lastError;
+            }
+        } catch (const std::exception &e) { my_err = e.what(); } catch (...) { my_err = "unknown exception"; }
+        if (!my_err.empty()) { std::lock_guard<std::mutex> g(em); if (first_err.empty()) first_err = my_err; }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_devices; k++) th.emplace_back(pipeline, k);
+    pipeline(0);
+    for (auto &t : th) t.join();
+    set_err(err, err_len, first_err);
+    return done.load();
     DUKE_GUARD_END(0, err, err_len)
 }
 

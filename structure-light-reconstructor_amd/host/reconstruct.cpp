@@ -211,10 +211,10 @@ private:
     std::vector<std::thread> th_;
 };
 
-bool ensure_ctx(slr_ctx *&ctx, std::string &err)
+bool ensure_ctx(slr_ctx *&ctx, std::string &err, int device = 0)
 {
     if (ctx) return true;
-    const int st = slr_create(0, &ctx);
+    const int st = slr_create(device, &ctx);
     if (st != SLR_OK) { err = std::string("no GPU context: ") + slr_status_string(st); warn("Reconstruct", err); return false; }
     return true;
 }
@@ -438,9 +438,9 @@ bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, co
 {
     if (!camerasLoaded || !sr) { lastError = "calibration not loaded"; return false; }
     if (scan_sns.empty()) return true;
-    if (!ensure_ctx(ctx, lastError)) return false;
+    if (!ensure_ctx(ctx, lastError, device)) return false;
     const bool two = scan_sns.size() > 1;
-    if (two && !ensure_ctx(ctx2, lastError)) return false;
+    if (two && !ensure_ctx(ctx2, lastError, device)) return false;
     slr_ctx *cx[2] = {ctx, two ? ctx2 : ctx};
     sr->calParameters();
     if (sr->Q.empty()) { lastError = "stereo calibration files missing"; warn("Reconstruct", lastError); return false; }
@@ -453,7 +453,7 @@ bool MFReconstruct::runReconstructionSeries(const std::vector<int> &scan_sns, co
     // Input slots: page-locked buffers the pool inflates scans into AHEAD of the GPU.  One slot is being consumed (scan i - 1, on
     // the GPU) while the others are decoded or wait decoded; two scans ahead keep every worker busy across scan boundaries, a
     // third pays only where one scan's 2 n files cannot occupy the CPUs there are.
-    const unsigned cpus = loader_threads(1 << 20, two);
+    const unsigned cpus = std::max(1u, loader_threads(1 << 20, two) / std::max(1u, loaderShare));
     const int ahead = !two ? 1 : (cpus > (unsigned)(2 * 2 * n) ? 3 : 2);
     const int ns = two ? std::min(kInSlots, ahead + 1) : 1;
     if (!series) series = new SeriesBuffers();

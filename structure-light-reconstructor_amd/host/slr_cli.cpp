@@ -2,6 +2,7 @@
 // directory in the reference's layout, runs one reconstruction on the GPU and writes reconstruction/<sn>.ply.
 //   slr_cli <project> <mode: gray|grayepi|mf> [--sn N] [--scan W H] [--cam W H] [--black T] [--white T] [--color] [--suffix .png|.pgm]
 //           [--series K]   (mf only: scans N .. N+K-1, pipelined: PNG decode of the next scan overlaps the GPU work of this one)
+//           [--devices 0,1,..]   (with --series: the scans are dealt round-robin to these GPUs, one pipeline per entry)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -12,6 +13,8 @@ extern "C" int duke_run_project(const char *, int, int, int, int, int, int, int,
                                 unsigned char *, unsigned char *, char *, int);
 extern "C" int duke_run_series(const char *, int, int, int, int, int, int, int, int, const char *, const char *, float *,
                                unsigned char *, char *, int);
+extern "C" int duke_run_series_multi(const char *, int, int, int, int, int, int, int, int, const char *, const char *, const int *, int,
+                                     float *, unsigned char *, char *, int);
 
 int main(int argc, char **argv)
 {
@@ -24,6 +27,7 @@ int main(int argc, char **argv)
     // defaults: Duke/Set.ui (scan 1280x1024, camera 1280x1024, blackThreshold 40, whiteThreshold 0)
     int sn = 0, sw = 1280, sh = 1024, cw = 1280, chh = 1024, black = 40, white = 0, color = 0, series = 0;
     std::string suffix = ".png";
+    int devices[64], n_devices = 0;
     for (int i = 3; i < argc; i++) {
         if (!strcmp(argv[i], "--sn") && i + 1 < argc) sn = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--scan") && i + 2 < argc) { sw = atoi(argv[++i]); sh = atoi(argv[++i]); }
@@ -33,12 +37,18 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--color")) color = 1;
         else if (!strcmp(argv[i], "--series") && i + 1 < argc) series = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--suffix") && i + 1 < argc) suffix = argv[++i];
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+            for (char *tok = strtok(argv[++i], ","); tok && n_devices < 64; tok = strtok(NULL, ",")) devices[n_devices++] = atoi(tok);
+        }
     }
     char err[512] = "";
     if (series > 0 && mode == 2) {
         const std::string pre = project + "/reconstruction/";
-        const int done = duke_run_series(project.c_str(), sn, series, sw, sh, cw, chh, black, white, suffix.c_str(), pre.c_str(), NULL, NULL,
-                                         err, (int)sizeof err);
+        const int done = n_devices > 0
+            ? duke_run_series_multi(project.c_str(), sn, series, sw, sh, cw, chh, black, white, suffix.c_str(), pre.c_str(), devices, n_devices,
+                                    NULL, NULL, err, (int)sizeof err)
+            : duke_run_series(project.c_str(), sn, series, sw, sh, cw, chh, black, white, suffix.c_str(), pre.c_str(), NULL, NULL,
+                              err, (int)sizeof err);
         printf("wrote %d of %d meshes to %s<sn>.ply\n", done, series, pre.c_str());
         if (done != series) { fprintf(stderr, "series stopped: %s\n", err); return 1; }
         return 0;

@@ -473,6 +473,20 @@ def test_scan_series_is_pipelined_and_identical_to_single_scans(host, synth, tmp
     # a missing scan stops the series where the reference's loop would
     assert host.duke_run_series(proj.encode(), 2, 4, scan_w, scan_h, W, H, 40, 0, b".png", None, None, None, err, 512) == 2
     assert b"not found" in err.value
+    # round 6: the series over several pipelines ("devices" 0, 0, 0 on this one-GPU box: three reconstructors on three host threads,
+    # scans dealt round-robin): the same clouds and the same files
+    ms = np.zeros((n, scan_h, scan_w, 3), np.float32)
+    mc = np.zeros((n, scan_h, scan_w), np.uint8)
+    mpre = os.path.join(proj, "reconstruction", "m")
+    devs = (C.c_int * 3)(0, 0, 0)
+    assert host.duke_run_series_multi(proj.encode(), 0, n, scan_w, scan_h, W, H, 40, 0, b".png", mpre.encode(), devs, 3, _p(ms), _p(mc), err, 512) == n, err.value
+    assert np.array_equal(mc, sc) and bits_equal(ms, ss)
+    for sn in range(n):
+        assert open(mpre + "%d.ply" % sn).read() == open(pre + "%d.ply" % sn).read()
+    # a missing scan: the pipelines that meet it stop, the others finish theirs; the error is reported
+    done = host.duke_run_series_multi(proj.encode(), 2, 4, scan_w, scan_h, W, H, 40, 0, b".png", None, devs, 2, None, None, err, 512)
+    assert done == 2 and b"not found" in err.value
+    assert host.duke_run_series_multi(proj.encode(), 0, n, scan_w, scan_h, W, H, 40, 0, b".png", None, None, 0, None, None, err, 512) == 0
 
 
 @pytest.mark.gpu
