@@ -140,6 +140,7 @@ def parse_args():
     ap.add_argument("--match-algo", type=int, default=0, help="SLR_OPT_MF_MATCH_ALGO (tuning: 0 auto, 4 lean K4 with per-thread stores, 5 / 6 512 x 8 shapes, 7 persistent grouped K4: FORMS=all builds, 8 lean K4 with the hash dedup = round 5's kernel)")
     ap.add_argument("--dma-shape", type=int, default=-1, help="SLR_OPT_RECT_DMA_SHAPE (tuning: tile of the LDS-DMA form 7: 0 256x16/512thr, 1 256x8/512, 2 256x8/256, 3 128x16/512, 4 128x8/256, 5 256x4/256, 6 128x16/256)")
     ap.add_argument("--dma-depth", type=int, default=-1, help="SLR_OPT_RECT_DMA_DEPTH (tuning: 1 or 2 phases of LDS-DMA in flight)")
+    ap.add_argument("--rect-resident", type=int, default=0, help="SLR_OPT_DEBUG_RECT_RESIDENT (experiments: workgroups of the persistent fused decodes; 0 = as many as are resident)")
     ap.add_argument("--debug-flags", type=int, default=0,
                     help="SLR_OPT_DEBUG_FLAGS (A/B runs of forms with identical results, e.g. 32 = map digests without the quad sort)")
     ap.add_argument("--batch-streams", type=int, default=0,
@@ -923,6 +924,8 @@ def main():
             c_.set_option(slr.capi.OPT_BATCH_STREAMS, args.batch_streams)
         if args.debug_flags:
             c_.set_option(slr.capi.OPT_DEBUG_FLAGS, args.debug_flags)
+        if args.rect_resident:
+            c_.set_option(slr.capi.OPT_DEBUG_RECT_RESIDENT, args.rect_resident)
         if args.hybrid_one_pass:
             c_.set_option(slr.capi.OPT_HYBRID_ONE_PASS, 1)
         if args.eval_model == "x87":
