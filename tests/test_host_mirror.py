@@ -189,6 +189,61 @@ def test_png_decoder_rejects_what_it_cannot_trust(host, tmp_path):
     assert read(tmp_path / "cut.pgm", (10, 10))[0] == 0
 
 
+def test_png_and_pgm_codec_against_pillow(host, tmp_path):
+    """row f1's codec against an INDEPENDENT implementation (Pillow / libpng-free zlib PNG reader and writer of its own): files
+    Pillow writes (grey 8-bit at several compression settings, 16-bit grey, grey + alpha, RGB, palette-free RGBA, binary PGM)
+    decode here to what cv::imread(path, 0) gives -- grey as is, 16-bit by its high byte, colour by OpenCV's fixed-point grey
+    conversion -- and files this codec writes (PNG, Adam7-interlaced PNG, PGM) read back identically through Pillow."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(12)
+    w, h = C.c_int(0), C.c_int(0)
+
+    def read(path, shape):
+        out = np.zeros(shape, np.uint8)
+        rc = host.duke_imread(str(path).encode(), _p(out), out.size, C.byref(w), C.byref(h))
+        return rc, out
+
+    for (hh, ww) in ((37, 53), (1, 1), (64, 200), (301, 1000)):
+        smooth = (np.linspace(0, 255, ww)[None, :] * np.linspace(0.2, 1.0, hh)[:, None]).astype(np.uint8)
+        for img in (rng.integers(0, 256, size=(hh, ww), dtype=np.uint8), smooth):
+            for k, kw in enumerate(({"compress_level": 0}, {"compress_level": 1}, {"compress_level": 9}, {"optimize": True})):
+                path = tmp_path / ("pil_%d_%d_%d.png" % (hh, ww, k))
+                Image.fromarray(img, "L").save(path, **kw)
+                rc, out = read(path, img.shape)
+                assert rc == 1 and (w.value, h.value) == (ww, hh) and np.array_equal(out, img), (hh, ww, kw)
+            path = tmp_path / "pil.pgm"
+            Image.fromarray(img, "L").save(path)                                     # binary P5
+            rc, out = read(path, img.shape)
+            assert rc == 1 and np.array_equal(out, img)
+            # ... and the other way: what this codec writes, Pillow reads
+            for mode, name in ((1, "our.png"), (2, "our_adam7.png"), (0, "our.pgm")):
+                assert host.duke_imwrite(str(tmp_path / name).encode(), _p(np.ascontiguousarray(img)), ww, hh, mode) == 1
+                with Image.open(tmp_path / name) as im:
+                    assert im.mode == "L" and im.size == (ww, hh)
+                    if mode == 2:
+                        assert im.info.get("interlace") == 1
+                    assert np.array_equal(np.asarray(im), img), (hh, ww, name)
+    # 16-bit grey: the high byte (cv::imread's depth conversion)
+    g16 = rng.integers(0, 65536, size=(23, 31)).astype(np.uint16)
+    Image.fromarray(g16).save(tmp_path / "pil16.png")
+    rc, out = read(tmp_path / "pil16.png", g16.shape)
+    assert rc == 1 and np.array_equal(out, (g16 >> 8).astype(np.uint8))
+    # colour and alpha: OpenCV's BGR -> grey fixed point on the colour samples, alpha dropped
+    rgb = rng.integers(0, 256, size=(19, 27, 3), dtype=np.uint8)
+    exp = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "pilrgb.png")
+    rc, out = read(tmp_path / "pilrgb.png", exp.shape)
+    assert rc == 1 and np.array_equal(out, exp)
+    rgba = np.dstack([rgb, rng.integers(0, 256, size=(19, 27, 1), dtype=np.uint8)])
+    Image.fromarray(rgba, "RGBA").save(tmp_path / "pilrgba.png")
+    rc, out = read(tmp_path / "pilrgba.png", exp.shape)
+    assert rc == 1 and np.array_equal(out, exp)
+    la = np.dstack([rgb[..., 0], rgba[..., 3]])
+    Image.fromarray(la, "LA").save(tmp_path / "pilla.png")
+    rc, out = read(tmp_path / "pilla.png", exp.shape)
+    assert rc == 1 and np.array_equal(out, rgb[..., 0])
+
+
 def test_map_builder_matches_oracle(host, oracle):
     W, H = 96, 64
     M = np.array([[110.0, 0, 47.3], [0, 112.0, 31.8], [0, 0, 1]])
