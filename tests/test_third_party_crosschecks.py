@@ -91,3 +91,40 @@ def test_stereo_rectify_outputs_are_rotations_that_rectify():
         assert abs(t[1]) < 1e-9 * abs(t[0]) and abs(t[2]) < 1e-9 * abs(t[0])
         assert P1[1, 1] == P2[1, 1] and P1[1, 2] == P2[1, 2]                # same rows: fy and cy shared
         assert np.isclose(P2[0, 3], P2[0, 0] * t[0]) and np.isclose(Q[3, 2], -1.0 / t[0])
+
+
+def test_init_undistort_rectify_map_inverts_the_camera_model_by_root_finding():
+    """cv::initUndistortRectifyMap (stereorect.cpp:42-43; oracle/slr_oracle.c, bit-identical to the device builder): the map sends a
+    rectified pixel (u, v) to the raw pixel that sees the same ray.  Checked from the other side with a general-purpose solver:
+    scipy.optimize.root finds the UNDISTORTED normalised point whose Brown-Conrady distortion (the formula of OpenCV's documentation)
+    lands on the map's source pixel; rotated by R and projected by P it must give (u, v) again -- to the 1/32-pixel quantisation of
+    the CV_16SC2 + CV_16UC1 map pair."""
+    import oracle as O
+    optimize = pytest.importorskip("scipy.optimize")
+    W, H = 160, 120
+    Mx = np.array([[210.0, 0, 81.3], [0, 214.0, 58.9], [0, 0, 1]])
+    D = np.array([-0.21, 0.07, 1.5e-3, -9e-4, 0.012])
+    R = Rotation.from_rotvec([0.03, -0.05, 0.02]).as_matrix()
+    P = np.array([[200.0, 0, 80.0, 0], [0, 200.0, 60.0, 0], [0, 0, 1, 0]])
+    xy, fr = O.init_undistort_rectify_map(Mx, D, R, P, W, H)
+    sx = xy[..., 0] + (fr & 31) / 32.0
+    sy = xy[..., 1] + (fr >> 5) / 32.0
+
+    def distort(p):
+        x, y = p
+        r2 = x * x + y * y
+        kr = 1 + D[0] * r2 + D[1] * r2 * r2 + D[4] * r2 * r2 * r2
+        return np.array([x * kr + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x), y * kr + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y])
+
+    worst = 0.0
+    for v in range(3, H, 13):
+        for u in range(2, W, 11):
+            target = np.array([(sx[v, u] - Mx[0, 2]) / Mx[0, 0], (sy[v, u] - Mx[1, 2]) / Mx[1, 1]])
+            sol = optimize.root(lambda p: distort(p) - target, target, tol=1e-12)
+            assert np.abs(distort(sol.x) - target).max() < 1e-10
+            ray = R @ np.array([sol.x[0], sol.x[1], 1.0])              # the raw camera's ray in the rectified camera's frame
+            uu = P[0, 0] * ray[0] / ray[2] + P[0, 2]
+            vv = P[1, 1] * ray[1] / ray[2] + P[1, 2]
+            worst = max(worst, abs(uu - u), abs(vv - v))
+    # half a step of the 1/32 grid, magnified by the local scale of the map (focal ratio and distortion: < 1.2 here)
+    assert worst < 0.6 / 32 * 1.2 + 1e-6, worst
