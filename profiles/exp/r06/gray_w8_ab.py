@@ -1,5 +1,6 @@
 """Round 6 experiment: the fused Gray decode compiled for 8 waves per SIMD (SLR_OPT_DEBUG_FLAGS bit 9: four workgroups per CU) against the
-shipped form, same process, 4096x3000 GRAY_EPI stack on the verged rig: bit-equality of the whole-path outputs and per-kernel times."""
+shipped form (the experiment's kernel is NOT in the tree any more -- LABNOTES section 12 has its description and numbers; this
+script is the harness it was measured with), same process, 4096x3000 GRAY_EPI stack on the verged rig: bit-equality of the whole-path outputs and per-kernel times."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
